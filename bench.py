@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched LBP sweep (BASELINE.json metric) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (default): BASELINE.json configs[2] -- the configuration the metric string is quoted on
+("batch=8192 graphs |X|=64"): 8192 train_mp-shaped user graphs PER GPU (sentence of 10 words, 3
+predicted + 7 given => K3 of pairwise factors + 24 unary factors, train_mp.py:257-299), |X|=64,
+float64, a UNIQUE pairwise table per (graph, factor) so the update kernel is HBM-bound
+(SURVEY.md section 8(d)).  One *step* is what the reference does per instance between building the
+graph and reading the posterior: `initialize` + `treelike_inference(3)` (train_mp.py:381-382) +
+`get_posterior_probs` (train_mp.py:400), over the whole batch; with N > 1 the per-step statistics
+vector is all-reduced over RCCL like train_mp.py's accumulate callback (train_mp.py:405-424).
+One *iter* of the metric is one sweep (up + down pass, LBP.py:227-243) over every graph of the
+batch, so a step contributes `sweeps` iters.
+
+value = whole-job iters/s x (graphs per GPU / 8192) aggregated over GPUs -- i.e. sweeps of an
+8192-graph batch per second; with N GPUs the job holds N batches (weak scaling).
+
+Extra objects on the JSON line: `roofline` (dominant kernel = the fused sweep launch; achieved =
+algorithmic bytes / HIP-event time of that launch) and `cpu_baseline` (the CPU oracle -- a port of
+the reference's per-graph, per-message NumPy cost model -- timed on this box's host cores on a
+bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+
+HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def workload_spec(name):
+    import cases as C
+    if name == 'user_k3':
+        return C.user_spec(10, [1, 4, 7], 64, 64, seed=1), [1, 4, 7], 3, 1236
+    if name == 'chain8':
+        return C.chain_spec(8, 64), [0] * 10, 10, 1235
+    if name == 'ring8':
+        return C.ring_spec(8, 64), [0] * 10, 10, 1235
+    if name == 'ring8_x512':
+        return C.ring_spec(8, 512), [0] * 10, 10, 1238
+    raise SystemExit('unknown workload %s' % name)
+
+
+def algorithmic_bytes_per_graph(topo, roots, X, elem=8):
+    """pairwise update (X^2 + 2X) s; variable update (d+1) X s; unary 2X s."""
+    from macaronicusermodeling_amd import _ffi
+    total = 0
+    for r in roots:
+        ops, _ = topo.compile_sweep(r)
+        for kind, a, b, c in ops.tolist():
+            if kind in (_ffi.OP_PAIR_TM, _ffi.OP_PAIR_MT):
+                total += (X * X + 2 * X) * elem
+            elif kind == _ffi.OP_VAR:
+                total += (b + 1) * X * elem
+            else:
+                total += 2 * X * elem
+    return total
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = port of the reference's cost model).  Runs BEFORE any GPU initialisation.
+# ---------------------------------------------------------------------------------------------------
+def _cpu_worker(args):
+    spec, roots, seeds = args
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    import cases as C
+    from oracle import lbp_oracle as O
+    g = O.Graph(spec)
+    n = 0
+    for seed in seeds:
+        inputs = C.make_inputs(spec, seed, 'uniform')
+        t0 = time.perf_counter()
+        msgs = O.init_messages(g)
+        for r in roots:
+            O.sweep(g, inputs, msgs, r)
+        for v in g.var_order:
+            O.marginal(g, msgs, v)
+        n += 1
+    return n
+
+
+def cpu_baseline(workload, batch, budget_s=12.0):
+    import multiprocessing as mp
+    import cases as C
+    from oracle import lbp_oracle as O
+    spec, roots, sweeps, seed = workload_spec(workload)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 32))
+    # calibrate on one graph (input generation excluded from the timed part below by pre-warming)
+    g = O.Graph(spec)
+    inputs = C.make_inputs(spec, seed, 'uniform')
+    t0 = time.perf_counter()
+    msgs = O.init_messages(g)
+    for r in roots:
+        O.sweep(g, inputs, msgs, r)
+    t1 = max(time.perf_counter() - t0, 1e-4)
+    per_worker = max(2, min(int(budget_s / t1 / 2), 4096))     # inputs cost about as much as sweeps
+    jobs = [(spec, roots, list(range(seed + w * per_worker, seed + (w + 1) * per_worker))) for w in range(cores)]
+    ctx = mp.get_context('fork')
+    with ctx.Pool(cores) as pool:
+        t0 = time.perf_counter()
+        done = sum(pool.map(_cpu_worker, jobs))
+        wall = time.perf_counter() - t0
+    graph_sweeps_per_s = done * sweeps / wall
+    return {'value': graph_sweeps_per_s / batch, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d graphs x %d sweeps of the same workload (%s), oracle/lbp_oracle.py, one process per '
+                      'core, BLAS threads 1, %.1f s wall incl. synthetic input generation; value = graph-sweeps/s / %d'
+                      % (done, sweeps, workload, wall, batch),
+            'graph_sweeps_per_s': graph_sweeps_per_s}
+
+
+# ---------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'chain8', 'ring8', 'ring8_x512'])
+    ap.add_argument('--batch', type=int, default=8192, help='graphs per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--traffic-bytes', type=float, default=None,
+                    help='HBM bytes per sweep launch from a rocprofv3 --pmc pass (profiles/), if known')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (a.gpus, a.gpus))
+        raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, a.gpus))
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.workload, 8192)            # before the GPU is touched (fork safety)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from macaronicusermodeling_amd.batch import FactorGraphBatch
+    from macaronicusermodeling_amd.topology import GraphTopology
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the engine has no CPU path')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    spec, roots, sweeps, seed = workload_spec(a.workload)
+    X, B = spec['X'], a.batch
+    topo = GraphTopology.from_spec(spec)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed + 7919 * rank)
+    fb = FactorGraphBatch(topo, X, B, device=dev)
+    pair = torch.rand(B * topo.P, X, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
+    unary = torch.rand(B * topo.U, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
+    fb.set_pair_tables(pair)
+    fb.set_unary_tables(unary)
+    labels = np.tile(np.array(spec['labels']), (B, 1))
+    labels_d = torch.from_numpy(labels.astype(np.int32)).to(dev)
+    stats = torch.zeros(16, dtype=torch.float64, device=dev)
+    marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)
+    lp = torch.empty(B, dtype=torch.float64, device=dev)
+    import ctypes as C
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.batch import _stream_ptr
+
+    fb.initialize()
+    fb.is_loopy = True          # chain workloads: run real sweeps, tree short-circuit overridden (LBP.py:219)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def step(i=None):
+        fb.initialize()
+        fb.is_loopy = True
+        if i is not None:
+            ev[i][0].record()
+        fb.sweep(roots)
+        if i is not None:
+            ev[i][1].record()
+        fb.marginals(out=marg)
+        _ffi.check(_ffi.lib.mlbp_log_posterior_f64(marg.data_ptr(), labels_d.data_ptr(), B, topo.n_vars, X,
+                                                   lp.data_ptr(), _stream_ptr(dev)))
+        stats[0] = lp.sum()
+        if world > 1:
+            dist.all_reduce(stats)          # the outer-loop reduction of train_mp.py:405-424 (one per step)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert fb.program(roots).status() == 0
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        iters_per_s = world * (B / 8192.0) * sweeps * a.steps / elapsed
+        sweep_ms = sorted(s.elapsed_time(e) for s, e in ev)
+        avg_ms = sum(sweep_ms) / len(sweep_ms)
+        alg_bytes = algorithmic_bytes_per_graph(topo, roots, X) * B
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'LBP sweep iters/sec (whole node), batch=8192 graphs |X|=64',
+            'value': iters_per_s, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '%s: %d graphs/GPU, |X|=%d, P=%d pairwise + U=%d unary factors, unique f64 '
+                                   'table per (graph,factor), step = initialize + %d sweeps + posterior read-out'
+                                   % (a.workload, B, X, topo.P, topo.U, sweeps),
+                       'graphs_per_gpu': B, 'X': X, 'sweeps_per_step': sweeps, 'roots': list(roots),
+                       'graph_sweeps_per_s': world * B * sweeps * a.steps / elapsed,
+                       'parallelism': 'graphs sharded over %d GPU(s), no data-path collective' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': a.traffic_bytes,
+                         'kernel': 'sweep_x64_kernel' if X == 64 else 'sweep_generic_kernel',
+                         'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': avg_ms,
+                         'min_launch_ms': sweep_ms[0], 'max_launch_ms': sweep_ms[-1]},
+            'cpu_baseline': cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

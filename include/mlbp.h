@@ -1,0 +1,193 @@
+/*
+ * mlbp.h -- C ABI of libmlbp.so: the MI355X-native (gfx950) loopy-belief-propagation hot path.
+ *
+ * The reference (arendu-zz/MacaronicUserModeling) has no C ABI: its hot path sits behind two
+ * Python modules, `LBP.py` (FactorGraph / VariableNode / FactorNode) and the Cython extension
+ * `array_utils.c_array_utils`.  The entry points below are what a binding for that path would
+ * bind; each cites the reference interface it replaces (paths relative to the reference root).
+ * The Python mirror of the reference API (macaronicusermodeling_amd/LBP.py and
+ * macaronicusermodeling_amd/array_utils/c_array_utils.py) calls ONLY these functions, through
+ * ctypes; INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MLBP_E* code otherwise; the text of the last
+ *     error on the calling thread is available from mlbp_last_error();
+ *   - pointers documented "device" are HIP device addresses (e.g. torch tensor.data_ptr());
+ *     pointers documented "host" are ordinary process memory; the library never frees or
+ *     reallocates caller memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); device functions only
+ *     enqueue work and do not synchronise unless stated;
+ *   - all floating-point data is IEEE float64, the reference's dtype (LBP.py:4); integer data is
+ *     int32 unless stated; matrices are row-major;
+ *   - no CPU fallback exists: a device function on a machine without a gfx950 device fails with
+ *     MLBP_ENODEVICE.
+ */
+#ifndef MLBP_H
+#define MLBP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLBP_VERSION_MAJOR 0
+#define MLBP_VERSION_MINOR 1
+
+enum {
+  MLBP_OK = 0,
+  MLBP_EINVAL = -1,    /* bad argument (shape, index out of range, NULL pointer)                 */
+  MLBP_EHIP = -2,      /* a HIP runtime call failed                                              */
+  MLBP_ENODEVICE = -3, /* no gfx950 device visible                                               */
+  MLBP_ENOMEM = -4,    /* output buffer capacity too small (host functions)                      */
+  MLBP_EUNSUPPORTED = -5
+};
+
+/* ---------------------------------------------------------------------------------------------
+ * library info
+ * ------------------------------------------------------------------------------------------- */
+int mlbp_version(void);                 /* major*100 + minor                                     */
+const char* mlbp_arch(void);            /* "gfx950": the only code object in the library         */
+const char* mlbp_last_error(void);      /* thread-local, never NULL                              */
+int mlbp_device_count(void);            /* number of visible HIP devices, 0 if none (no error)   */
+
+/* ---------------------------------------------------------------------------------------------
+ * HOST integer logic (bit-exact with the reference; runs without a GPU)
+ *
+ * A topology describes one factor graph after FactorGraph.initialize() has sorted the factors by
+ * id (LBP.py:195-196).  Variables and factors are referred to by dense indices:
+ *   variable index v in [0, n_vars), factor index f in [0, n_factors) (id-sorted position).
+ * A *node* is encoded as: variable v -> v;  factor f -> n_vars + f.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mlbp_topology {
+  int32_t n_vars;
+  int32_t n_factors;
+  const int32_t* fac_nvars;   /* host [n_factors]   1 (unary) or 2 (pairwise); LBP.py:446-447     */
+  const int32_t* fac_var;     /* host [2*n_factors] variable index per VARSET position, -1 pad    */
+  const int32_t* fac_dim;     /* host [2*n_factors] table axis of that variable (var_id2dim)      */
+  const int32_t* var_fac_off; /* host [n_vars+1]    CSR offsets into var_fac                      */
+  const int32_t* var_fac;     /* host [..]          factor indices in FACSET (creation) order     */
+} mlbp_topology;
+
+/* FactorGraph.has_loops with an explicit root instead of the random.sample draw (LBP.py:174-190).
+ * Returns 1 / 0, or a negative error code. */
+int mlbp_has_loops(const mlbp_topology* t, int32_t root_var);
+
+/* FactorGraph.get_message_schedule (LBP.py:155-172).  Writes (child node, parent node) pairs in
+ * discovery order to pairs[2*i], pairs[2*i+1]; returns the number of pairs or MLBP_ENOMEM when
+ * cap_pairs is too small. */
+int mlbp_message_schedule(const mlbp_topology* t, int32_t root_var, int32_t* pairs, int32_t cap_pairs);
+
+/* Message-slot numbering used by every device function: factors in index order; a unary factor
+ * owns one slot (factor->variable); a pairwise factor owns, for each varset position k,
+ * slot (variable->factor) then slot (factor->variable) (the creation order of LBP.py:211-216).
+ * f2v[2*f+k] / v2f[2*f+k] receive the slot or -1.  pair_slot[f] / unary_slot[f] receive the
+ * factor's position among the pairwise / unary factors (or -1).  Returns n_msgs. */
+int mlbp_message_slots(const mlbp_topology* t, int32_t* f2v, int32_t* v2f, int32_t* pair_slot,
+                       int32_t* unary_slot);
+
+/* Operation list ("program") of one sweep of FactorGraph.treelike_inference rooted at root_var
+ * (LBP.py:223-243): the up pass over the reversed schedule then the down pass, updates whose
+ * destination is a unary factor dropped (LBP.py:228, 237).  Each op is 4 int32 words
+ * {kind, a, b, c}:
+ *   MLBP_OP_UNARY    a = unary slot                    c = dst message slot   (LBP.py:494-498)
+ *   MLBP_OP_PAIR_TM  a = pair slot  b = src msg slot   c = dst   out = T . m  (LBP.py:509)
+ *   MLBP_OP_PAIR_MT  a = pair slot  b = src msg slot   c = dst   out = m^T . T (LBP.py:518)
+ *   MLBP_OP_VAR      a = offset into srcs, b = count   c = dst   product of srcs (LBP.py:381-389)
+ * Returns the op count, or MLBP_ENOMEM; *n_srcs receives the number of srcs entries written. */
+enum { MLBP_OP_UNARY = 0, MLBP_OP_PAIR_TM = 1, MLBP_OP_PAIR_MT = 2, MLBP_OP_VAR = 3 };
+int mlbp_compile_sweep(const mlbp_topology* t, int32_t root_var, int32_t* ops, int32_t cap_ops,
+                       int32_t* srcs, int32_t cap_srcs, int32_t* n_srcs);
+
+/* ---------------------------------------------------------------------------------------------
+ * DEVICE: programs (validated, device-resident op lists)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mlbp_program mlbp_program;
+
+/* Validates every slot index of the host op list against (n_msgs, P, U), copies ops / srcs /
+ * sweep table to the device and returns an opaque handle.  sweeps[2*s], sweeps[2*s+1] = (first
+ * op, op count) of sweep s, so sweeps with equal roots can share their ops. */
+int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, int32_t n_srcs,
+                        const int32_t* sweeps, int32_t n_sweeps, int32_t n_msgs, int32_t P, int32_t U,
+                        mlbp_program** out);
+int mlbp_program_destroy(mlbp_program* p);
+
+/* Synchronising read-and-reset of the program's device status word: 0 = clean; 1 = a kernel skipped
+ * a graph because one of its table indices lay outside [0, n_*_tables) (instead of reading out of
+ * bounds); negative = error code. */
+int mlbp_program_status(const mlbp_program* p);
+
+/* ---------------------------------------------------------------------------------------------
+ * DEVICE: the batched sweep (the hot path)
+ *
+ * Runs program->n_sweeps sweeps of sum-product message passing on B independent graphs that
+ * share one topology / root sequence.  One workgroup owns one graph for the whole call; messages
+ * live on-chip between updates; pairwise tables are streamed from HBM.
+ * Replaces: FactorGraph.treelike_inference (LBP.py:218-245) with VariableNode.update_message_to
+ * (LBP.py:377-389), FactorNode.update_message_to (LBP.py:490-526), Message.renormalize
+ * (LBP.py:649-657), au.dense_dot / au.normalize / au.pointwise_multiply
+ * (c_array_utils.pyx:90-91, 29-40, 12-16).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct mlbp_sweep_args {
+  int32_t B;                  /* graphs                                                           */
+  int32_t X;                  /* states per variable (len(v.domain))                              */
+  int32_t n_pair_tables;      /* tables in pair_tables                                            */
+  int32_t n_unary_tables;     /* columns in unary_tables                                          */
+  const double* pair_tables;  /* device [n_pair_tables][X][X]                                     */
+  const int32_t* pair_tab;    /* device [B][P]  table index of pair slot p of graph b             */
+  const double* unary_tables; /* device [n_unary_tables][X]                                       */
+  const int32_t* unary_tab;   /* device [B][U]                                                    */
+  double* msgs;               /* device [B][n_msgs][X]  in/out                                    */
+  int32_t normalize_messages; /* FactorGraph.normalize_messages (LBP.py:41)                       */
+  int32_t reserved;
+} mlbp_sweep_args;
+
+int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
+
+/* Fills msgs[B][n_msgs][X] with 1/X: FactorGraph.initialize (LBP.py:211-216). */
+int mlbp_init_messages_f64(double* msgs, int64_t n_rows, int32_t X, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DEVICE: read-outs
+ * ------------------------------------------------------------------------------------------- */
+/* VariableNode.get_marginal for every variable of every graph (LBP.py:392-400):
+ * out[b][v] = renormalize(uniform * prod_k msgs[b][in_slots[in_off[v]+k]]), nan_to_num after each
+ * product.  in_off / in_slots are DEVICE int32 arrays ([n_vars+1], [..]) whose contents the
+ * caller guarantees to lie in [0, n_msgs). */
+int mlbp_marginals_f64(const double* msgs, int32_t B, int32_t n_msgs, int32_t X, int32_t n_vars,
+                       const int32_t* in_off, const int32_t* in_slots, int32_t normalize_messages,
+                       double* out, void* stream);
+
+/* FactorGraph.get_posterior_probs (LBP.py:247-259): out[b] = sum_v log(marg[b][v][label[b][v]]),
+ * -inf replaced by -99.99.  labels is a DEVICE int32 [B][n_vars] array. */
+int mlbp_log_posterior_f64(const double* marginals, const int32_t* labels, int32_t B, int32_t n_vars,
+                           int32_t X, double* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DEVICE: array primitives (the c_array_utils surface), batched over `batch` independent items
+ * ------------------------------------------------------------------------------------------- */
+/* au.dense_dot (c_array_utils.pyx:90-91): C[b] = A[b] (M x K) . B[b] (K x N), arbitrary element
+ * strides so transposed views (msg.m.T, LBP.py:518) are accepted. Strides are in ELEMENTS. */
+int mlbp_dense_dot_f64(int32_t batch, int32_t M, int32_t K, int32_t N,
+                       const double* A, int64_t a_batch, int64_t a_row, int64_t a_col,
+                       const double* B, int64_t b_batch, int64_t b_row, int64_t b_col,
+                       double* C, int64_t c_batch, int64_t c_row, void* stream);
+
+/* au.pointwise_multiply / au.dense_pointwise_multiply (c_array_utils.pyx:12-16, 93-94), with the
+ * optional nan_to_num of LBP.pointwise_multiply (LBP.py:728-729). Contiguous n elements. */
+int mlbp_pointwise_multiply_f64(const double* a, const double* b, double* out, int64_t n,
+                                int32_t nan_to_num, void* stream);
+
+/* au.normalize (c_array_utils.pyx:29-40) and Message.renormalize (LBP.py:649-657) over `batch`
+ * contiguous vectors of n elements: total > 0 -> x / total; otherwise
+ *   mode MLBP_NORM_ZERO    -> zeros   (au.normalize's m1.fill(0))
+ *   mode MLBP_NORM_UNIFORM -> 1/n     (Message.renormalize)
+ * positive[b] (device int32, may be NULL) receives 1 when the total was > 0. in may equal out. */
+enum { MLBP_NORM_ZERO = 0, MLBP_NORM_UNIFORM = 1 };
+int mlbp_normalize_f64(const double* in, double* out, int32_t batch, int64_t n, int32_t mode,
+                       int32_t* positive, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLBP_H */

@@ -1,0 +1,95 @@
+"""ctypes binding of libmlbp.so (include/mlbp.h).  The ONLY door from Python into the engine.
+
+There is no CPU fallback: if the shared library is missing the import fails loudly, and device
+entry points called on a machine without an MI355X return MLBP_ENODEVICE, raised as MlbpError.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libmlbp.so')
+
+MLBP_OK, MLBP_EINVAL, MLBP_EHIP, MLBP_ENODEVICE, MLBP_ENOMEM, MLBP_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+OP_UNARY, OP_PAIR_TM, OP_PAIR_MT, OP_VAR = 0, 1, 2, 3
+NORM_ZERO, NORM_UNIFORM = 0, 1
+
+
+class MlbpError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, 'libmlbp error %d: %s' % (code, msg))
+        self.code = code
+
+
+class Topology(C.Structure):
+    _fields_ = [('n_vars', C.c_int32), ('n_factors', C.c_int32),
+                ('fac_nvars', C.POINTER(C.c_int32)), ('fac_var', C.POINTER(C.c_int32)),
+                ('fac_dim', C.POINTER(C.c_int32)), ('var_fac_off', C.POINTER(C.c_int32)),
+                ('var_fac', C.POINTER(C.c_int32))]
+
+
+class SweepArgs(C.Structure):
+    _fields_ = [('B', C.c_int32), ('X', C.c_int32), ('n_pair_tables', C.c_int32),
+                ('n_unary_tables', C.c_int32), ('pair_tables', C.c_void_p), ('pair_tab', C.c_void_p),
+                ('unary_tables', C.c_void_p), ('unary_tab', C.c_void_p), ('msgs', C.c_void_p),
+                ('normalize_messages', C.c_int32), ('reserved', C.c_int32)]
+
+
+_i32p = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+_i32, _i64 = C.c_int32, C.c_int64
+
+# name -> (restype, argtypes); mirrors include/mlbp.h one to one (tests/test_abi.py checks that).
+SIGNATURES = {
+    'mlbp_version': (C.c_int, []),
+    'mlbp_arch': (C.c_char_p, []),
+    'mlbp_last_error': (C.c_char_p, []),
+    'mlbp_device_count': (C.c_int, []),
+    'mlbp_has_loops': (C.c_int, [C.POINTER(Topology), _i32]),
+    'mlbp_message_schedule': (C.c_int, [C.POINTER(Topology), _i32, _i32p, _i32]),
+    'mlbp_message_slots': (C.c_int, [C.POINTER(Topology), _i32p, _i32p, _i32p, _i32p]),
+    'mlbp_compile_sweep': (C.c_int, [C.POINTER(Topology), _i32, _i32p, _i32, _i32p, _i32, _i32p]),
+    'mlbp_program_create': (C.c_int, [_i32p, _i32, _i32p, _i32, _i32p, _i32, _i32, _i32, _i32,
+                                      C.POINTER(_vp)]),
+    'mlbp_program_destroy': (C.c_int, [_vp]),
+    'mlbp_program_status': (C.c_int, [_vp]),
+    'mlbp_sweep_f64': (C.c_int, [_vp, C.POINTER(SweepArgs), _vp]),
+    'mlbp_init_messages_f64': (C.c_int, [_vp, _i64, _i32, _vp]),
+    'mlbp_marginals_f64': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    'mlbp_log_posterior_f64': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'mlbp_dense_dot_f64': (C.c_int, [_i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _vp, _i64, _i64,
+                                     _i64, _vp, _i64, _i64, _vp]),
+    'mlbp_pointwise_multiply_f64': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    'mlbp_normalize_f64': (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libmlbp.so not found at %s.  Build it with `python -m macaronicusermodeling_amd.build` '
+            '(hipcc, gfx950).  There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    return lib.mlbp_last_error().decode('utf-8', 'replace')
+
+
+def check(rc):
+    """Raises MlbpError for negative return codes; returns rc otherwise."""
+    if rc < 0:
+        raise MlbpError(rc, last_error())
+    return rc
+
+
+def i32ptr(arr):
+    """numpy int32 C-contiguous array -> POINTER(c_int32)."""
+    return arr.ctypes.data_as(_i32p)

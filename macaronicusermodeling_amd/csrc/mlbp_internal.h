@@ -1,0 +1,26 @@
+// Internal declarations shared by the host (mlbp_host.cpp) and device (mlbp_*.hip) translation
+// units of libmlbp.so.  Not part of the ABI.
+#ifndef MLBP_INTERNAL_H
+#define MLBP_INTERNAL_H
+
+#include "../../include/mlbp.h"
+
+namespace mlbp {
+// Records a printf-style message for mlbp_last_error() and returns `code`.
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+}  // namespace mlbp
+
+// Device-resident, validated op list (see mlbp_program_create).
+struct mlbp_program {
+  int32_t n_ops, n_srcs, n_sweeps, n_msgs, P, U;
+  int32_t n_pairseq;      // pair ops over all sweeps, in execution order
+  int32_t max_srcs;       // largest MLBP_OP_VAR fan-in
+  int32_t* d_ops;         // [n_ops][4]
+  int32_t* d_srcs;        // [n_srcs]
+  int32_t* d_sweeps;      // [n_sweeps][2]
+  int32_t* d_pairseq;     // [n_pairseq + 1] pair slot of the k-th executed pair op (-1 terminated)
+  int32_t* d_status;      // [1] set non-zero by a kernel that met an out-of-range table index
+  int device;
+};
+
+#endif

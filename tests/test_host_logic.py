@@ -1,0 +1,120 @@
+"""Host-side integer logic of libmlbp.so (C++), bit-exact against reference-generated fixtures.
+Runs without a GPU."""
+import numpy as np
+import pytest
+
+import cases as C
+from conftest import load_golden
+from macaronicusermodeling_amd import _ffi
+from macaronicusermodeling_amd.topology import GraphTopology
+from oracle import lbp_oracle as O
+
+
+def _encode(topo, pairs):
+    out = []
+    for a, b in pairs:
+        row = []
+        for n in (a, b):
+            name = topo.node_name(n)
+            row += list(C.node_code(name))
+        out.append(row)
+    return np.array(out, dtype=np.int64).reshape(-1, 4)
+
+
+def test_schedules_and_loop_test_match_reference_fixtures():
+    gold = load_golden('schedules')
+    n = 0
+    for spec in C.schedule_topologies():
+        topo = GraphTopology.from_spec(spec)
+        for vid in topo.var_ids:
+            assert topo.has_loops(vid) == bool(gold['%s/loops_root%d' % (spec['name'], vid)])
+            np.testing.assert_array_equal(_encode(topo, topo.message_schedule(vid)),
+                                          gold['%s/sched_root%d' % (spec['name'], vid)])
+            n += 1
+    assert n == len([k for k in gold.files if '/sched_' in k])
+
+
+@pytest.mark.parametrize('case', C.inference_cases(), ids=lambda c: c['name'])
+def test_case_schedules(case):
+    gold = load_golden(case['name'])
+    topo = GraphTopology.from_spec(case['spec'])
+    assert topo.has_loops(case['roots'][0]) == bool(gold['is_loopy'])
+    for r in sorted(set(case['roots'])):
+        np.testing.assert_array_equal(_encode(topo, topo.message_schedule(r)), gold['sched_root%d' % r])
+    assert topo.slot_keys() == C.msg_keys(case['spec'])
+    np.testing.assert_array_equal(np.array(topo.var_ids), gold['var_order'])
+
+
+def _oracle_ops(spec, root):
+    """The op list implied by the oracle's own schedule walk, for comparison with the compiler."""
+    g = O.Graph(spec)
+    topo = GraphTopology.from_spec(spec)
+    slot = {k: i for i, k in enumerate(C.msg_keys(spec))}
+    ops = []
+    sched = O.message_schedule(g, root)
+    sends = [(c, p) for c, p in reversed(sched)] + [(p, c) for c, p in sched]
+    pair_ids = [f['id'] for f in g.factors if len(f['vars']) == 2]
+    unary_ids = [f['id'] for f in g.factors if len(f['vars']) == 1]
+    for frm, to in sends:
+        if to[0] == O.FAC and len(g.by_id[to[1]]['vars']) < 2:
+            continue
+        if frm[0] == O.VAR:
+            srcs = [slot['F_%d' % f, 'X_%d' % frm[1]] for f in g.facset[frm[1]] if f != to[1]]
+            ops.append(('var', tuple(srcs), slot['X_%d' % frm[1], 'F_%d' % to[1]]))
+        else:
+            f = g.by_id[frm[1]]
+            dst = slot['F_%d' % f['id'], 'X_%d' % to[1]]
+            if len(f['vars']) == 1:
+                ops.append(('unary', unary_ids.index(f['id']), dst))
+            else:
+                other = [u for u in f['vars'] if u != to[1]][0]
+                kind = 'tm' if g.dim_of(f, other) == 1 else 'mt'
+                ops.append((kind, pair_ids.index(f['id']), slot['X_%d' % other, 'F_%d' % f['id']], dst))
+    return ops
+
+
+@pytest.mark.parametrize('spec', C.schedule_topologies() + [c['spec'] for c in C.inference_cases()[:9]],
+                         ids=lambda s: s['name'])
+def test_compiled_sweep_equals_oracle_walk(spec):
+    topo = GraphTopology.from_spec(spec)
+    for root in topo.var_ids:
+        ops, srcs = topo.compile_sweep(root)
+        got = []
+        for kind, a, b, c in ops.tolist():
+            if kind == _ffi.OP_VAR:
+                got.append(('var', tuple(srcs[a:a + b].tolist()), c))
+            elif kind == _ffi.OP_UNARY:
+                got.append(('unary', a, c))
+            else:
+                got.append(('tm' if kind == _ffi.OP_PAIR_TM else 'mt', a, b, c))
+        assert got == _oracle_ops(spec, root)
+
+
+def test_update_counts_per_sweep():
+    """per sweep exactly 2P pairwise f->v, U unary f->v, 2P v->f."""
+    for spec in (C.chain_spec(8, 4), C.ring_spec(8, 4), C.user_spec(10, [1, 4, 7], 4, 4)):
+        topo = GraphTopology.from_spec(spec)
+        ops, _ = topo.compile_sweep(topo.var_ids[0])
+        kinds = ops[:, 0]
+        assert ((kinds == _ffi.OP_PAIR_TM) | (kinds == _ffi.OP_PAIR_MT)).sum() == 2 * topo.P
+        assert (kinds == _ffi.OP_UNARY).sum() == topo.U
+        assert (kinds == _ffi.OP_VAR).sum() == 2 * topo.P
+
+
+def test_program_concatenation_shares_equal_roots():
+    topo = GraphTopology.from_spec(C.ring_spec(8, 4))
+    ops, srcs, sweeps = topo.compile_program([0, 3, 0, 0])
+    one, _ = topo.compile_sweep(0)
+    assert len(ops) == 2 * len(one)
+    assert sweeps.tolist() == [[0, len(one)], [len(one), len(one)], [0, len(one)], [0, len(one)]]
+
+
+def test_bad_topologies_are_rejected():
+    with pytest.raises(NotImplementedError):
+        GraphTopology([(0, [0, 1, 2], [0, 1, 2])])
+    with pytest.raises(_ffi.MlbpError):
+        GraphTopology([(0, [0, 1], [0, 0])])
+    with pytest.raises(_ffi.MlbpError):
+        GraphTopology([(0, [0, 0], [0, 1])])
+    with pytest.raises(ValueError):
+        GraphTopology([(0, [0], [0]), (0, [1], [0])])

@@ -98,7 +98,7 @@ def cpu_baseline(workload, batch, budget_s=12.0):
     from oracle import lbp_oracle as O
     spec, roots, sweeps, seed = workload_spec(workload)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 32))
+    cores = max(1, min(cores, 16))   # a 1-GPU box's CPU share
     # calibrate on one graph (input generation excluded from the timed part below by pre-warming)
     g = O.Graph(spec)
     inputs = C.make_inputs(spec, seed, 'uniform')
@@ -171,7 +171,7 @@ def main():
     unary = torch.rand(B * topo.U, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
     fb.set_pair_tables(pair)
     fb.set_unary_tables(unary)
-    labels = np.tile(np.array(spec['labels']), (B, 1))
+    labels = np.tile(np.array([dict(zip(spec['var_ids'], spec['labels']))[v] for v in topo.var_ids]), (B, 1))
     labels_d = torch.from_numpy(labels.astype(np.int32)).to(dev)
     stats = torch.zeros(16, dtype=torch.float64, device=dev)
     marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)

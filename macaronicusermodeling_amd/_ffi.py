@@ -68,6 +68,11 @@ def _load():
         raise ImportError(
             'libmlbp.so not found at %s.  Build it with `python -m macaronicusermodeling_amd.build` '
             '(hipcc, gfx950).  There is no CPU fallback.' % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7; libmlbp.so must share THAT runtime instance (device
+    # pointers and streams cross the boundary), so torch's copy has to be the one already mapped
+    # when the loader resolves libmlbp's NEEDED entry.  Loading in the other order leaves two HIP
+    # runtimes in the process and ours sees no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = header / library mismatch

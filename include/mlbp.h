@@ -187,6 +187,42 @@ enum { MLBP_NORM_ZERO = 0, MLBP_NORM_UNIFORM = 1 };
 int mlbp_normalize_f64(const double* in, double* out, int32_t batch, int64_t n, int32_t mode,
                        int32_t* positive, void* stream);
 
+/* Top-K selection used by the reference's approximate ("sparse") primitives, K = 100
+ * (c_array_utils.pyx:118,194; np.argpartition(-v, K-1)[:K]).  Writes the indices of the K largest
+ * entries of the strided vector v to idx (device int32 [K]) in descending value order, ties broken
+ * by lower index (the reference leaves tie order unspecified).  K > n fails with MLBP_EINVAL and the
+ * text of NumPy's error, "kth(=K-1) out of bounds (n)". */
+int mlbp_topk_f64(const double* v, int64_t stride, int32_t n, int32_t K, int32_t* idx, void* stream);
+
+/* au.sparse_vec_mat_dot (c_array_utils.pyx:193-205) given the selected indices:
+ *   vec_is_row = 0: out[i] = sum_q mat[i][idx[q]] * vec[idx[q]]     (mat[:, idx] . vec[idx])
+ *   vec_is_row = 1: out[j] = sum_q vec[idx[q]] * mat[idx[q]][j]     (vec[0, idx] . mat[idx, :])
+ * mat strides in elements. */
+int mlbp_sparse_vec_mat_dot_f64(const double* vec, int64_t vstride, const double* mat, int64_t m_row, int64_t m_col,
+                                int32_t n_out, const int32_t* idx, int32_t K, int32_t vec_is_row, double* out,
+                                void* stream);
+
+/* au.sparse_dot (c_array_utils.pyx:117-129): out (n x n, fully written) = zeros with the
+ * (cidx x ridx) block set to c[i] * r[j]. */
+int mlbp_sparse_dot_f64(const double* c, const double* r, int32_t n, const int32_t* cidx, const int32_t* ridx,
+                        int32_t K, double* out, void* stream);
+
+/* au.sparse_pointwise_multiply (c_array_utils.pyx:108-114): out = zeros, block = sparse_m * dense_m. */
+int mlbp_sparse_pointwise_multiply_f64(const double* sparse_m, const double* dense_m, int32_t n_rows, int32_t n_cols,
+                                       const int32_t* cidx, int32_t Kc, const int32_t* ridx, int32_t Kr, double* out,
+                                       void* stream);
+
+/* au.sparse_normalize (c_array_utils.pyx:23-26): divides the block by its own sum IN PLACE (no
+ * zero-sum guard, like the reference).  scratch1: device double[1]. */
+int mlbp_sparse_normalize_f64(double* m, int32_t n_cols, const int32_t* cidx, int32_t Kc, const int32_t* ridx,
+                              int32_t Kr, double* scratch1, void* stream);
+
+/* Elementwise natural log (np.log at LBP.py:139, 252, 408, 411: log-marginal read-outs). */
+int mlbp_log_f64(const double* in, double* out, int64_t n, void* stream);
+
+/* FactorNode.cell_gradient (LBP.py:615-619): out = onehot(cell) - beliefs over n contiguous cells. */
+int mlbp_observed_minus_f64(const double* beliefs, int64_t n, int64_t cell, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,87 @@ __global__ __launch_bounds__(256) void normalize_kernel(const double* in, double
   if (positive && threadIdx.x == 0) positive[blockIdx.x] = pos ? 1 : 0;
 }
 
+// Rank-select of the K largest entries of v[0..n) (ties: lower index first).  One workgroup;
+// rank_i = #{j : v_j > v_i or (v_j == v_i and j < i)}; entries with rank < K are written to
+// idx[rank], i.e. in descending value order.  O(n^2 / 256) compares per thread -- n is a vocabulary
+// size (hundreds to a few thousand).  NaNs compare false everywhere and rank first among equals;
+// the reference's np.argpartition leaves their place unspecified.
+__global__ __launch_bounds__(256) void topk_kernel(const double* v, int64_t stride, int n, int K, int32_t* idx) {
+  extern __shared__ double sv[];
+  for (int i = threadIdx.x; i < n; i += 256) sv[i] = v[(int64_t)i * stride];
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double x = sv[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const double y = sv[j];
+      rank += (y > x) || (y == x && j < i);
+    }
+    if (rank < K) idx[rank] = i;
+  }
+}
+
+// au.sparse_vec_mat_dot (c_array_utils.pyx:193-205) after the top-K selection:
+//   vec_is_row = 0: out_i = sum_{k in idx} mat[i][k] * vec[k]      (mat[:, idx] . vec[idx])
+//   vec_is_row = 1: out_j = sum_{k in idx} vec[k] * mat[k][j]      (vec[0, idx] . mat[idx, :])
+__global__ void gather_dot_kernel(const double* vec, int64_t vstride, const double* mat, int64_t mrow, int64_t mcol,
+                                  int n_out, const int32_t* idx, int K, int vec_is_row, double* out) {
+  int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  double acc = 0.0;
+  for (int q = 0; q < K; ++q) {
+    const int k = idx[q];
+    const double m = vec_is_row ? mat[(int64_t)k * mrow + (int64_t)o * mcol] : mat[(int64_t)o * mrow + (int64_t)k * mcol];
+    acc += vec_is_row ? vec[(int64_t)k * vstride] * m : m * vec[(int64_t)k * vstride];
+  }
+  out[o] = acc;
+}
+
+__global__ void zero_kernel(double* p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.0;
+}
+
+// Block (cidx x ridx) operations on an n_rows x n_cols row-major matrix.
+//   mode 0: out[ci][rj] = c[ci] * r[rj]                 (au.sparse_dot, pyx:128)
+//   mode 1: out[ci][rj] = a[ci][rj] * b[ci][rj]         (au.sparse_pointwise_multiply, pyx:113)
+//   mode 2: out[ci][rj] = a[ci][rj] / *total            (au.sparse_normalize, pyx:25)
+__global__ void block_op_kernel(int mode, const double* a, const double* b, const double* total, int n_cols,
+                                const int32_t* cidx, int Kc, const int32_t* ridx, int Kr, double* out) {
+  const int n = Kc * Kr;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    const int i = cidx[e / Kr], j = ridx[e % Kr];
+    const int64_t at = (int64_t)i * n_cols + j;
+    double v;
+    if (mode == 0) v = a[i] * b[j];
+    else if (mode == 1) v = a[at] * b[at];
+    else v = a[at] / *total;
+    out[at] = v;
+  }
+}
+
+// total = sum of the (cidx x ridx) block; one workgroup (au.sparse_normalize, pyx:24).
+__global__ __launch_bounds__(256) void block_sum_kernel(const double* a, int n_cols, const int32_t* cidx, int Kc,
+                                                        const int32_t* ridx, int Kr, double* total) {
+  __shared__ double part[4];
+  double acc = 0.0;
+  for (int e = threadIdx.x; e < Kc * Kr; e += 256) acc += a[(int64_t)cidx[e / Kr] * n_cols + ridx[e % Kr]];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *total = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ void log_kernel(const double* in, double* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = log(in[i]);
+}
+
+// out = onehot(cell) - beliefs  (FactorNode.cell_gradient, LBP.py:615-619).
+__global__ void observed_minus_kernel(const double* beliefs, int64_t n, int64_t cell, double* out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (i == cell ? 1.0 : 0.0) - beliefs[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -139,6 +220,93 @@ int mlbp_normalize_f64(const double* in, double* out, int32_t batch, int64_t n, 
     return fail(MLBP_EINVAL, "mlbp_normalize_f64: bad arguments");
   if (int e = need_device()) return e;
   hipLaunchKernelGGL(normalize_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, in, out, n, mode, positive);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_topk_f64(const double* v, int64_t stride, int32_t n, int32_t K, int32_t* idx, void* stream) {
+  if (!v || !idx || n <= 0 || K <= 0) return fail(MLBP_EINVAL, "mlbp_topk_f64: bad arguments");
+  if (K > n) return fail(MLBP_EINVAL, "kth(=%d) out of bounds (%d)", K - 1, n);   // np.argpartition's ValueError text
+  if (n > 16384) return fail(MLBP_EUNSUPPORTED, "mlbp_topk_f64: n=%d > 16384", n);
+  if (int e = need_device()) return e;
+  size_t lds = (size_t)n * sizeof(double);
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, v, stride, n, K, idx);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_sparse_vec_mat_dot_f64(const double* vec, int64_t vstride, const double* mat, int64_t m_row, int64_t m_col,
+                                int32_t n_out, const int32_t* idx, int32_t K, int32_t vec_is_row, double* out,
+                                void* stream) {
+  if (!vec || !mat || !idx || !out || n_out <= 0 || K <= 0)
+    return fail(MLBP_EINVAL, "mlbp_sparse_vec_mat_dot_f64: bad arguments");
+  if (int e = need_device()) return e;
+  hipLaunchKernelGGL(gather_dot_kernel, dim3((n_out + 127) / 128), dim3(128), 0, (hipStream_t)stream, vec, vstride, mat,
+                     m_row, m_col, n_out, idx, K, vec_is_row, out);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+static int launch_block_op(int mode, const double* a, const double* b, const double* total, int n_cols,
+                           const int32_t* cidx, int Kc, const int32_t* ridx, int Kr, double* out, void* stream) {
+  int n = Kc * Kr;
+  int blocks = (n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096;
+  hipLaunchKernelGGL(block_op_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mode, a, b, total, n_cols, cidx,
+                     Kc, ridx, Kr, out);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+static int launch_zero(double* p, int64_t n, void* stream) {
+  int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_sparse_dot_f64(const double* c, const double* r, int32_t n, const int32_t* cidx, const int32_t* ridx,
+                        int32_t K, double* out, void* stream) {
+  if (!c || !r || !cidx || !ridx || !out || n <= 0 || K <= 0) return fail(MLBP_EINVAL, "mlbp_sparse_dot_f64: bad arguments");
+  if (int e = need_device()) return e;
+  if (int e = launch_zero(out, (int64_t)n * n, stream)) return e;
+  return launch_block_op(0, c, r, nullptr, n, cidx, K, ridx, K, out, stream);
+}
+
+int mlbp_sparse_pointwise_multiply_f64(const double* sparse_m, const double* dense_m, int32_t n_rows, int32_t n_cols,
+                                       const int32_t* cidx, int32_t Kc, const int32_t* ridx, int32_t Kr, double* out,
+                                       void* stream) {
+  if (!sparse_m || !dense_m || !cidx || !ridx || !out || n_rows <= 0 || n_cols <= 0 || Kc <= 0 || Kr <= 0)
+    return fail(MLBP_EINVAL, "mlbp_sparse_pointwise_multiply_f64: bad arguments");
+  if (int e = need_device()) return e;
+  if (int e = launch_zero(out, (int64_t)n_rows * n_cols, stream)) return e;
+  return launch_block_op(1, sparse_m, dense_m, nullptr, n_cols, cidx, Kc, ridx, Kr, out, stream);
+}
+
+int mlbp_sparse_normalize_f64(double* m, int32_t n_cols, const int32_t* cidx, int32_t Kc, const int32_t* ridx,
+                              int32_t Kr, double* scratch1, void* stream) {
+  if (!m || !cidx || !ridx || !scratch1 || n_cols <= 0 || Kc <= 0 || Kr <= 0)
+    return fail(MLBP_EINVAL, "mlbp_sparse_normalize_f64: bad arguments");
+  if (int e = need_device()) return e;
+  hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, m, n_cols, cidx, Kc, ridx, Kr, scratch1);
+  HIP_TRY(hipGetLastError());
+  return launch_block_op(2, m, nullptr, scratch1, n_cols, cidx, Kc, ridx, Kr, m, stream);
+}
+
+int mlbp_log_f64(const double* in, double* out, int64_t n, void* stream) {
+  if (!in || !out || n <= 0) return fail(MLBP_EINVAL, "mlbp_log_f64: bad arguments");
+  if (int e = need_device()) return e;
+  int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(log_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, n);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_observed_minus_f64(const double* beliefs, int64_t n, int64_t cell, double* out, void* stream) {
+  if (!beliefs || !out || n <= 0 || cell < 0 || cell >= n) return fail(MLBP_EINVAL, "mlbp_observed_minus_f64: bad arguments");
+  if (int e = need_device()) return e;
+  int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(observed_minus_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, beliefs, n, cell, out);
   HIP_TRY(hipGetLastError());
   return MLBP_OK;
 }

@@ -14,11 +14,13 @@ from . import _ffi
 
 
 class GraphTopology:
-    def __init__(self, factors, var_ids=None):
+    def __init__(self, factors, var_ids=None, facsets=None):
         """factors: iterable of (factor_id, [var ids in varset order], [table axis per var]) in
         CREATION order (the order `add_varset_with_potentials` was called: it fixes each
         variable's facset order, LBP.py:449-452).  var_ids: optional explicit variable order (the
-        insertion order of FactorGraph.variables); defaults to first appearance."""
+        insertion order of FactorGraph.variables); defaults to first appearance.  facsets: optional
+        {var id: [factor ids]} giving each variable's neighbour order explicitly (the object API
+        passes VariableNode.facset); defaults to creation order."""
         factors = [(int(fid), [int(v) for v in vs], [int(d) for d in ds]) for fid, vs, ds in factors]
         if not factors:
             raise ValueError('a graph needs at least one factor (LBP.py:194)')
@@ -47,10 +49,14 @@ class GraphTopology:
             for k, (v, d) in enumerate(zip(vs, ds)):
                 self.fac_var[2 * j + k] = self.var_index[v]
                 self.fac_dim[2 * j + k] = d
-        facsets = [[] for _ in range(n)]
-        for fid, vs, _ in factors:                                   # creation order
-            for v in vs:
-                facsets[self.var_index[v]].append(self.factor_index[fid])
+        if facsets is None:
+            fs = [[] for _ in range(n)]
+            for fid, vs, _ in factors:                               # creation order
+                for v in vs:
+                    fs[self.var_index[v]].append(self.factor_index[fid])
+        else:
+            fs = [[self.factor_index[int(fid)] for fid in facsets[v]] for v in self.var_ids]
+        facsets = fs
         self.facsets = facsets
         self.var_fac_off = np.zeros(n + 1, dtype=np.int32)
         self.var_fac_off[1:] = np.cumsum([len(s) for s in facsets])

@@ -1,0 +1,192 @@
+"""The drop-in object API (macaronicusermodeling_amd.LBP) driven through exactly the calls the
+generator made on the reference, compared with the reference's recorded outputs.  These tests read
+like the reference's own usage: build_graph() is shared with tests/golden/make_golden.py."""
+import types
+
+import numpy as np
+import pytest
+
+import cases as C
+from conftest import load_golden
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+class Roots:
+    def __init__(self, L):
+        self.queue = []
+        L.random = types.SimpleNamespace(sample=self.sample)
+
+    def sample(self, population, k):
+        r = self.queue.pop(0)
+        assert r in population
+        return [r]
+
+
+@pytest.fixture()
+def L():
+    import importlib
+    import macaronicusermodeling_amd.LBP as mod
+    mod = importlib.reload(mod)
+    return mod
+
+
+def _stack(fg, keys):
+    return np.stack([fg.messages[k].m.reshape(-1) for k in keys])
+
+
+def _run(L, case, approx=False):
+    spec = case['spec']
+    gold = load_golden(case['name'])
+    inputs = C.make_inputs(spec, case['seed'], case['kind'] or 'uniform')
+    roots = Roots(L)
+    fg = C.build_graph(L, spec, inputs)
+    fg.learning_rate = 0.05
+    fg.regularization_param = 0.2 / 17.0
+    if approx:
+        fg.use_approx_inference = True
+        fg.use_approx_beliefs = True
+    keys = C.msg_keys(spec)
+    roots.queue = [case['roots'][0]]
+    fg.initialize()
+    assert bool(fg.isLoopy) == bool(gold['is_loopy'])
+    assert sorted(fg.messages.keys()) == sorted(keys)
+    np.testing.assert_array_equal(_stack(fg, keys), gold['msgs_init'])
+    assert fg.messages[keys[0]].m.shape == (spec['X'], 1)
+    if case['force_loopy']:
+        fg.isLoopy = True
+    if 'request' in case:
+        roots.queue = list(case['roots'])
+        fg.treelike_inference(case['request'])
+        assert len(case['roots']) - len(roots.queue) == int(gold['roots_consumed'])
+        np.testing.assert_allclose(_stack(fg, keys), gold['msgs_s%d' % case['snaps'][0]], rtol=RTOL, atol=1e-300)
+    else:
+        done = 0
+        for s in case['snaps']:
+            roots.queue = list(case['roots'][done:s])
+            fg.treelike_inference(s - done)
+            done = s
+            np.testing.assert_allclose(_stack(fg, keys), gold['msgs_s%d' % s], rtol=RTOL, atol=1e-300)
+    for r in sorted(set(case['roots'])):
+        sched = fg.get_message_schedule(fg.variables[r])
+        enc = np.array([[*C.node_code(str(a)), *C.node_code(str(b))] for a, b in sched], dtype=np.int64)
+        np.testing.assert_array_equal(enc, gold['sched_root%d' % r])
+    vorder = list(fg.variables.keys())
+    np.testing.assert_array_equal(np.array(vorder), gold['var_order'])
+    marg = np.stack([fg.variables[v].get_marginal().m.reshape(-1) for v in vorder])
+    np.testing.assert_allclose(marg, gold['marginals'], rtol=RTOL, atol=1e-300)
+    np.testing.assert_allclose(fg.get_posterior_probs(), float(gold['log_posterior']), rtol=1e-10)
+    if spec['X'] >= 50:
+        top = [[int(w[1:]) for w, _ in fg.variables[v].get_max_vocab(50)[2]] for v in vorder]
+        np.testing.assert_array_equal(np.array(top), gold['top50'])
+        np.testing.assert_array_equal(np.array(fg.get_precision_counts()), gold['precision_counts'])
+    if case.get('light'):
+        return fg
+    for f in fg.factors:
+        np.testing.assert_allclose(f.get_factor_beliefs(), gold['belief_F%d' % f.id], rtol=1e-10, atol=1e-300)
+    if spec['style'] == 'trainmp':
+        for f in fg.factors:
+            g = f.get_gradient()
+            assert g.shape == gold['grad_F%d' % f.id].shape
+            np.testing.assert_allclose(g, gold['grad_F%d' % f.id], rtol=1e-8, atol=1e-12)
+        ee, ed = fg.get_unregularized_gradeint()
+        np.testing.assert_allclose(ee, gold['grad_unreg_en_en'], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(ed, gold['grad_unreg_en_de'], rtol=1e-8, atol=1e-12)
+        ed2, ee2 = fg.get_gradient()
+        np.testing.assert_allclose(ee2, gold['grad_reg_en_en'], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(ed2, gold['grad_reg_en_de'], rtol=1e-8, atol=1e-12)
+        ree, red = fg.return_gradient()
+        np.testing.assert_allclose(ree, gold['grad_ret_en_en'], rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(red, gold['grad_ret_en_de'], rtol=1e-8, atol=1e-12)
+    return fg
+
+
+@pytest.mark.parametrize('case', C.inference_cases(), ids=lambda c: c['name'])
+def test_object_api_matches_reference(L, case):
+    _run(L, case)
+
+
+@pytest.mark.parametrize('case', C.approx_cases(), ids=lambda c: c['name'])
+def test_object_api_approximate_modes(L, case):
+    _run(L, case, approx=True)
+
+
+def test_single_message_updates_and_message_assignment(L):
+    """VariableNode / FactorNode.update_message_to one at a time (the loop of LBP.py:227-243 written
+    out by hand) must equal the fused sweep; writing graph.messages[...] must reach the device."""
+    case = [c for c in C.inference_cases() if c['name'] == 'shuffled_x64'][0]
+    spec = case['spec']
+    inputs = C.make_inputs(spec, case['seed'], case['kind'])
+    roots = Roots(L)
+    fg1 = C.build_graph(L, spec, inputs)
+    fg2 = C.build_graph(L, spec, inputs)
+    for fg in (fg1, fg2):
+        roots.queue = [2]
+        fg.initialize()
+    roots.queue = [7]
+    fg1.treelike_inference(1)
+    sched = fg2.get_message_schedule(fg2.variables[7])
+    for frm, to in reversed(sched):
+        if not (isinstance(to, L.FactorNode) and len(to.varset) < 2):
+            frm.update_message_to(to)
+    for to, frm in sched:
+        if not (isinstance(to, L.FactorNode) and len(to.varset) < 2):
+            frm.update_message_to(to)
+    keys = C.msg_keys(spec)
+    np.testing.assert_allclose(_stack(fg2, keys), _stack(fg1, keys), rtol=1e-13, atol=0)
+    # assignment through the dict view
+    k = keys[3]
+    m = L.Message.new_message(C.domain_of(64), 0.0)
+    m.m[5, 0] = 1.0
+    fg2.messages[k] = m
+    assert fg2.messages[k].m[5, 0] == 1.0 and fg2.messages[k].m.sum() == 1.0
+    with pytest.raises(KeyError):
+        fg2.messages['X_999', 'F_0']
+
+
+def test_module_level_helpers(L):
+    a = L.Message(np.array([0.2, 0.0, 0.6, 0.2]))
+    b = L.Message(np.array([[0.5], [np.inf], [0.5], [0.0]]))
+    with np.errstate(all='ignore'):
+        want = np.nan_to_num(a.m * b.m)
+    np.testing.assert_array_equal(L.pointwise_multiply(a, b).m, want)
+    z = L.Message(np.zeros(8))
+    z.renormalize()
+    np.testing.assert_array_equal(z.m, np.full((8, 1), 0.125))
+    m = L.Message(np.array([1.0, 3.0]))
+    m.renormalize()
+    np.testing.assert_allclose(m.m.reshape(-1), [0.25, 0.75], rtol=1e-15)
+    assert L.VAR_TYPE_PREDICTED == 'var_type_predicted' and L.UNARY_FACTOR == 'unary_factor'
+    with pytest.raises(NotImplementedError):
+        f = L.FactorNode(0)
+        vs = [L.VariableNode(i, L.VAR_TYPE_PREDICTED, 'en', ['a', 'b'], 'a') for i in range(3)]
+        f.add_varset_with_potentials(vs, L.PotentialTable({0: 0, 1: 1, 2: 2}, table=np.ones((2, 2))))
+
+
+def test_to_string_and_to_dist_formats(L):
+    """Wire format of the prediction / .dist text (LBP.py:109-143), checked on a user graph."""
+    case = [c for c in C.inference_cases() if c['name'] == 'user_k3_x64'][0]
+    spec = case['spec']
+    inputs = C.make_inputs(spec, case['seed'])
+    roots = Roots(L)
+    fg = C.build_graph(L, spec, inputs)
+    for f in fg.factors:
+        f.word_label = 'w%d' % (f.position or 0)
+    roots.queue = [1]
+    fg.initialize()
+    roots.queue = [1, 4, 7]
+    fg.treelike_inference(3)
+    gold = load_golden(case['name'])
+    lines = fg.to_dist().split('\n')
+    assert len(lines) == 3
+    truth, guess, logs = lines[0].split(' ||| ')
+    assert truth == 'None' and guess == 'w%d' % spec['labels'][0]
+    vals = np.array([float(x) for x in logs.split()])
+    np.testing.assert_allclose(vals, np.log(gold['marginals'][0]), atol=6e-7)
+    strings = fg.to_string()
+    assert len(strings) == 10            # one line per sentence position (3 predicted + 7 given)
+    toks = [s for s in strings if s.startswith('w1 ')][0].split()
+    assert len(toks) == 3 + 2 * 50

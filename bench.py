@@ -131,6 +131,8 @@ def main():
     ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'chain8', 'ring8', 'ring8_x512'])
     ap.add_argument('--batch', type=int, default=8192, help='graphs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sweeps', type=int, default=None, help='override sweeps per step (roots cycle)')
+    ap.add_argument('--variant', type=int, default=None, help='mlbp_set_sweep_variant (A/B measurement)')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per sweep launch from a rocprofv3 --pmc pass (profiles/), if known')
     a = ap.parse_args()
@@ -162,6 +164,9 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     spec, roots, sweeps, seed = workload_spec(a.workload)
+    if a.sweeps:
+        roots = [roots[i % len(roots)] for i in range(a.sweeps)]
+        sweeps = a.sweeps
     X, B = spec['X'], a.batch
     topo = GraphTopology.from_spec(spec)
     gen = torch.Generator(device=dev)
@@ -180,16 +185,16 @@ def main():
     from macaronicusermodeling_amd import _ffi
     from macaronicusermodeling_amd.batch import _stream_ptr
 
+    if a.variant is not None:
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(a.variant))
     fb.initialize()
     fb.is_loopy = True          # chain workloads: run real sweeps, tree short-circuit overridden (LBP.py:219)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
     def step(i=None):
-        fb.initialize()
-        fb.is_loopy = True
         if i is not None:
             ev[i][0].record()
-        fb.sweep(roots)
+        fb.sweep(roots, init=True)       # initialize (uniform messages) is fused into the sweep launch
         if i is not None:
             ev[i][1].record()
         fb.marginals(out=marg)
@@ -239,7 +244,7 @@ def main():
                        'parallelism': 'graphs sharded over %d GPU(s), no data-path collective' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': a.traffic_bytes,
-                         'kernel': 'sweep_x64_kernel' if X == 64 else 'sweep_generic_kernel',
+                         'kernel': 'sweep_x64_fused_kernel' if X == 64 else 'sweep_generic_kernel',
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': avg_ms,
                          'min_launch_ms': sweep_ms[0], 'max_launch_ms': sweep_ms[-1]},
             'cpu_baseline': cpu,

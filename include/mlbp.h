@@ -139,10 +139,18 @@ typedef struct mlbp_sweep_args {
   const int32_t* unary_tab;   /* device [B][U]                                                    */
   double* msgs;               /* device [B][n_msgs][X]  in/out                                    */
   int32_t normalize_messages; /* FactorGraph.normalize_messages (LBP.py:41)                       */
-  int32_t reserved;
+  int32_t init_messages;      /* non-zero: start from uniform 1/X messages (FactorGraph.initialize,
+                                 LBP.py:211-216, fused into the launch) instead of reading msgs      */
 } mlbp_sweep_args;
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
+
+/* Kernel-variant selector for A/B measurement (not needed in normal use): 1 = default (fused
+ * kernel, pairwise tables register-resident when the graph has at most 3 of them), 0 = the
+ * first-generation kernel, 10+N = fused kernel with exactly N resident tables (N = 0 streams every
+ * table for every update).  Also settable through the MLBP_SWEEP_VARIANT environment variable.
+ * All variants compute the same updates in the same order. */
+int mlbp_set_sweep_variant(int32_t variant);
 
 /* Fills msgs[B][n_msgs][X] with 1/X: FactorGraph.initialize (LBP.py:211-216). */
 int mlbp_init_messages_f64(double* msgs, int64_t n_rows, int32_t X, void* stream);

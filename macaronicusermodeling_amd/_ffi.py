@@ -31,7 +31,7 @@ class SweepArgs(C.Structure):
     _fields_ = [('B', C.c_int32), ('X', C.c_int32), ('n_pair_tables', C.c_int32),
                 ('n_unary_tables', C.c_int32), ('pair_tables', C.c_void_p), ('pair_tab', C.c_void_p),
                 ('unary_tables', C.c_void_p), ('unary_tab', C.c_void_p), ('msgs', C.c_void_p),
-                ('normalize_messages', C.c_int32), ('reserved', C.c_int32)]
+                ('normalize_messages', C.c_int32), ('init_messages', C.c_int32)]
 
 
 _i32p = C.POINTER(C.c_int32)
@@ -52,6 +52,7 @@ SIGNATURES = {
                                       C.POINTER(_vp)]),
     'mlbp_program_destroy': (C.c_int, [_vp]),
     'mlbp_program_status': (C.c_int, [_vp]),
+    'mlbp_set_sweep_variant': (C.c_int, [_i32]),
     'mlbp_sweep_f64': (C.c_int, [_vp, C.POINTER(SweepArgs), _vp]),
     'mlbp_init_messages_f64': (C.c_int, [_vp, _i64, _i32, _vp]),
     'mlbp_marginals_f64': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),

@@ -114,8 +114,9 @@ class FactorGraphBatch:
             self._programs[key] = Program(self.topo, key)
         return self._programs[key]
 
-    def sweep(self, roots):
-        """Runs len(roots) sweeps, sweep s rooted at variable id roots[s], on every graph."""
+    def sweep(self, roots, init=False):
+        """Runs len(roots) sweeps, sweep s rooted at variable id roots[s], on every graph, in one
+        launch.  init=True starts from uniform messages (initialize() fused into the launch)."""
         prog = self.program(roots)
         a = _ffi.SweepArgs()
         a.B, a.X = self.B, self.X
@@ -131,6 +132,7 @@ class FactorGraphBatch:
             a.unary_tables, a.unary_tab = self.unary_tables.data_ptr(), self.unary_tab.data_ptr()
         a.msgs = self.msgs.data_ptr()
         a.normalize_messages = 1 if self.normalize_messages else 0
+        a.init_messages = 1 if init else 0
         _ffi.check(_ffi.lib.mlbp_sweep_f64(prog.handle, C.byref(a), _stream_ptr(self.device)))
         return prog
 

@@ -20,6 +20,12 @@ struct mlbp_program {
   int32_t* d_sweeps;      // [n_sweeps][2]
   int32_t* d_pairseq;     // [n_pairseq + 1] pair slot of the k-th executed pair op (-1 terminated)
   int32_t* d_status;      // [1] set non-zero by a kernel that met an out-of-range table index
+  // fused form used by the X = 64 kernel (build_fused_program in mlbp_sweep.hip)
+  int32_t n_fops, n_hoist, n_psrcs, n_cprod, n_cpw;
+  int32_t* d_fops;        // one block: op headers [n_fops][8], source lists [n_psrcs], hoist list
+                          // [n_hoist][2], constant-product lists [n_cpw]
+  int32_t* d_fsweeps;     // [n_sweeps][2]
+  int32_t* d_fpairseq;    // pair slot of the k-th executed pairwise update of the fused form (-1 terminated)
   int device;
 };
 

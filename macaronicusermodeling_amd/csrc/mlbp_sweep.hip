@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstdlib>
 #include <vector>
 
 #include "mlbp_internal.h"
@@ -41,16 +42,55 @@ __device__ __forceinline__ double nan_to_num(double x) {
   return x;
 }
 
+// 64-bit DPP move: lane l receives the value of the lane selected by CTRL inside its row of 16.
+// 0xB1 = quad_perm[1,0,3,2] (l^1), 0x4E = quad_perm[2,3,0,1] (l^2), 0x1B = quad_perm[3,2,1,0] (3-l),
+// 0x141 = row_half_mirror (7-l within 8), 0x140 = row_mirror (15-l within 16).  VALU speed: no LDS
+// crossbar round trip as with ds_bpermute (__shfl_xor).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// Sum over the 64 lanes, the same bits in every lane: four DPP steps give each row of 16 its
+// sum (every pairing adds the same two operands in both partners, so the row agrees bitwise), then
+// the four row sums are combined through scalar registers.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+}
+
+// acc * m followed by nan_to_num; the three compares only run when some lane of the wave saw a
+// non-finite product (wave-uniform branch).
+__device__ __forceinline__ double mul_nan_to_num(double m, double acc) {
+  double p = m * acc;
+  if (__builtin_expect(__any(!__builtin_isfinite(p)), 0)) p = nan_to_num(p);
+  return p;
 }
 
 // Message.renormalize (LBP.py:649-657): positive total -> v / total, else uniform.
 __device__ __forceinline__ double renorm(double v, double total, double uniform, bool normalize) {
   if (!normalize) return v;
   return total > 0.0 ? v / total : uniform;
+}
+
+// Program data (op headers, source lists, sweep table) is read-only for the whole launch and
+// wave-uniform.  Reading it through the CONSTANT address space lets the compiler use scalar loads
+// (s_load -> SGPRs, lgkmcnt) instead of per-lane vector loads that queue behind the table stream
+// on vmcnt; a plain `const int32_t*` is not enough because the kernel also stores to global memory.
+typedef const int32_t __attribute__((address_space(4))) * const_i32p;
+__device__ __forceinline__ const_i32p as_const(const int32_t* p) {
+  return (const_i32p)(uintptr_t)p;
 }
 
 struct SweepDev {
@@ -215,6 +255,350 @@ __global__ __launch_bounds__(WG) void sweep_x64_kernel(SweepDev d) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// X = 64, float64, second generation ("fused" program form, see build_fused_program):
+//   * unary factor->variable messages depend on nothing but their table, so when the program
+//     allows it (every such slot is written before it is first read) they are all computed once,
+//     in parallel over the 4 waves, before the first sweep, and the UNARY ops are dropped -- the
+//     values are bit-identical to recomputing them every sweep as the reference does;
+//   * a variable->factor update that feeds the next pairwise update is fused into it: every wave
+//     forms the product redundantly (lane i = state i), so no barrier separates the two;
+//   * every wave finishes every update redundantly (same inputs, same order => same bits) and
+//     stores the result itself, so a wave only ever reads back its own LDS writes; the single
+//     workgroup barrier per pairwise update orders the exchange of partial sums, which lives in a
+//     double-buffered scratch;
+//   * NT > 0: the graph's (at most NT) pairwise tables are loaded ONCE into registers and reused
+//     by every sweep of the call (16 f64 per thread and table); NT == 0 streams with a one-table
+//     register prefetch as before;
+//   * init != 0 starts from uniform messages instead of reading them (FactorGraph.initialize fused).
+// ------------------------------------------------------------------------------------------------
+// Diagnostic build only (-DMLBP_STAMPS, tools/stamp_profile.py): per-phase shader-clock sums of
+// workgroup 0..15's wave 0 go to a side buffer that no other code reads.  Never defined in the
+// shipped library.
+#ifdef MLBP_STAMPS
+__device__ unsigned long long* g_stamp_buf = nullptr;
+#define STAMP_DECL unsigned long long _t0 = 0, _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t0) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP(i) { unsigned long long _t1; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t1) :: "memory"); __builtin_amdgcn_sched_barrier(0); _ph[i] += _t1 - _t0; _t0 = _t1; }
+#define STAMP_FLUSH if (g_stamp_buf && blockIdx.x < 64 && threadIdx.x == 0) { for (int _i = 0; _i < 8; ++_i) g_stamp_buf[blockIdx.x * 8 + _i] = _ph[_i]; }
+#else
+#define STAMP_DECL
+#define STAMP_START
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
+enum { FOP_UNARY = 0, FOP_PAIR_TM = 1, FOP_PAIR_MT = 2, FOP_VAR = 3, FOP_VAR_PAIR_TM = 4, FOP_VAR_PAIR_MT = 5 };
+
+struct FusedDev {
+  const int32_t* image;    // fused op headers, source lists, hoist list, constant-product lists (one block)
+  const int32_t* fsweeps;  // [n_sweeps][2]
+  int32_t n_fops, n_psrcs, n_hoist, n_cprod, n_cpw, n_ext, init;
+};
+
+__device__ __forceinline__ void wg_barrier() {
+  // LDS traffic only: wait for this wave's LDS ops, then the workgroup barrier.  Outstanding
+  // global loads (table prefetch) stay in flight across it.
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool MT>
+__device__ __forceinline__ void pair_partials(const double2 (&T)[8], const double* m, double* red, int rg, int cp,
+                                              int lane) {
+  if (MT) {
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double mi = m[8 * k + rg];
+      a0 += mi * T[k].x;
+      a1 += mi * T[k].y;
+    }
+    reinterpret_cast<double2*>(red + rg * 64)[cp] = make_double2(a0, a1);
+  } else {
+    const double2 mj = reinterpret_cast<const double2*>(m)[cp];
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = T[k].x * mj.x + T[k].y * mj.y;
+    // transposing butterfly over the 16 lanes of a DPP row: each step pairs lane l with its mirror
+    // and halves the live values (8 -> 4 -> 2 -> 1); "up" lanes keep the upper half.
+    {
+      const bool up = lane & 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double send = up ? v[i] : v[i + 4], keep = up ? v[i + 4] : v[i];
+        v[i] = keep + dpp_mov<0x140>(send);
+      }
+    }
+    {
+      const bool up = lane & 4;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const double send = up ? v[i] : v[i + 2], keep = up ? v[i + 2] : v[i];
+        v[i] = keep + dpp_mov<0x141>(send);
+      }
+    }
+    {
+      const bool up = lane & 2;
+      const double send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
+      v[0] = keep + dpp_mov<0x1B>(send);
+    }
+    v[0] += dpp_mov<0xB1>(v[0]);
+    // lane holds row 8k+rg summed over the 32 columns of its 16-lane row; the other 32 columns
+    // sit in the neighbouring row of the same half-wave: both go to LDS, added after the barrier.
+    if ((lane & 1) == 0) {
+      const int k = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+      red[((lane >> 4) & 1) * 64 + 8 * k + rg] = v[0];
+    }
+  }
+}
+
+// Register budget: the resident tables take 32 VGPRs each; the waves-per-SIMD floor keeps the
+// allocator at 3 workgroups per CU with 3 resident tables (<= 168 VGPRs) and 4 otherwise (<= 128).
+//
+// LDS image of one workgroup (doubles unless noted):
+//   msg   [n_msgs][64]      the graph's messages
+//   ext   [n_ext][64]       slot n_msgs = the uniform vector; then one "constant product" per
+//                           distinct set of hoisted unary messages a variable multiplies in
+//   gin   [64]              input vector of the pairwise update in flight
+//   red   [8][64]           partial sums of the contraction
+//   prog  int32             fused op headers [n_fops][8], source lists, hoist / constant-product
+//                           lists, the graph's table indices
+template <bool NORM, int NT>
+__global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x64_fused_kernel(SweepDev d, FusedDev f) {
+  extern __shared__ double lds[];
+  double* msg = lds;
+  double* gin = lds + (size_t)(d.n_msgs + f.n_ext) * 64;
+  double* red = gin + 64;
+  int32_t* prog = reinterpret_cast<int32_t*>(red + 512);
+  const int32_t* psrcs = prog + f.n_fops * 8;          // [n_psrcs]
+  const int32_t* phoist = psrcs + f.n_psrcs;            // [n_hoist][2]
+  const int32_t* pcp = phoist + 2 * f.n_hoist;          // [n_cpw] constant-product lists: count, slots...
+  int32_t* tabidx = const_cast<int32_t*>(pcp) + f.n_cpw;  // [P + U] this graph's table indices
+  int32_t* flags = tabidx + d.P + d.U;                  // [0] = vector wave already stored the v->f message
+
+  STAMP_DECL
+  STAMP_START
+  const int g = blockIdx.x;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int rg = t >> 5, cp = t & 31;
+  double* gm = d.msgs + (size_t)g * d.n_msgs * 64;
+  const double uniform = 1.0 / 64.0;
+  const const_i32p c_fsweeps = as_const(f.fsweeps), c_pairseq = as_const(d.pairseq);
+
+  // ---- phase A: table indices (range-checked), program image and messages into LDS ----
+  bool ok = true;
+  for (int i = t; i < d.P + d.U; i += WG) {
+    const int v = i < d.P ? d.pair_tab[(size_t)g * d.P + i] : d.unary_tab[(size_t)g * d.U + (i - d.P)];
+    ok &= (unsigned)v < (unsigned)(i < d.P ? d.n_pair_tables : d.n_unary_tables);
+    tabidx[i] = v;
+  }
+  {
+    const int n_img = f.n_fops * 8 + f.n_psrcs + 2 * f.n_hoist + f.n_cpw;
+    for (int i = t; i < n_img; i += WG) prog[i] = f.image[i];
+    double2* dst = reinterpret_cast<double2*>(msg);
+    if (f.init) {
+      for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = make_double2(uniform, uniform);
+    } else {
+      const double2* src = reinterpret_cast<const double2*>(gm);
+      for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = src[i];
+    }
+    if (t < 32) dst[d.n_msgs * 32 + t] = make_double2(uniform, uniform);    // ext slot 0
+    if (t == 0) flags[0] = 0;
+  }
+  if (!__syncthreads_and(ok ? 1 : 0)) {       // an out-of-range table index: skip the graph, raise the status word
+    if (t == 0) atomicExch(d.status, 1);
+    return;
+  }
+
+  // ---- phase B: every HBM load of the prologue in flight together ----
+  constexpr int NR = NT > 0 ? NT : 1;
+  double2 tab[NR][8];
+  int pair_k = 0;
+  if (NT > 0) {
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+      if (p < d.P) {
+        const int ti = __builtin_amdgcn_readfirstlane(tabidx[p]);
+        const double2* T = reinterpret_cast<const double2*>(d.pair_tables + (size_t)ti * 4096);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tab[p][k] = T[k * WG + t];
+      }
+    }
+  } else {
+    const int s0 = c_pairseq[0];
+    if (s0 >= 0) {
+      const int ti = __builtin_amdgcn_readfirstlane(tabidx[s0]);
+      const double2* T = reinterpret_cast<const double2*>(d.pair_tables + (size_t)ti * 4096);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tab[0][k] = T[k * WG + t];
+    }
+  }
+  // hoisted unary messages: wave w takes entries w, w+4, ...; 8 loads in flight per wave
+  constexpr int HB = 8;
+  for (int h0 = wave; h0 < f.n_hoist; h0 += 4 * HB) {
+    double r[HB];
+#pragma unroll
+    for (int j = 0; j < HB; ++j) {
+      const int h = h0 + 4 * j;
+      r[j] = (h < f.n_hoist) ? d.unary_tables[(size_t)tabidx[d.P + phoist[2 * h]] * 64 + lane] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < HB; ++j) {
+      const int h = h0 + 4 * j;
+      if (h < f.n_hoist) msg[phoist[2 * h + 1] * 64 + lane] = renorm(r[j], wave_sum(r[j]), uniform, NORM);
+    }
+  }
+  wg_barrier();
+  // constant products: uniform times the hoisted messages a variable multiplies in, in facset
+  // order with nan_to_num after each product (the constant prefix of LBP.py:381-386)
+  {
+    int at = 0;
+    for (int k = 0; k < f.n_cprod; ++k) {
+      const int cnt = pcp[at];
+      if ((k & 3) == wave) {
+        double acc = uniform;
+        bool clean = true;
+        for (int q = 0; q < cnt; ++q) {
+          acc *= msg[pcp[at + 1 + q] * 64 + lane];
+          clean = clean && __all(__builtin_isfinite(acc));
+        }
+        // a non-finite intermediate means nan_to_num would have acted inside the constant part:
+        // poison the product so that every update using it takes the exact-order path
+        msg[(d.n_msgs + 1 + k) * 64 + lane] = clean ? acc : __builtin_nan("");
+      }
+      at += 1 + cnt;
+    }
+  }
+  wg_barrier();
+  STAMP(0)   // prologue
+
+  // Main loop.  Wave 0 is the graph's "vector wave": it alone runs the 64-element work on the
+  // critical path of every update (variable product, gathering the partial sums, normalising the
+  // factor->variable message); all four waves run the table contraction.  Two LDS-only barriers per
+  // pairwise update hand the input vector to the contraction and the partial sums back.
+  for (int s = 0; s < d.n_sweeps; ++s) {
+    const int op0 = c_fsweeps[2 * s], nop = c_fsweeps[2 * s + 1];
+    for (int o = op0; o < op0 + nop; ++o) {
+      const int4 h0 = reinterpret_cast<const int4*>(prog)[2 * o];
+      const int4 h1 = reinterpret_cast<const int4*>(prog)[2 * o + 1];
+      const int kind = __builtin_amdgcn_readfirstlane(h0.x);
+      STAMP(1)   // op header
+      if (kind == FOP_UNARY) {
+        if (wave == 0) {
+          const int us = __builtin_amdgcn_readfirstlane(h0.y), c = __builtin_amdgcn_readfirstlane(h0.w);
+          const double r = d.unary_tables[(size_t)tabidx[d.P + us] * 64 + lane];
+          msg[c * 64 + lane] = renorm(r, wave_sum(r), uniform, NORM);
+        }
+        continue;
+      }
+      int pslot, dst;
+      const double* m;
+      const bool from_var = (kind == FOP_VAR || kind == FOP_VAR_PAIR_TM || kind == FOP_VAR_PAIR_MT);
+      const int c = __builtin_amdgcn_readfirstlane(h0.w);
+      if (from_var) {
+        if (wave == 0) {
+          // fast form: (constant product) x (the varying messages), valid while every factor is
+          // finite and non-negative and the product is not identically zero; then the product's
+          // scale cancels in the normalised pairwise update, so the contraction takes it
+          // unnormalised and wave 1 normalises and stores the variable->factor message meanwhile
+          const int a = __builtin_amdgcn_readfirstlane(h0.y), n = __builtin_amdgcn_readfirstlane(h0.z);
+          const int4 s4 = *reinterpret_cast<const int4*>(psrcs + a);
+          double acc = msg[s4.x * 64 + lane];
+          if (n > 1) acc *= msg[s4.y * 64 + lane];
+          if (n > 2) acc *= msg[s4.z * 64 + lane];
+          if (n > 3) acc *= msg[s4.w * 64 + lane];
+          for (int q = 4; q < n; ++q) acc *= msg[psrcs[a + q] * 64 + lane];
+          const bool fast = __all(acc >= 0.0 && acc < __builtin_huge_val()) && __any(acc > 0.0);
+          STAMP(2)   // variable product
+#ifdef MLBP_STAMPS
+          if (!fast) _ph[2] += (1ULL << 40);
+          if (!__all(acc >= 0.0)) _ph[2] += (1ULL << 44);
+          if (!__all(acc < __builtin_huge_val())) _ph[2] += (1ULL << 48);
+          if (!__any(acc > 0.0)) _ph[2] += (1ULL << 52);
+#endif
+          if (fast && kind != FOP_VAR) {
+            gin[lane] = acc;
+            if (lane == 0) flags[0] = 0;
+          } else {
+            // exact reference order (LBP.py:381-389) from the raw messages
+            const int ae = __builtin_amdgcn_readfirstlane(h1.z), ne = __builtin_amdgcn_readfirstlane(h1.w);
+            double ex = uniform;
+            for (int q = 0; q < ne; ++q) ex = mul_nan_to_num(msg[psrcs[ae + q] * 64 + lane], ex);
+            const double mn = renorm(ex, wave_sum(ex), uniform, NORM);
+            msg[c * 64 + lane] = mn;
+            gin[lane] = mn;
+            if (lane == 0) flags[0] = 1;
+          }
+          STAMP(3)   // (slow path only) normalisation
+        }
+        if (kind == FOP_VAR) continue;
+        m = gin;
+        pslot = __builtin_amdgcn_readfirstlane(h1.x);
+        dst = __builtin_amdgcn_readfirstlane(h1.y);
+      } else {
+        pslot = __builtin_amdgcn_readfirstlane(h0.y);
+        m = msg + __builtin_amdgcn_readfirstlane(h0.z) * 64;
+        dst = c;
+      }
+      const bool mt = (kind == FOP_PAIR_MT || kind == FOP_VAR_PAIR_MT);
+      wg_barrier();          // the input vector (and every earlier vector-wave store) is visible
+      STAMP(5)   // barrier
+      if (NT > 0) {
+#pragma unroll
+        for (int p = 0; p < NT; ++p) {
+          if (p == pslot) {
+            if (mt) pair_partials<true>(tab[p], m, red, rg, cp, lane);
+            else pair_partials<false>(tab[p], m, red, rg, cp, lane);
+          }
+        }
+      } else {
+        double2 cur[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cur[k] = tab[0][k];
+        ++pair_k;
+        const int sn = c_pairseq[pair_k];
+        if (sn >= 0) {
+          const int ti = __builtin_amdgcn_readfirstlane(tabidx[sn]);
+          const double2* T = reinterpret_cast<const double2*>(d.pair_tables + (size_t)ti * 4096);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) tab[0][k] = T[k * WG + t];
+        }
+        if (mt) pair_partials<true>(cur, m, red, rg, cp, lane);
+        else pair_partials<false>(cur, m, red, rg, cp, lane);
+      }
+      if (from_var && wave == 1 && flags[0] == 0) {
+        // off the critical path: normalise and store the variable->factor message (LBP.py:387-389)
+        const double v = gin[lane];
+        msg[c * 64 + lane] = renorm(v, wave_sum(v), uniform, NORM);
+      }
+      STAMP(4)   // partial sums
+      wg_barrier();          // partial sums are in LDS
+      STAMP(5)   // barrier
+      if (wave == 0) {
+        double r;
+        if (mt) {
+          r = 0.0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) r += red[q * 64 + lane];
+        } else {
+          r = red[lane] + red[64 + lane];
+        }
+        STAMP(6)   // gather partials
+        msg[dst * 64 + lane] = renorm(r, wave_sum(r), uniform, NORM);
+        STAMP(7)   // normalise
+      }
+    }
+  }
+  STAMP_FLUSH
+  wg_barrier();
+  {
+    const double2* src = reinterpret_cast<const double2*>(msg);
+    double2* dst = reinterpret_cast<double2*>(gm);
+    for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = src[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Any X: messages in LDS when they fit (LDSMSG) else in place in global memory (only this
 // workgroup touches its graph's messages; __syncthreads orders the accesses).
 // ------------------------------------------------------------------------------------------------
@@ -337,6 +721,122 @@ __global__ void log_posterior_kernel(const double* marg, const int32_t* labels, 
   out[g] = total;
 }
 
+// Fused program form (see sweep_x64_fused_kernel).  Input: the validated 4-word op list.
+struct FusedProgram {
+  std::vector<int32_t> fops, psrcs, fsweeps, hoist, cpw, pairseq;
+  int n_cprod = 0;
+};
+
+void build_fused_program(const int32_t* ops, const int32_t* srcs, const int32_t* sweeps, int n_sweeps, int n_msgs,
+                         FusedProgram& out) {
+  // 1. may the unary messages be hoisted?  Every read of a unary factor's message slot must come
+  //    after a UNARY op has written that slot (then the value read is always the same constant).
+  std::vector<char> is_unary_dst(n_msgs, 0), written(n_msgs, 0);
+  std::vector<int> unary_of(n_msgs, -1);
+  bool hoistable = true;
+  for (int s = 0; s < n_sweeps; ++s)
+    for (int o = sweeps[2 * s]; o < sweeps[2 * s] + sweeps[2 * s + 1]; ++o)
+      if (ops[4 * o] == MLBP_OP_UNARY) {
+        int c = ops[4 * o + 3];
+        if (is_unary_dst[c] && unary_of[c] != ops[4 * o + 1]) hoistable = false;  // two tables, one slot
+        is_unary_dst[c] = 1;
+        unary_of[c] = ops[4 * o + 1];
+      }
+  for (int s = 0; s < n_sweeps && hoistable; ++s)
+    for (int o = sweeps[2 * s]; o < sweeps[2 * s] + sweeps[2 * s + 1] && hoistable; ++o) {
+      const int kind = ops[4 * o], a = ops[4 * o + 1], b = ops[4 * o + 2], c = ops[4 * o + 3];
+      if (kind == MLBP_OP_UNARY) {
+        written[c] = 1;
+      } else if (kind == MLBP_OP_VAR) {
+        for (int q = a; q < a + b; ++q)
+          if (is_unary_dst[srcs[q]] && !written[srcs[q]]) hoistable = false;
+        if (is_unary_dst[c]) hoistable = false;
+      } else {
+        if ((is_unary_dst[b] && !written[b]) || is_unary_dst[c]) hoistable = false;
+      }
+    }
+  if (hoistable)
+    for (int c = 0; c < n_msgs; ++c)
+      if (is_unary_dst[c]) { out.hoist.push_back(unary_of[c]); out.hoist.push_back(c); }
+  // 2. per variable update: fast source list = [base slot, varying sources...] where the base is the
+  //    uniform vector (ext slot 0) or the constant product of the hoisted sources (ext slot 1+k);
+  //    exact source list = the original one.  Lists start on multiples of 4 words (int4 reads).
+  std::vector<std::vector<int>> cprods;                      // distinct constant-source lists
+  auto pad4 = [&]() { while (out.psrcs.size() % 4) out.psrcs.push_back(n_msgs); };
+  auto var_lists = [&](int a, int b, int& fa, int& fn, int& ea, int& en) {
+    std::vector<int> consts, vars;
+    for (int q = a; q < a + b; ++q) (hoistable && is_unary_dst[srcs[q]] ? consts : vars).push_back(srcs[q]);
+    int base = n_msgs;                                        // uniform
+    if (!consts.empty()) {
+      int k = 0;
+      for (; k < (int)cprods.size(); ++k)
+        if (cprods[k] == consts) break;
+      if (k == (int)cprods.size()) cprods.push_back(consts);
+      base = n_msgs + 1 + k;
+    }
+    pad4();
+    fa = (int)out.psrcs.size();
+    out.psrcs.push_back(base);
+    for (int v : vars) out.psrcs.push_back(v);
+    fn = 1 + (int)vars.size();
+    pad4();
+    ea = (int)out.psrcs.size();
+    for (int q = a; q < a + b; ++q) out.psrcs.push_back(srcs[q]);
+    en = b;
+  };
+  // 3. fuse "variable -> factor" into the pairwise update it feeds; drop hoisted unary ops.
+  for (int s = 0; s < n_sweeps; ++s) {
+    const int first = sweeps[2 * s], cnt = sweeps[2 * s + 1];
+    const int f0 = (int)out.fops.size() / 8;
+    for (int o = first; o < first + cnt; ++o) {
+      const int kind = ops[4 * o], a = ops[4 * o + 1], b = ops[4 * o + 2], c = ops[4 * o + 3];
+      if (kind == MLBP_OP_UNARY) {
+        if (!hoistable) out.fops.insert(out.fops.end(), {FOP_UNARY, a, 0, c, 0, 0, 0, 0});
+      } else if (kind == MLBP_OP_VAR) {
+        int fa, fn, ea, en;
+        var_lists(a, b, fa, fn, ea, en);
+        const bool next_is_pair = o + 1 < first + cnt &&
+                                  (ops[4 * (o + 1)] == MLBP_OP_PAIR_TM || ops[4 * (o + 1)] == MLBP_OP_PAIR_MT) &&
+                                  ops[4 * (o + 1) + 2] == c;
+        if (next_is_pair) {
+          const int pk = ops[4 * (o + 1)];
+          out.fops.insert(out.fops.end(), {pk == MLBP_OP_PAIR_TM ? FOP_VAR_PAIR_TM : FOP_VAR_PAIR_MT, fa, fn, c,
+                                           ops[4 * (o + 1) + 1], ops[4 * (o + 1) + 3], ea, en});
+          out.pairseq.push_back(ops[4 * (o + 1) + 1]);
+          ++o;
+        } else {
+          out.fops.insert(out.fops.end(), {FOP_VAR, fa, fn, c, 0, 0, ea, en});
+        }
+      } else {
+        out.fops.insert(out.fops.end(), {kind == MLBP_OP_PAIR_TM ? FOP_PAIR_TM : FOP_PAIR_MT, a, b, c, 0, 0, 0, 0});
+        out.pairseq.push_back(a);
+      }
+    }
+    out.fsweeps.push_back(f0);
+    out.fsweeps.push_back((int)out.fops.size() / 8 - f0);
+  }
+  out.pairseq.push_back(-1);
+  for (int q = 0; q < 8; ++q) out.psrcs.push_back(n_msgs);   // tail padding for the int4 reads
+  pad4();
+  out.n_cprod = (int)cprods.size();
+  for (auto& l : cprods) {
+    out.cpw.push_back((int)l.size());
+    for (int v : l) out.cpw.push_back(v);
+  }
+}
+
+// MLBP_SWEEP_VARIANT (experiments / A-B profiling only): 0 = first-generation kernel, 1 = fused
+// kernel with the default table-residency rule (default), 10+N = fused kernel forcing N resident
+// tables (N = 0 streams).
+int g_sweep_variant = -1;
+int sweep_variant() {
+  if (g_sweep_variant < 0) {
+    const char* e = getenv("MLBP_SWEEP_VARIANT");
+    g_sweep_variant = e ? atoi(e) : 1;
+  }
+  return g_sweep_variant;
+}
+
 int check_device() {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -417,6 +917,7 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
   p->max_srcs = max_srcs;
   pairseq.push_back(-1);
   p->d_ops = p->d_srcs = p->d_sweeps = p->d_pairseq = p->d_status = nullptr;
+  p->d_fops = p->d_fsweeps = p->d_fpairseq = nullptr;
   (void)hipGetDevice(&p->device);
   auto up = [&](int32_t** dst, const int32_t* src, size_t n) -> hipError_t {
     hipError_t e = hipMalloc(dst, (n ? n : 1) * sizeof(int32_t));
@@ -424,11 +925,27 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
     return n ? hipMemcpy(*dst, src, n * sizeof(int32_t), hipMemcpyHostToDevice) : hipSuccess;
   };
   hipError_t e = up(&p->d_ops, ops, (size_t)n_ops * 4);
-  if (e == hipSuccess) e = up(&p->d_srcs, srcs, (size_t)n_srcs);
+  std::vector<int32_t> srcs_padded(srcs ? srcs : nullptr, srcs ? srcs + n_srcs : nullptr);
+  srcs_padded.resize(((size_t)n_srcs + 16 + 3) / 4 * 4, 0);   // the fused kernel reads sources 16 at a time
+  if (e == hipSuccess) e = up(&p->d_srcs, srcs_padded.data(), srcs_padded.size());
   if (e == hipSuccess) e = up(&p->d_sweeps, sweeps, (size_t)n_sweeps * 2);
   if (e == hipSuccess) e = up(&p->d_pairseq, pairseq.data(), pairseq.size());
   int32_t zero = 0;
   if (e == hipSuccess) e = up(&p->d_status, &zero, 1);
+  FusedProgram fp;
+  build_fused_program(ops, srcs, sweeps, n_sweeps, n_msgs, fp);
+  p->n_fops = (int)fp.fops.size() / 8;
+  p->n_hoist = (int)fp.hoist.size() / 2;
+  p->n_psrcs = (int)fp.psrcs.size();
+  p->n_cprod = fp.n_cprod;
+  p->n_cpw = (int)fp.cpw.size();
+  std::vector<int32_t> image(fp.fops);
+  image.insert(image.end(), fp.psrcs.begin(), fp.psrcs.end());
+  image.insert(image.end(), fp.hoist.begin(), fp.hoist.end());
+  image.insert(image.end(), fp.cpw.begin(), fp.cpw.end());
+  if (e == hipSuccess) e = up(&p->d_fops, image.data(), image.size());
+  if (e == hipSuccess) e = up(&p->d_fsweeps, fp.fsweeps.data(), fp.fsweeps.size());
+  if (e == hipSuccess) e = up(&p->d_fpairseq, fp.pairseq.data(), fp.pairseq.size());
   if (e != hipSuccess) {
     mlbp_program_destroy(p);
     return fail(MLBP_EHIP, "mlbp_program_create: device upload failed: %s", hipGetErrorString(e));
@@ -441,6 +958,7 @@ int mlbp_program_destroy(mlbp_program* p) {
   if (!p) return MLBP_OK;
   (void)hipFree(p->d_ops); (void)hipFree(p->d_srcs); (void)hipFree(p->d_sweeps);
   (void)hipFree(p->d_pairseq); (void)hipFree(p->d_status);
+  (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq);
   delete p;
   return MLBP_OK;
 }
@@ -466,6 +984,43 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   hipStream_t st = (hipStream_t)stream;
   const bool norm = a->normalize_messages != 0;
   const size_t LDS_MAX = 160 * 1024;
+  const int variant = sweep_variant();
+  if (a->X == 64 && variant != 0) {
+    const int n_ext = 1 + prog->n_cprod;
+    const size_t img_words = (size_t)prog->n_fops * 8 + prog->n_psrcs + 2 * prog->n_hoist + prog->n_cpw;
+    size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 64 + 512) * sizeof(double) +
+                 (img_words + prog->P + prog->U + 4) * sizeof(int32_t);
+    if (lds <= LDS_MAX) {
+      FusedDev f;
+      f.image = prog->d_fops; f.fsweeps = prog->d_fsweeps;
+      f.n_fops = prog->n_fops; f.n_psrcs = prog->n_psrcs; f.n_hoist = prog->n_hoist;
+      f.n_cprod = prog->n_cprod; f.n_cpw = prog->n_cpw; f.n_ext = n_ext;
+      f.init = a->init_messages;
+      d.pairseq = prog->d_fpairseq;
+      // register-resident tables when the graph has few enough of them; variant 2.. forces NT
+      int nt = (prog->P <= 3) ? prog->P : 0;
+      if (variant >= 10) nt = (variant - 10 <= 4 && prog->P <= variant - 10) ? variant - 10 : 0;
+      if (prog->P == 0) nt = 0;
+      void (*k)(SweepDev, FusedDev) = nullptr;
+#define MLBP_PICK(N) k = norm ? sweep_x64_fused_kernel<true, N> : sweep_x64_fused_kernel<false, N>
+      switch (nt) {
+        case 1: MLBP_PICK(1); break;
+        case 2: MLBP_PICK(2); break;
+        case 3: MLBP_PICK(3); break;
+        case 4: MLBP_PICK(4); break;
+        default: MLBP_PICK(0); break;
+      }
+#undef MLBP_PICK
+      HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, st, d, f);
+      HIP_TRY(hipGetLastError());
+      return MLBP_OK;
+    }
+  }
+  if (a->init_messages) {
+    int e = mlbp_init_messages_f64(a->msgs, (int64_t)a->B * prog->n_msgs, a->X, stream);
+    if (e) return e;
+  }
   if (a->X == 64) {
     size_t lds = ((size_t)prog->n_msgs * 64 + 8 * 64) * sizeof(double);
     if (lds <= LDS_MAX) {
@@ -486,6 +1041,20 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), base, st, d);
   }
   HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+#ifdef MLBP_STAMPS
+int mlbp_debug_set_stamp_buffer(void* dev_ptr) {
+  unsigned long long* p = (unsigned long long*)dev_ptr;
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)));
+  return MLBP_OK;
+}
+#endif
+
+int mlbp_set_sweep_variant(int32_t variant) {
+  if (variant < 0 || (variant > 1 && (variant < 10 || variant > 14))) return fail(MLBP_EINVAL, "unknown sweep variant %d", variant);
+  g_sweep_variant = variant;
   return MLBP_OK;
 }
 

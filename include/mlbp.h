@@ -172,6 +172,55 @@ int mlbp_log_posterior_f64(const double* marginals, const int32_t* labels, int32
                            int32_t X, double* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * DEVICE: factor beliefs and the log-linear gradient, batched over graphs
+ * ------------------------------------------------------------------------------------------- */
+/* FactorNode.get_factor_beliefs for every pairwise factor (LBP.py:543-569):
+ * out[b][p] = normalise((c r^T) * T) with c / r the messages from the dim-0 / dim-1 variable
+ * (device int32 c_slot[P], r_slot[P] give their message slots); all-zero when the total is <= 0
+ * (au.normalize).  out: device [B][P][X][X]. */
+int mlbp_pair_beliefs_f64(const double* msgs, int32_t B, int32_t n_msgs, int32_t X, int32_t P,
+                          const double* pair_tables, const int32_t* pair_tab, int32_t n_pair_tables,
+                          const int32_t* c_slot, const int32_t* r_slot, double* out, void* stream);
+
+/* FactorGraph.get_unregularized_gradeint (LBP.py:301-320) for every graph of a batch, fused with
+ * FactorNode.get_gradient / cell_gradient / get_factor_beliefs (LBP.py:592-619, 528-574) so that no
+ * belief matrix is materialised:
+ *   pairwise en_en factor p: grad_k += phi[l0][l1][k] - sum_ij b_ij phi[i][j][k]
+ *   unary factor u:          grad_k += phi[lab][obs][k] - sum_x b_x phi[x][obs][k],  b = normalise(table)
+ * phi selection follows FactorNode.get_phi (LBP.py:469-480): kind 0 = phi_en_en (gap > 1),
+ * 1 = phi_en_en_w1 (gap == 1), 2 = phi_en_de.  All index arrays are DEVICE int32; per-graph indices
+ * are range-checked in the kernel (a bad index skips the factor and raises mlbp_gradient_status). */
+typedef struct mlbp_gradient_args {
+  int32_t B, X, n_msgs, P, U;
+  int32_t F_ee, F_ed;           /* feature counts: (3, 6) as train_mp.py:520-523; (2,2), (1,1) also built */
+  int32_t Vde;                  /* columns of phi_en_de / pot_en_de                                 */
+  int32_t n_pair_tables, n_unary_tables;
+  const double* msgs;           /* [B][n_msgs][X]                                                   */
+  const double* pair_tables;    /* [n_pair_tables][X][X]                                            */
+  const int32_t* pair_tab;      /* [B][P]                                                           */
+  const int32_t* pair_c_slot;   /* [P] message slot  (dim-0 variable -> factor)                     */
+  const int32_t* pair_r_slot;   /* [P] message slot  (dim-1 variable -> factor)                     */
+  const int32_t* pair_phi;      /* [P] 0 / 1                                                        */
+  const int32_t* pair_label;    /* [B][P][2] supervised label index of the dim-0 / dim-1 variable   */
+  const double* unary_tables;   /* [n_unary_tables][X]                                              */
+  const int32_t* unary_tab;     /* [B][U]                                                           */
+  const int32_t* unary_kind;    /* [U] 0 / 1 / 2                                                    */
+  const int32_t* unary_obs;     /* [B][U] observed column (PotentialTable.observed_dim)             */
+  const int32_t* unary_label;   /* [B][U] supervised label index of the factor's variable           */
+  const double* phi_en_en;      /* [X][X][F_ee]                                                     */
+  const double* phi_en_en_w1;   /* [X][X][F_ee]                                                     */
+  const double* phi_en_de;      /* [X][Vde][F_ed]                                                   */
+  double* grad_en_en;           /* out [B][F_ee]                                                    */
+  double* grad_en_de;           /* out [B][F_ed]                                                    */
+} mlbp_gradient_args;
+int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream);
+int mlbp_gradient_status(void); /* synchronising read-and-reset: 1 = some factor was skipped        */
+
+/* out[j] = sum over rows of in[rows][cols], fixed summation order (bitwise reproducible): the
+ * device half of batch_sgd_accumulate (train_mp.py:405-424). */
+int mlbp_sum_rows_f64(const double* in, int64_t rows, int32_t cols, double* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * DEVICE: array primitives (the c_array_utils surface), batched over `batch` independent items
  * ------------------------------------------------------------------------------------------- */
 /* au.dense_dot (c_array_utils.pyx:90-91): C[b] = A[b] (M x K) . B[b] (K x N), arbitrary element
@@ -224,6 +273,13 @@ int mlbp_sparse_pointwise_multiply_f64(const double* sparse_m, const double* den
  * zero-sum guard, like the reference).  scratch1: device double[1]. */
 int mlbp_sparse_normalize_f64(double* m, int32_t n_cols, const int32_t* cidx, int32_t Kc, const int32_t* ridx,
                               int32_t Kr, double* scratch1, void* stream);
+
+/* Potential construction, the step just before the path (train_mp.py:220-255):
+ * pot[i][j] = exp(sum_k phi[i][j][k] * theta[k]).  pot (row-major [rows][cols]) and/or pot_t (its
+ * transpose [cols][rows], so a unary factor's column PotentialTable.slice_potentials takes,
+ * LBP.py:702-703, is one contiguous row) may be NULL.  theta: device [F]. */
+int mlbp_potentials_f64(const double* phi, const double* theta, int32_t rows, int32_t cols, int32_t F, double* pot,
+                        double* pot_t, void* stream);
 
 /* Elementwise natural log (np.log at LBP.py:139, 252, 408, 411: log-marginal read-outs). */
 int mlbp_log_f64(const double* in, double* out, int64_t n, void* stream);

@@ -27,6 +27,17 @@ class Topology(C.Structure):
                 ('var_fac', C.POINTER(C.c_int32))]
 
 
+class GradientArgs(C.Structure):
+    _fields_ = [('B', C.c_int32), ('X', C.c_int32), ('n_msgs', C.c_int32), ('P', C.c_int32), ('U', C.c_int32),
+                ('F_ee', C.c_int32), ('F_ed', C.c_int32), ('Vde', C.c_int32), ('n_pair_tables', C.c_int32),
+                ('n_unary_tables', C.c_int32), ('msgs', C.c_void_p), ('pair_tables', C.c_void_p),
+                ('pair_tab', C.c_void_p), ('pair_c_slot', C.c_void_p), ('pair_r_slot', C.c_void_p),
+                ('pair_phi', C.c_void_p), ('pair_label', C.c_void_p), ('unary_tables', C.c_void_p),
+                ('unary_tab', C.c_void_p), ('unary_kind', C.c_void_p), ('unary_obs', C.c_void_p),
+                ('unary_label', C.c_void_p), ('phi_en_en', C.c_void_p), ('phi_en_en_w1', C.c_void_p),
+                ('phi_en_de', C.c_void_p), ('grad_en_en', C.c_void_p), ('grad_en_de', C.c_void_p)]
+
+
 class SweepArgs(C.Structure):
     _fields_ = [('B', C.c_int32), ('X', C.c_int32), ('n_pair_tables', C.c_int32),
                 ('n_unary_tables', C.c_int32), ('pair_tables', C.c_void_p), ('pair_tab', C.c_void_p),
@@ -57,6 +68,10 @@ SIGNATURES = {
     'mlbp_init_messages_f64': (C.c_int, [_vp, _i64, _i32, _vp]),
     'mlbp_marginals_f64': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     'mlbp_log_posterior_f64': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    'mlbp_pair_beliefs_f64': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    'mlbp_gradient_f64': (C.c_int, [C.POINTER(GradientArgs), _vp]),
+    'mlbp_gradient_status': (C.c_int, []),
+    'mlbp_sum_rows_f64': (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     'mlbp_dense_dot_f64': (C.c_int, [_i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _vp, _i64, _i64,
                                      _i64, _vp, _i64, _i64, _vp]),
     'mlbp_pointwise_multiply_f64': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
@@ -66,6 +81,7 @@ SIGNATURES = {
     'mlbp_sparse_dot_f64': (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     'mlbp_sparse_pointwise_multiply_f64': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp]),
     'mlbp_sparse_normalize_f64': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp]),
+    'mlbp_potentials_f64': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     'mlbp_log_f64': (C.c_int, [_vp, _vp, _i64, _vp]),
     'mlbp_observed_minus_f64': (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
 }

@@ -170,3 +170,113 @@ class FactorGraphBatch:
         _ffi.check(_ffi.lib.mlbp_log_posterior_f64(m.data_ptr(), lab_d.data_ptr(), self.B, self.topo.n_vars,
                                                    self.X, out.data_ptr(), _stream_ptr(self.device)))
         return out
+
+    # ---- beliefs / gradient (LBP.py:528-619, 301-320) ---------------------------------------------
+    def _pair_slots(self):
+        """device int32 [P] message slots of the dim-0 / dim-1 variable -> factor messages."""
+        if not hasattr(self, '_c_slot'):
+            topo = self.topo
+            c, r = [], []
+            for j in topo.pair_factors:
+                k0 = 0 if topo.fac_dim[2 * j] == 0 else 1          # varset position sitting on table axis 0
+                c.append(int(topo.v2f[2 * j + k0]))
+                r.append(int(topo.v2f[2 * j + 1 - k0]))
+            self._c_slot = torch.tensor(c or [0], dtype=torch.int32, device=self.device)
+            self._r_slot = torch.tensor(r or [0], dtype=torch.int32, device=self.device)
+        return self._c_slot, self._r_slot
+
+    def pair_beliefs(self):
+        """[B][P][X][X]: FactorNode.get_factor_beliefs of every pairwise factor (LBP.py:543-569)."""
+        c, r = self._pair_slots()
+        out = torch.empty(self.B, self.topo.P, self.X, self.X, dtype=torch.float64, device=self.device)
+        _ffi.check(_ffi.lib.mlbp_pair_beliefs_f64(self.msgs.data_ptr(), self.B, self.topo.n_msgs, self.X, self.topo.P,
+                                                  self.pair_tables.data_ptr(), self.pair_tab.data_ptr(),
+                                                  self.pair_tables.shape[0], c.data_ptr(), r.data_ptr(),
+                                                  out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
+    def set_features(self, phi_en_en, phi_en_en_w1, phi_en_de, pair_phi, unary_kind):
+        """Feature tensors (X,X,F_ee) x2 and (X,Vde,F_ed) shared by the batch, and the per-slot
+        selector FactorNode.get_phi implies (LBP.py:469-480): pair_phi[p] in {0: gap > 1, 1: gap == 1},
+        unary_kind[u] in {0, 1 (en_en by gap), 2 (en_de)}."""
+        dev = self.device
+        self.phi_en_en = torch.as_tensor(phi_en_en, dtype=torch.float64).to(dev).contiguous()
+        self.phi_en_en_w1 = torch.as_tensor(phi_en_en_w1, dtype=torch.float64).to(dev).contiguous()
+        self.phi_en_de = torch.as_tensor(phi_en_de, dtype=torch.float64).to(dev).contiguous()
+        X = self.X
+        if tuple(self.phi_en_en.shape[:2]) != (X, X) or self.phi_en_en_w1.shape != self.phi_en_en.shape or \
+                self.phi_en_de.shape[0] != X:
+            raise ValueError('feature tensors must be (X,X,F_ee), (X,X,F_ee), (X,Vde,F_ed)')
+        pp = np.asarray(pair_phi, dtype=np.int64).reshape(self.topo.P)
+        uk = np.asarray(unary_kind, dtype=np.int64).reshape(self.topo.U)
+        if (pp.size and (pp.min() < 0 or pp.max() > 1)) or (uk.size and (uk.min() < 0 or uk.max() > 2)):
+            raise ValueError('pair_phi must be 0/1 and unary_kind 0/1/2')
+        self._pair_phi = torch.from_numpy(np.ascontiguousarray(pp if pp.size else np.zeros(1)).astype(np.int32)).to(dev)
+        self._unary_kind = torch.from_numpy(np.ascontiguousarray(uk if uk.size else np.zeros(1)).astype(np.int32)).to(dev)
+        self._unary_kind_host = uk
+
+    def set_observations(self, var_labels, unary_obs):
+        """var_labels [B][n_vars]: supervised label index per variable (GraphTopology.var_ids order);
+        unary_obs [B][U]: observed column of each unary factor (PotentialTable.observed_dim)."""
+        topo, B, X = self.topo, self.B, self.X
+        lab = np.asarray(var_labels, dtype=np.int64).reshape(B, topo.n_vars)
+        obs = np.asarray(unary_obs, dtype=np.int64).reshape(B, topo.U)
+        if lab.min() < 0 or lab.max() >= X:
+            raise IndexError('label index out of range')
+        Vde = int(self.phi_en_de.shape[1])
+        for u in range(topo.U):
+            lim = Vde if self._unary_kind_host[u] == 2 else X
+            if obs[:, u].min() < 0 or obs[:, u].max() >= lim:
+                raise IndexError('observed column out of range for unary slot %d' % u)
+        pl = np.zeros((B, max(topo.P, 1), 2), dtype=np.int32)
+        for p, j in enumerate(topo.pair_factors):
+            k0 = 0 if topo.fac_dim[2 * j] == 0 else 1
+            pl[:, p, 0] = lab[:, topo.fac_var[2 * j + k0]]
+            pl[:, p, 1] = lab[:, topo.fac_var[2 * j + 1 - k0]]
+        ul = np.zeros((B, max(topo.U, 1)), dtype=np.int32)
+        for u, j in enumerate(topo.unary_factors):
+            ul[:, u] = lab[:, topo.fac_var[2 * j]]
+        dev = self.device
+        self._labels = torch.from_numpy(lab.astype(np.int32)).to(dev)
+        self._pair_label = torch.from_numpy(pl).to(dev)
+        self._unary_label = torch.from_numpy(ul).to(dev)
+        self._unary_obs = torch.from_numpy(np.ascontiguousarray(obs if topo.U else np.zeros((B, 1))).astype(np.int32)).to(dev)
+
+    def gradient(self, out_ee=None, out_ed=None):
+        """Per-graph unregularised gradients ([B][F_ee], [B][F_ed]):
+        FactorGraph.get_unregularized_gradeint (LBP.py:301-320), beliefs fused in."""
+        topo = self.topo
+        F_ee, F_ed = int(self.phi_en_en.shape[2]), int(self.phi_en_de.shape[2])
+        if out_ee is None:
+            out_ee = torch.empty(self.B, F_ee, dtype=torch.float64, device=self.device)
+        if out_ed is None:
+            out_ed = torch.empty(self.B, F_ed, dtype=torch.float64, device=self.device)
+        c, r = self._pair_slots()
+        a = _ffi.GradientArgs()
+        a.B, a.X, a.n_msgs, a.P, a.U = self.B, self.X, topo.n_msgs, topo.P, topo.U
+        a.F_ee, a.F_ed, a.Vde = F_ee, F_ed, int(self.phi_en_de.shape[1])
+        a.msgs = self.msgs.data_ptr()
+        if topo.P:
+            a.n_pair_tables = self.pair_tables.shape[0]
+            a.pair_tables, a.pair_tab = self.pair_tables.data_ptr(), self.pair_tab.data_ptr()
+            a.pair_c_slot, a.pair_r_slot = c.data_ptr(), r.data_ptr()
+            a.pair_phi, a.pair_label = self._pair_phi.data_ptr(), self._pair_label.data_ptr()
+        if topo.U:
+            a.n_unary_tables = self.unary_tables.shape[0]
+            a.unary_tables, a.unary_tab = self.unary_tables.data_ptr(), self.unary_tab.data_ptr()
+            a.unary_kind, a.unary_obs = self._unary_kind.data_ptr(), self._unary_obs.data_ptr()
+            a.unary_label = self._unary_label.data_ptr()
+        a.phi_en_en, a.phi_en_en_w1 = self.phi_en_en.data_ptr(), self.phi_en_en_w1.data_ptr()
+        a.phi_en_de = self.phi_en_de.data_ptr()
+        a.grad_en_en, a.grad_en_de = out_ee.data_ptr(), out_ed.data_ptr()
+        _ffi.check(_ffi.lib.mlbp_gradient_f64(C.byref(a), _stream_ptr(self.device)))
+        return out_ee, out_ed
+
+    def sum_rows(self, t, out=None):
+        """Column sums of a [rows][cols] device tensor in a fixed order (mlbp_sum_rows_f64)."""
+        t2 = t.reshape(t.shape[0], -1)
+        if out is None:
+            out = torch.empty(t2.shape[1], dtype=torch.float64, device=self.device)
+        _ffi.check(_ffi.lib.mlbp_sum_rows_f64(t2.data_ptr(), t2.shape[0], t2.shape[1], out.data_ptr(),
+                                              _stream_ptr(self.device)))
+        return out

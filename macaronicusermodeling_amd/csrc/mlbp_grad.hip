@@ -1,0 +1,306 @@
+// Factor beliefs and the log-linear gradient, batched over graphs (gfx950).
+//
+// Reference path: FactorNode.get_factor_beliefs (LBP.py:528-574), cell_gradient (LBP.py:615-619),
+// get_gradient (LBP.py:592-613) and FactorGraph.get_unregularized_gradeint (LBP.py:301-320).
+// The reference materialises three X*X temporaries per pairwise factor (outer product, product
+// with the table, normalised beliefs) and then contracts with the (X,X,F) feature tensor.  Here one
+// pass over the table accumulates Z = sum c_i r_j T_ij and S_k = sum c_i r_j T_ij phi_ijk, and
+//     grad_k = phi[l0][l1][k] - S_k / Z            (zero beliefs when Z <= 0, like au.normalize)
+// so the belief matrix never exists in memory.  Per pairwise factor the HBM traffic is the table
+// (X*X*8 bytes, unique per graph) -- the feature tensors are shared by the whole batch and stay in
+// L2.  One workgroup per graph; wave-level reductions; results per graph, summed over the batch by
+// mlbp_sum_rows_f64 (the device half of train_mp.py's accumulate callback).
+#include <hip/hip_runtime.h>
+
+#include "mlbp_internal.h"
+
+using mlbp::fail;
+
+namespace {
+
+constexpr int WG = 256;
+constexpr int FMAX = 8;
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) return fail(MLBP_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+}
+
+struct GradDev {
+  mlbp_gradient_args a;
+  int32_t* status;
+};
+
+// sums[0..n) over the workgroup; result valid in every thread.  scratch: [4][FMAX+1] doubles.
+template <int N>
+__device__ __forceinline__ void block_sums(double (&v)[N], double* scratch) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) scratch[(threadIdx.x >> 6) * N + k] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = (scratch[k] + scratch[N + k]) + (scratch[2 * N + k] + scratch[3 * N + k]);
+}
+
+template <int F>
+__device__ void pair_gradient(const GradDev& d, int g, int p, double* scratch, double* out) {
+  const mlbp_gradient_args& a = d.a;
+  const int X = a.X;
+  const int tab = a.pair_tab[(size_t)g * a.P + p];
+  const int l0 = a.pair_label[((size_t)g * a.P + p) * 2], l1 = a.pair_label[((size_t)g * a.P + p) * 2 + 1];
+  const bool ok = (unsigned)tab < (unsigned)a.n_pair_tables && (unsigned)l0 < (unsigned)X && (unsigned)l1 < (unsigned)X;
+  if (!ok) {
+    if (threadIdx.x == 0) atomicExch(d.status, 1);
+    return;
+  }
+  const double* T = a.pair_tables + (size_t)tab * X * X;
+  const double* phi = a.pair_phi[p] ? a.phi_en_en_w1 : a.phi_en_en;
+  const double* c = a.msgs + ((size_t)g * a.n_msgs + a.pair_c_slot[p]) * X;
+  const double* r = a.msgs + ((size_t)g * a.n_msgs + a.pair_r_slot[p]) * X;
+  double acc[F + 1];
+#pragma unroll
+  for (int k = 0; k <= F; ++k) acc[k] = 0.0;
+  for (int e = threadIdx.x; e < X * X; e += WG) {
+    const int i = e / X, j = e - i * X;
+    const double w = (c[i] * r[j]) * T[e];     // (c.r) then * T: the reference's order (LBP.py:566-568)
+    acc[0] += w;
+#pragma unroll
+    for (int k = 0; k < F; ++k) acc[1 + k] += w * phi[(size_t)e * F + k];
+  }
+  block_sums<F + 1>(acc, scratch);
+  const double Z = acc[0];
+#pragma unroll
+  for (int k = 0; k < F; ++k) {
+    const double expect = Z > 0.0 ? acc[1 + k] / Z : 0.0;
+    out[k] += phi[((size_t)l0 * X + l1) * F + k] - expect;
+  }
+}
+
+// One wave per unary factor: beliefs = au.normalize(table) (LBP.py:540), gradient
+// g^T . phi[:, observed_dim, :] (LBP.py:600-603).
+template <int F>
+__device__ void unary_gradient(const GradDev& d, int g, int u, const double* phi, int cols, double* out) {
+  const mlbp_gradient_args& a = d.a;
+  const int X = a.X;
+  const int lane = threadIdx.x & 63;
+  const int tab = a.unary_tab[(size_t)g * a.U + u];
+  const int obs = a.unary_obs[(size_t)g * a.U + u];
+  const int lab = a.unary_label[(size_t)g * a.U + u];
+  const bool ok = (unsigned)tab < (unsigned)a.n_unary_tables && (unsigned)obs < (unsigned)cols && (unsigned)lab < (unsigned)X;
+  if (!ok) {
+    if (lane == 0) atomicExch(d.status, 1);
+    return;
+  }
+  const double* t = a.unary_tables + (size_t)tab * X;
+  double acc[F + 1];
+#pragma unroll
+  for (int k = 0; k <= F; ++k) acc[k] = 0.0;
+  for (int x = lane; x < X; x += 64) {
+    const double w = t[x];
+    acc[0] += w;
+#pragma unroll
+    for (int k = 0; k < F; ++k) acc[1 + k] += w * phi[((size_t)x * cols + obs) * F + k];
+  }
+#pragma unroll
+  for (int k = 0; k <= F; ++k) acc[k] = wave_sum(acc[k]);
+  const double Z = acc[0];
+#pragma unroll
+  for (int k = 0; k < F; ++k) {
+    const double expect = Z > 0.0 ? acc[1 + k] / Z : 0.0;
+    out[k] += phi[((size_t)lab * cols + obs) * F + k] - expect;
+  }
+}
+
+template <int FEE, int FED>
+__global__ __launch_bounds__(WG) void gradient_kernel(GradDev d) {
+  __shared__ double scratch[4 * (FMAX + 1)];
+  __shared__ double wave_out[4][2 * FMAX];
+  const mlbp_gradient_args& a = d.a;
+  const int g = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // pairwise factors: whole workgroup per factor (all are en_en, LBP.py:305-315)
+  double gee[FEE];
+#pragma unroll
+  for (int k = 0; k < FEE; ++k) gee[k] = 0.0;
+  for (int p = 0; p < a.P; ++p) pair_gradient<FEE>(d, g, p, scratch, gee);
+  // unary factors: one wave each
+  double uee[FEE], ued[FED];
+#pragma unroll
+  for (int k = 0; k < FEE; ++k) uee[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < FED; ++k) ued[k] = 0.0;
+  for (int u = wave; u < a.U; u += 4) {
+    const int kind = a.unary_kind[u];
+    if (kind == 2) unary_gradient<FED>(d, g, u, a.phi_en_de, a.Vde, ued);
+    else unary_gradient<FEE>(d, g, u, kind ? a.phi_en_en_w1 : a.phi_en_en, a.X, uee);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < FEE; ++k) wave_out[wave][k] = uee[k];
+#pragma unroll
+    for (int k = 0; k < FED; ++k) wave_out[wave][FMAX + k] = ued[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < FEE; ++k)
+      a.grad_en_en[(size_t)g * FEE + k] = gee[k] + ((wave_out[0][k] + wave_out[1][k]) + (wave_out[2][k] + wave_out[3][k]));
+#pragma unroll
+    for (int k = 0; k < FED; ++k)
+      a.grad_en_de[(size_t)g * FED + k] =
+          (wave_out[0][FMAX + k] + wave_out[1][FMAX + k]) + (wave_out[2][FMAX + k] + wave_out[3][FMAX + k]);
+  }
+}
+
+// beliefs of every pairwise factor, materialised: out[b][p][i][j]
+__global__ __launch_bounds__(WG) void pair_beliefs_kernel(const double* msgs, int n_msgs, int X, int P,
+                                                          const double* tables, const int32_t* pair_tab,
+                                                          int n_tables, const int32_t* c_slot, const int32_t* r_slot,
+                                                          double* out, int32_t* status) {
+  __shared__ double scratch[4];
+  const int g = blockIdx.x / P, p = blockIdx.x % P;
+  const int tab = pair_tab[(size_t)g * P + p];
+  if ((unsigned)tab >= (unsigned)n_tables) {
+    if (threadIdx.x == 0) atomicExch(status, 1);
+    return;
+  }
+  const double* T = tables + (size_t)tab * X * X;
+  const double* c = msgs + ((size_t)g * n_msgs + c_slot[p]) * X;
+  const double* r = msgs + ((size_t)g * n_msgs + r_slot[p]) * X;
+  double* o = out + (size_t)blockIdx.x * X * X;
+  double part = 0.0;
+  for (int e = threadIdx.x; e < X * X; e += WG) {
+    const int i = e / X, j = e - i * X;
+    const double w = (c[i] * r[j]) * T[e];
+    o[e] = w;
+    part += w;
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const double Z = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+  for (int e = threadIdx.x; e < X * X; e += WG) o[e] = Z > 0.0 ? o[e] / Z : 0.0;
+}
+
+// out[j] = sum_b in[b][j]; deterministic (fixed order), one workgroup.
+__global__ __launch_bounds__(WG) void sum_rows_kernel(const double* in, int64_t rows, int cols, double* out) {
+  __shared__ double part[WG];
+  for (int j = 0; j < cols; ++j) {
+    double acc = 0.0;
+    for (int64_t b = threadIdx.x; b < rows; b += WG) acc += in[b * cols + j];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = WG / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[j] = part[0];
+    __syncthreads();
+  }
+}
+
+int32_t* g_status = nullptr;
+int status_word(int32_t** out) {
+  if (!g_status) {
+    HIP_TRY(hipMalloc(&g_status, sizeof(int32_t)));
+    HIP_TRY(hipMemset(g_status, 0, sizeof(int32_t)));
+  }
+  *out = g_status;
+  return MLBP_OK;
+}
+
+int need_device() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(MLBP_ENODEVICE, "no HIP device visible: libmlbp.so has no CPU fallback");
+  }
+  return MLBP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream) {
+  if (!a) return fail(MLBP_EINVAL, "mlbp_gradient_f64: NULL args");
+  if (a->B <= 0 || a->X <= 0 || a->n_msgs <= 0 || a->P < 0 || a->U < 0)
+    return fail(MLBP_EINVAL, "mlbp_gradient_f64: bad sizes");
+  if (!((a->F_ee == 3 && a->F_ed == 6) || (a->F_ee == 2 && a->F_ed == 2) || (a->F_ee == 1 && a->F_ed == 1)))
+    return fail(MLBP_EUNSUPPORTED, "mlbp_gradient_f64: feature counts (%d, %d) not instantiated (3/6, 2/2, 1/1)", a->F_ee, a->F_ed);
+  if (!a->msgs || !a->grad_en_en || !a->grad_en_de) return fail(MLBP_EINVAL, "mlbp_gradient_f64: NULL buffers");
+  if (a->P > 0 && (!a->pair_tables || !a->pair_tab || !a->pair_c_slot || !a->pair_r_slot || !a->pair_phi || !a->pair_label ||
+                   !a->phi_en_en || !a->phi_en_en_w1))
+    return fail(MLBP_EINVAL, "mlbp_gradient_f64: pairwise inputs missing");
+  if (a->U > 0 && (!a->unary_tables || !a->unary_tab || !a->unary_kind || !a->unary_obs || !a->unary_label ||
+                   !a->phi_en_en || !a->phi_en_en_w1 || !a->phi_en_de || a->Vde <= 0))
+    return fail(MLBP_EINVAL, "mlbp_gradient_f64: unary inputs missing");
+  if (int e = need_device()) return e;
+  GradDev d;
+  d.a = *a;
+  if (int e = status_word(&d.status)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  if (a->F_ee == 3) hipLaunchKernelGGL((gradient_kernel<3, 6>), dim3(a->B), dim3(WG), 0, st, d);
+  else if (a->F_ee == 2) hipLaunchKernelGGL((gradient_kernel<2, 2>), dim3(a->B), dim3(WG), 0, st, d);
+  else hipLaunchKernelGGL((gradient_kernel<1, 1>), dim3(a->B), dim3(WG), 0, st, d);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_pair_beliefs_f64(const double* msgs, int32_t B, int32_t n_msgs, int32_t X, int32_t P,
+                          const double* pair_tables, const int32_t* pair_tab, int32_t n_pair_tables,
+                          const int32_t* c_slot, const int32_t* r_slot, double* out, void* stream) {
+  if (!msgs || !pair_tables || !pair_tab || !c_slot || !r_slot || !out || B <= 0 || P <= 0 || X <= 0 || n_msgs <= 0)
+    return fail(MLBP_EINVAL, "mlbp_pair_beliefs_f64: bad arguments");
+  if (int e = need_device()) return e;
+  int32_t* status = nullptr;
+  if (int e = status_word(&status)) return e;
+  hipLaunchKernelGGL(pair_beliefs_kernel, dim3(B * P), dim3(WG), 0, (hipStream_t)stream, msgs, n_msgs, X, P, pair_tables,
+                     pair_tab, n_pair_tables, c_slot, r_slot, out, status);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_sum_rows_f64(const double* in, int64_t rows, int32_t cols, double* out, void* stream) {
+  if (!in || !out || rows <= 0 || cols <= 0) return fail(MLBP_EINVAL, "mlbp_sum_rows_f64: bad arguments");
+  if (int e = need_device()) return e;
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(WG), 0, (hipStream_t)stream, in, rows, cols, out);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_gradient_status(void) {
+  // Synchronising read-and-reset: 1 when a gradient / belief kernel skipped a factor because a table,
+  // label or observed-column index was out of range.
+  if (!g_status) return 0;
+  int32_t v = 0, zero = 0;
+  HIP_TRY(hipMemcpy(&v, g_status, sizeof(v), hipMemcpyDeviceToHost));
+  if (v) HIP_TRY(hipMemcpy(g_status, &zero, sizeof(zero), hipMemcpyHostToDevice));
+  return v;
+}
+
+}  // extern "C"

@@ -168,6 +168,24 @@ __global__ __launch_bounds__(256) void block_sum_kernel(const double* a, int n_c
   if (threadIdx.x == 0) *total = part[0] + part[1] + part[2] + part[3];
 }
 
+// pot[i][j] = exp(sum_k phi[i][j][k] * theta[k])  (train_mp.py:220-255), written in both layouts:
+// row-major [rows][cols] for pairwise tables and transposed [cols][rows] so that a unary factor's
+// table (a COLUMN of the pot, LBP.py:702-703) is one contiguous row for the sweep kernel.
+__global__ void potentials_kernel(const double* phi, const double* theta, int rows, int cols, int F, double* pot,
+                                  double* pot_t) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int k = 0; k < F; ++k) acc += phi[e * F + k] * theta[k];
+    const double v = exp(acc);
+    if (pot) pot[e] = v;
+    if (pot_t) {
+      const int64_t i = e / cols, j = e - i * cols;
+      pot_t[j * rows + i] = v;
+    }
+  }
+}
+
 __global__ void log_kernel(const double* in, double* out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = log(in[i]);
@@ -291,6 +309,19 @@ int mlbp_sparse_normalize_f64(double* m, int32_t n_cols, const int32_t* cidx, in
   hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, m, n_cols, cidx, Kc, ridx, Kr, scratch1);
   HIP_TRY(hipGetLastError());
   return launch_block_op(2, m, nullptr, scratch1, n_cols, cidx, Kc, ridx, Kr, m, stream);
+}
+
+int mlbp_potentials_f64(const double* phi, const double* theta, int32_t rows, int32_t cols, int32_t F, double* pot,
+                        double* pot_t, void* stream) {
+  if (!phi || !theta || rows <= 0 || cols <= 0 || F <= 0 || (!pot && !pot_t))
+    return fail(MLBP_EINVAL, "mlbp_potentials_f64: bad arguments");
+  if (int e = need_device()) return e;
+  const int64_t n = (int64_t)rows * cols;
+  int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(potentials_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, phi, theta, rows, cols, F, pot,
+                     pot_t);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
 }
 
 int mlbp_log_f64(const double* in, double* out, int64_t n, void* stream) {

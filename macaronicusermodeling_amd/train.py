@@ -1,0 +1,127 @@
+"""The train_mp.py-shaped outer step on the GPU: potentials -> sweeps -> gradient -> reduce -> theta.
+
+Mirrors `batch_sgd` (train_mp.py:362-402) + `batch_sgd_accumulate` (train_mp.py:405-424) for a
+whole shard of instances at once:
+
+    pots   = exp(phi . theta^T)                       train_mp.py:220-255   mlbp_potentials_f64
+    fg.initialize(); fg.treelike_inference(3)         train_mp.py:381-382   mlbp_sweep_f64 (init fused)
+    g_en_en, g_en_de = fg.return_gradient()           train_mp.py:398       mlbp_gradient_f64
+    p = fg.get_posterior_probs()                      train_mp.py:400       mlbp_marginals / log_posterior
+    theta += sum_i lr (g_i - reg theta)               train_mp.py:405-424   mlbp_sum_rows_f64 + all-reduce
+
+The reference applies each instance's step as its worker finishes (stale, asynchronous); here every
+instance of a step sees the same theta and the steps are summed -- identical to the reference when
+all tasks were pickled with the same theta.
+
+Pairwise tables are the two shared pots (`pot_en_en`, `pot_en_en_w1`) referenced through the
+table-index indirection; a unary factor's table is a COLUMN of a pot (LBP.py:702-703), read as a
+row of the transposed pot the potentials kernel also writes -- no per-instance copies.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi, dist as mdist
+from .batch import FactorGraphBatch, _stream_ptr
+from .topology import GraphTopology
+
+
+class UserGraphTrainer:
+    def __init__(self, spec, var_labels, unary_obs, phi_en_en, phi_en_en_w1, phi_en_de, theta_en_en, theta_en_de,
+                 device='cuda:0', sweeps=3, roots=None):
+        """spec: a 'trainmp'-style spec (tests/golden/cases.py: factors carry factor_type / gap);
+        var_labels [B][n_vars], unary_obs [B][U]: this rank's shard of instances."""
+        self.spec = spec
+        self.topo = topo = GraphTopology.from_spec(spec)
+        by_id = {f['id']: f for f in spec['factors']}
+        X = spec['X']
+        self.device = torch.device(device)
+        B = int(np.asarray(var_labels).shape[0])
+        self.batch = fb = FactorGraphBatch(topo, X, B, device=self.device)
+        pair_phi, unary_kind = [], []
+        for j in topo.pair_factors:
+            f = by_id[topo.factor_ids[j]]
+            if f['factor_type'] != 'en_en' or f['gap'] < 1:
+                raise BaseException('only 2 kinds of distances are supported ...')      # LBP.py:463
+            pair_phi.append(0 if f['gap'] > 1 else 1)
+        for j in topo.unary_factors:
+            f = by_id[topo.factor_ids[j]]
+            if f['factor_type'] == 'en_de':
+                unary_kind.append(2)
+            elif f['factor_type'] == 'en_en' and f['gap'] >= 1:
+                unary_kind.append(0 if f['gap'] > 1 else 1)
+            else:
+                raise BaseException('only two kinds of potentials are supported...')    # LBP.py:467
+        fb.set_features(phi_en_en, phi_en_en_w1, phi_en_de, pair_phi, unary_kind)
+        fb.set_observations(var_labels, unary_obs)
+        self.Vde = int(fb.phi_en_de.shape[1])
+        self.F_ee, self.F_ed = int(fb.phi_en_en.shape[2]), int(fb.phi_en_de.shape[2])
+        dev = self.device
+        self.theta_en_en = torch.as_tensor(np.asarray(theta_en_en, dtype=np.float64).reshape(-1)).to(dev)
+        self.theta_en_de = torch.as_tensor(np.asarray(theta_en_de, dtype=np.float64).reshape(-1)).to(dev)
+        # pots: [pot_en_en, pot_en_en_w1] as pairwise tables; their transposes + pot_en_de^T as unary rows
+        self.pair_tables = torch.empty(2, X, X, dtype=torch.float64, device=dev)
+        self.unary_tables = torch.empty(2 * X + self.Vde, X, dtype=torch.float64, device=dev)
+        fb.pair_tables = self.pair_tables
+        fb.pair_tab = torch.from_numpy(np.tile(np.array(pair_phi or [0], dtype=np.int32), (B, 1))).to(dev)
+        obs = np.asarray(unary_obs, dtype=np.int64).reshape(B, topo.U)
+        base = np.array([0, X, 2 * X], dtype=np.int64)[np.array(unary_kind, dtype=np.int64)] if topo.U else np.zeros(0)
+        fb.unary_tables = self.unary_tables
+        fb.unary_tab = torch.from_numpy((obs + base[None, :]).astype(np.int32)).to(dev)
+        self.sweeps = int(sweeps)
+        self.roots = list(roots) if roots is not None else [topo.var_ids[i % topo.n_vars] for i in range(self.sweeps)]
+        fb.is_loopy = topo.has_loops(self.roots[0])
+        self.n_sweeps_run = self.sweeps if fb.is_loopy else 1                            # LBP.py:219
+        self._g_ee = torch.empty(B, self.F_ee, dtype=torch.float64, device=dev)
+        self._g_ed = torch.empty(B, self.F_ed, dtype=torch.float64, device=dev)
+        self._marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)
+        self._lp = torch.empty(B, dtype=torch.float64, device=dev)
+        self._rows = torch.empty(B, self.F_ee + self.F_ed + 2, dtype=torch.float64, device=dev)
+        self.stats = torch.zeros(self.F_ee + self.F_ed + 2, dtype=torch.float64, device=dev)
+
+    def build_potentials(self):
+        fb, X, st = self.batch, self.spec['X'], _stream_ptr(self.device)
+        ut = self.unary_tables
+        _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_en.data_ptr(), self.theta_en_en.data_ptr(), X, X, self.F_ee,
+                                                self.pair_tables[0].data_ptr(), ut[0:X].data_ptr(), st))
+        _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_en_w1.data_ptr(), self.theta_en_en.data_ptr(), X, X, self.F_ee,
+                                                self.pair_tables[1].data_ptr(), ut[X:2 * X].data_ptr(), st))
+        _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_de.data_ptr(), self.theta_en_de.data_ptr(), X, self.Vde,
+                                                self.F_ed, None, ut[2 * X:].data_ptr(), st))
+
+    def local_statistics(self):
+        """Runs inference on this rank's shard and returns the fused statistics buffer (device):
+        [sum_i grad_en_en (F_ee) | sum_i grad_en_de (F_ed) | sum_i log-posterior | instance count]."""
+        fb = self.batch
+        self.build_potentials()
+        fb.sweep(self.roots[:self.n_sweeps_run], init=True)
+        fb.gradient(self._g_ee, self._g_ed)
+        fb.marginals(out=self._marg)
+        _ffi.check(_ffi.lib.mlbp_log_posterior_f64(self._marg.data_ptr(), fb._labels.data_ptr(), fb.B, self.topo.n_vars,
+                                                   fb.X, self._lp.data_ptr(), _stream_ptr(self.device)))
+        r = self._rows
+        r[:, :self.F_ee] = self._g_ee
+        r[:, self.F_ee:self.F_ee + self.F_ed] = self._g_ed
+        r[:, -2] = self._lp
+        r[:, -1] = 1.0
+        fb.sum_rows(r, out=self.stats)
+        return self.stats
+
+    def step(self, learning_rate, reg_param):
+        """One synchronous optimisation step over ALL ranks' shards: returns (mean log-posterior,
+        theta_en_en, theta_en_de).  reg_param is FactorGraph.regularization_param, i.e. the reference's
+        `--reg_param / N` (train_mp.py:160)."""
+        stats = mdist.all_reduce_sum_(self.local_statistics())
+        apply_update(self.theta_en_en, self.theta_en_de, stats, self.F_ee, self.F_ed, learning_rate, reg_param)
+        return float(stats[-2].item() / stats[-1].item()), self.theta_en_en, self.theta_en_de
+
+
+def apply_update(theta_en_en, theta_en_de, stats, F_ee, F_ed, learning_rate, reg_param):
+    """theta += sum_i lr (g_i - reg theta) = lr (sum_i g_i - n reg theta): the sum of the per-instance
+    steps `return_gradient` produces (LBP.py:293-299, 322-327) as `batch_sgd_accumulate` adds them
+    (train_mp.py:419-424).  Works on CPU or device tensors (it is part of the gloo tests)."""
+    n = stats[-1]
+    theta_en_en += learning_rate * (stats[:F_ee] - n * reg_param * theta_en_en)
+    theta_en_de += learning_rate * (stats[F_ee:F_ee + F_ed] - n * reg_param * theta_en_de)
+    return theta_en_en, theta_en_de

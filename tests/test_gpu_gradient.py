@@ -1,0 +1,146 @@
+"""Batched beliefs / gradient kernels and the train_mp-shaped step against reference fixtures and
+the CPU oracle."""
+import numpy as np
+import pytest
+
+import cases as C
+from conftest import load_golden
+from helpers import batch_tables, case_inputs
+from oracle import lbp_oracle as O
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+USER_CASES = [c for c in C.inference_cases() if c['spec']['style'] == 'trainmp']
+
+
+def _meta(spec, topo):
+    by_id = {f['id']: f for f in spec['factors']}
+    pair_phi = [0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1 for j in topo.pair_factors]
+    kinds, obs = [], []
+    for j in topo.unary_factors:
+        f = by_id[topo.factor_ids[j]]
+        kinds.append(2 if f['factor_type'] == 'en_de' else (0 if f['gap'] > 1 else 1))
+        obs.append(f['observed_dim'])
+    label_of = dict(zip(spec['var_ids'], spec['labels']))
+    labels = [label_of[v] for v in topo.var_ids]
+    return pair_phi, kinds, obs, labels
+
+
+@pytest.mark.parametrize('case', USER_CASES, ids=lambda c: c['name'])
+def test_batched_gradient_and_beliefs(case):
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.batch import FactorGraphBatch
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = case['spec']
+    gold = load_golden(case['name'])
+    topo = GraphTopology.from_spec(spec)
+    nb = 3
+    inputs = case_inputs(case, nb)
+    # all graphs of the batch share graph 0's feature tensors (they are batch-level inputs); their
+    # potentials differ, which is what the kernels read per graph
+    for i in inputs[1:]:
+        for k in ('phi_en_en', 'phi_en_en_w1', 'phi_en_de'):
+            i[k] = inputs[0][k]
+    pair, unary = batch_tables(spec, topo, inputs)
+    fb = FactorGraphBatch(topo, spec['X'], nb)
+    if topo.P:
+        fb.set_pair_tables(pair)
+    fb.set_unary_tables(unary)
+    pair_phi, kinds, obs, labels = _meta(spec, topo)
+    fb.set_features(inputs[0]['phi_en_en'], inputs[0]['phi_en_en_w1'], inputs[0]['phi_en_de'], pair_phi, kinds)
+    fb.set_observations(np.tile(labels, (nb, 1)), np.tile(obs, (nb, 1)))
+    fb.initialize(case['roots'][0])
+    n = fb.treelike_inference(case.get('request', max(case['snaps'])), case['roots'] * 10)
+    g_ee, g_ed = fb.gradient()
+    assert _ffi.lib.mlbp_gradient_status() == 0
+    g_ee, g_ed = g_ee.cpu().numpy(), g_ed.cpu().numpy()
+    np.testing.assert_allclose(g_ee[0], gold['grad_unreg_en_en'].reshape(-1), rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(g_ed[0], gold['grad_unreg_en_de'].reshape(-1), rtol=1e-8, atol=1e-11)
+    g = O.Graph(spec)
+    for b in range(1, nb):
+        msgs = O.init_messages(g)
+        O.treelike_inference(g, inputs[b], msgs, n, case['roots'] * 10, True)
+        ee, ed = O.unregularized_gradient(g, inputs[b], msgs)
+        np.testing.assert_allclose(g_ee[b], ee.reshape(-1), rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(g_ed[b], ed.reshape(-1), rtol=1e-8, atol=1e-11)
+    if topo.P:
+        bel = fb.pair_beliefs().cpu().numpy()
+        for p, j in enumerate(topo.pair_factors):
+            np.testing.assert_allclose(bel[0, p], gold['belief_F%d' % topo.factor_ids[j]], rtol=1e-10, atol=1e-300)
+    tot = fb.sum_rows(torch.from_numpy(g_ed).to(fb.device)).cpu().numpy()
+    np.testing.assert_allclose(tot, g_ed.sum(0), rtol=1e-13)
+
+
+def test_zero_table_gives_zero_beliefs_like_au_normalize():
+    from macaronicusermodeling_amd.batch import FactorGraphBatch
+    from macaronicusermodeling_amd.topology import GraphTopology
+    case = USER_CASES[0]
+    spec = case['spec']
+    topo = GraphTopology.from_spec(spec)
+    inputs = case_inputs(case, 1)
+    pair, unary = batch_tables(spec, topo, inputs)
+    pair[0] = 0.0
+    fb = FactorGraphBatch(topo, spec['X'], 1)
+    fb.set_pair_tables(pair); fb.set_unary_tables(unary)
+    fb.initialize()
+    assert float(fb.pair_beliefs()[0, 0].abs().sum()) == 0.0
+
+
+def _instances(spec, topo, B, seed):
+    """Per-instance labels and observed columns (what differs between train_mp instances of one
+    sentence shape)."""
+    rs = np.random.RandomState(seed)
+    by_id = {f['id']: f for f in spec['factors']}
+    X, Vde = spec['X'], spec['Vde']
+    labels = rs.randint(0, X, size=(B, topo.n_vars))
+    obs = np.zeros((B, topo.U), dtype=np.int64)
+    for u, j in enumerate(topo.unary_factors):
+        f = by_id[topo.factor_ids[j]]
+        obs[:, u] = rs.randint(0, Vde if f['factor_type'] == 'en_de' else X, size=B)
+    return labels, obs
+
+
+def _oracle_step(spec, inputs, labels, obs, roots, lr, reg):
+    """sum over instances of return_gradient + log posterior, by the oracle."""
+    import copy
+    tot_ee = np.zeros_like(inputs['theta_en_en']); tot_ed = np.zeros_like(inputs['theta_en_de']); lp = 0.0
+    topo_vars = None
+    for b in range(labels.shape[0]):
+        s = copy.deepcopy(spec)
+        g0 = O.Graph(s)
+        topo_vars = g0.var_order
+        s['labels'] = [int(labels[b, topo_vars.index(v)]) for v in s['var_ids']]
+        unary_ids = [f['id'] for f in g0.factors if len(f['vars']) == 1]
+        for f in s['factors']:
+            if len(f['vars']) == 1:
+                f['observed_dim'] = int(obs[b, unary_ids.index(f['id'])])
+        g = O.Graph(s)
+        msgs = O.init_messages(g)
+        O.treelike_inference(g, inputs, msgs, len(roots), roots, O.has_loops(g, roots[0]))
+        ee, ed = O.return_gradient(g, inputs, msgs, reg, lr)
+        tot_ee += ee; tot_ed += ed
+        lp += O.log_posterior(g, msgs)
+    return tot_ee, tot_ed, lp
+
+
+def test_train_step_matches_sum_of_reference_steps():
+    """UserGraphTrainer.step == theta + sum_i return_gradient_i (train_mp.py:398, 419-424) with the
+    potentials built on the device from phi and theta (train_mp.py:220-255)."""
+    from macaronicusermodeling_amd.train import UserGraphTrainer
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = C.user_spec(10, [1, 4, 7], 64, 48, seed=1)
+    topo = GraphTopology.from_spec(spec)
+    inputs = C.make_inputs(spec, 77)
+    B, roots, lr, reg = 6, [4, 1, 7], 0.1, 0.2 / 6
+    labels, obs = _instances(spec, topo, B, 5)
+    tr = UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],
+                          inputs['theta_en_en'], inputs['theta_en_de'], roots=roots)
+    tr.build_potentials()
+    np.testing.assert_allclose(tr.pair_tables[0].cpu().numpy(), inputs['pot_en_en'], rtol=1e-14)
+    np.testing.assert_allclose(tr.unary_tables[2 * 64:].cpu().numpy(), inputs['pot_en_de'].T, rtol=1e-14)
+    mean_lp, t_ee, t_ed = tr.step(lr, reg)
+    s_ee, s_ed, lp = _oracle_step(spec, inputs, labels, obs, roots, lr, reg)
+    np.testing.assert_allclose(t_ee.cpu().numpy(), (inputs['theta_en_en'] + s_ee).reshape(-1), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(t_ed.cpu().numpy(), (inputs['theta_en_de'] + s_ed).reshape(-1), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(mean_lp, lp / B, rtol=1e-10)

@@ -224,6 +224,14 @@ def main():
         elapsed = float(t.item())
     assert fb.program(roots).status() == 0
 
+    traffic, traffic_src = a.traffic_bytes, 'command line' if a.traffic_bytes else None
+    if traffic is None:
+        try:    # HBM bytes per launch measured with rocprofv3 --pmc for this exact workload (profiles/)
+            rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get(a.workload)
+            if rec and rec['batch'] == B and rec['sweeps'] == sweeps and a.variant in (None, 1):
+                traffic, traffic_src = rec['hbm_bytes_per_launch'], rec['source']
+        except (OSError, ValueError, KeyError):
+            pass
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         iters_per_s = world * (B / 8192.0) * sweeps * a.steps / elapsed
@@ -243,7 +251,7 @@ def main():
                        'graph_sweeps_per_s': world * B * sweeps * a.steps / elapsed,
                        'parallelism': 'graphs sharded over %d GPU(s), no data-path collective' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': a.traffic_bytes,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': 'sweep_x64_fused_kernel' if X == 64 else 'sweep_generic_kernel',
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': avg_ms,
                          'min_launch_ms': sweep_ms[0], 'max_launch_ms': sweep_ms[-1]},

@@ -145,11 +145,16 @@ typedef struct mlbp_sweep_args {
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
 
-/* Kernel-variant selector for A/B measurement (not needed in normal use): 1 = default (fused
- * kernel, pairwise tables register-resident when the graph has at most 3 of them), 0 = the
- * first-generation kernel, 10+N = fused kernel with exactly N resident tables (N = 0 streams every
- * table for every update).  Also settable through the MLBP_SWEEP_VARIANT environment variable.
- * All variants compute the same updates in the same order. */
+/* Kernel-variant selector for A/B measurement (not needed in normal use; also settable through the
+ * MLBP_SWEEP_VARIANT environment variable):
+ *   1     default: for X = 64 the scale-free kernel (messages carried with an exact power-of-two
+ *         scale, true normalisation deferred to the end of the call, one barrier per update)
+ *         followed by the exact fused kernel on the graphs it flagged as degenerate;
+ *   3     exact fused kernel only (normalises after every update like the reference);
+ *   0     first-generation kernel;   10+N  exact fused kernel with N register-resident tables
+ *         (N = 0 streams);           20+N  scale-free kernel with N resident tables (N = 1..4).
+ * All variants perform the same updates in the same order; exact variants agree bitwise, the
+ * scale-free one to rounding. */
 int mlbp_set_sweep_variant(int32_t variant);
 
 /* Fills msgs[B][n_msgs][X] with 1/X: FactorGraph.initialize (LBP.py:211-216). */

@@ -21,7 +21,10 @@ struct mlbp_program {
   int32_t* d_pairseq;     // [n_pairseq + 1] pair slot of the k-th executed pair op (-1 terminated)
   int32_t* d_status;      // [1] set non-zero by a kernel that met an out-of-range table index
   // fused form used by the X = 64 kernel (build_fused_program in mlbp_sweep.hip)
-  int32_t n_fops, n_hoist, n_psrcs, n_cprod, n_cpw;
+  int32_t n_fops, n_hoist, n_psrcs, n_cprod, n_cpw, n_written;
+  bool sf_ok;             // the scale-free kernel applies (no in-loop unary ops)
+  unsigned char* d_bail;  // [bail_cap] per-graph "redo with the exact kernel" flags
+  int32_t bail_cap;
   int32_t* d_fops;        // one block: op headers [n_fops][8], source lists [n_psrcs], hoist list
                           // [n_hoist][2], constant-product lists [n_cpw]
   int32_t* d_fsweeps;     // [n_sweeps][2]

@@ -18,6 +18,7 @@
 
 #include <cfloat>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "mlbp_internal.h"
@@ -287,9 +288,21 @@ __device__ unsigned long long* g_stamp_buf = nullptr;
 #define STAMP_FLUSH
 #endif
 
+// Diagnostic build only (-DMLBP_ABLATE, tools/ablate_profile.py): MLBP_ABLATE_MASK removes one phase
+// of the fused kernel at a time (results become wrong; only the timing delta matters).
+#ifdef MLBP_ABLATE
+__device__ int g_ablate_mask = 0;
+#define ABLATED(bit) (ablate_mask_ & (1 << (bit)))
+#define ABLATE_DECL const int ablate_mask_ = __builtin_amdgcn_readfirstlane(g_ablate_mask);
+#else
+#define ABLATED(bit) 0
+#define ABLATE_DECL
+#endif
+
 enum { FOP_UNARY = 0, FOP_PAIR_TM = 1, FOP_PAIR_MT = 2, FOP_VAR = 3, FOP_VAR_PAIR_TM = 4, FOP_VAR_PAIR_MT = 5 };
 
 struct FusedDev {
+  const uint8_t* only;     // when non-NULL: run only graphs with only[g] != 0 (fix-up pass)
   const int32_t* image;    // fused op headers, source lists, hoist list, constant-product lists (one block)
   const int32_t* fsweeps;  // [n_sweeps][2]
   int32_t n_fops, n_psrcs, n_hoist, n_cprod, n_cpw, n_ext, init;
@@ -376,8 +389,10 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
   int32_t* flags = tabidx + d.P + d.U;                  // [0] = vector wave already stored the v->f message
 
   STAMP_DECL
+  ABLATE_DECL
   STAMP_START
   const int g = blockIdx.x;
+  if (f.only && !f.only[g]) return;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int rg = t >> 5, cp = t & 31;
@@ -483,6 +498,7 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
       const int4 h1 = reinterpret_cast<const int4*>(prog)[2 * o + 1];
       const int kind = __builtin_amdgcn_readfirstlane(h0.x);
       STAMP(1)   // op header
+      if (ABLATED(5)) continue;
       if (kind == FOP_UNARY) {
         if (wave == 0) {
           const int us = __builtin_amdgcn_readfirstlane(h0.y), c = __builtin_amdgcn_readfirstlane(h0.w);
@@ -501,14 +517,14 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
           // finite and non-negative and the product is not identically zero; then the product's
           // scale cancels in the normalised pairwise update, so the contraction takes it
           // unnormalised and wave 1 normalises and stores the variable->factor message meanwhile
-          const int a = __builtin_amdgcn_readfirstlane(h0.y), n = __builtin_amdgcn_readfirstlane(h0.z);
+          const int a = __builtin_amdgcn_readfirstlane(h0.y), n = ABLATED(0) ? 0 : __builtin_amdgcn_readfirstlane(h0.z);
           const int4 s4 = *reinterpret_cast<const int4*>(psrcs + a);
-          double acc = msg[s4.x * 64 + lane];
+          double acc = ABLATED(0) ? uniform : msg[s4.x * 64 + lane];
           if (n > 1) acc *= msg[s4.y * 64 + lane];
           if (n > 2) acc *= msg[s4.z * 64 + lane];
           if (n > 3) acc *= msg[s4.w * 64 + lane];
           for (int q = 4; q < n; ++q) acc *= msg[psrcs[a + q] * 64 + lane];
-          const bool fast = __all(acc >= 0.0 && acc < __builtin_huge_val()) && __any(acc > 0.0);
+          const bool fast = ABLATED(6) ? true : (__all(acc >= 0.0 && acc < __builtin_huge_val()) && __any(acc > 0.0));
           STAMP(2)   // variable product
 #ifdef MLBP_STAMPS
           if (!fast) _ph[2] += (1ULL << 40);
@@ -516,7 +532,9 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
           if (!__all(acc < __builtin_huge_val())) _ph[2] += (1ULL << 48);
           if (!__any(acc > 0.0)) _ph[2] += (1ULL << 52);
 #endif
-          if (fast && kind != FOP_VAR) {
+          if (ABLATED(7)) {
+            asm volatile("" ::"v"(acc));
+          } else if (fast && kind != FOP_VAR) {
             gin[lane] = acc;
             if (lane == 0) flags[0] = 0;
           } else {
@@ -541,9 +559,10 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
         dst = c;
       }
       const bool mt = (kind == FOP_PAIR_MT || kind == FOP_VAR_PAIR_MT);
-      wg_barrier();          // the input vector (and every earlier vector-wave store) is visible
+      if (!ABLATED(4)) wg_barrier();          // the input vector (and every earlier vector-wave store) is visible
       STAMP(5)   // barrier
-      if (NT > 0) {
+      if (ABLATED(1)) {
+      } else if (NT > 0) {
 #pragma unroll
         for (int p = 0; p < NT; ++p) {
           if (p == pslot) {
@@ -566,15 +585,17 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
         if (mt) pair_partials<true>(cur, m, red, rg, cp, lane);
         else pair_partials<false>(cur, m, red, rg, cp, lane);
       }
-      if (from_var && wave == 1 && flags[0] == 0) {
+      if (!ABLATED(3) && from_var && wave == 1 && flags[0] == 0) {
         // off the critical path: normalise and store the variable->factor message (LBP.py:387-389)
         const double v = gin[lane];
         msg[c * 64 + lane] = renorm(v, wave_sum(v), uniform, NORM);
       }
       STAMP(4)   // partial sums
-      wg_barrier();          // partial sums are in LDS
+      if (!ABLATED(4)) wg_barrier();          // partial sums are in LDS
       STAMP(5)   // barrier
-      if (wave == 0) {
+      if (wave == 0 && ABLATED(2)) {
+        if (!ABLATED(8)) msg[dst * 64 + lane] = uniform;
+      } else if (wave == 0) {
         double r;
         if (mt) {
           r = 0.0;
@@ -593,6 +614,232 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
   wg_barrier();
   {
     const double2* src = reinterpret_cast<const double2*>(msg);
+    double2* dst = reinterpret_cast<double2*>(gm);
+    for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = src[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// X = 64, float64, "scale-free" form of the fused kernel (normalize_messages only).
+//
+// Every normalisation of the reference divides a vector by a positive scalar, and every later use
+// of that vector is linear in it, so the scalars cancel in every NORMALISED quantity.  This kernel
+// therefore carries each message multiplied by an exact power of two (largest element in [1,2))
+// instead of normalised -- v_ldexp, no rounding -- and performs the true normalisations (sum and
+// divide, LBP.py:649-657) once, after the last sweep, for exactly the slots the program wrote.
+// What that removes from the critical path of every update: both wave reductions + divisions and
+// one of the two workgroup barriers.  All four waves run the same instruction stream (each keeps
+// its own copy of the 64-state vectors; only the table contraction is split), so the one barrier
+// per pairwise update is the exchange of partial sums.
+//
+// The rescaling changes results only at rounding level (<= 1 ulp per update).  Inputs where the
+// reference's rules act on absolute values are NOT handled here: a negative or non-finite entry, a
+// subnormal/zero maximum (zero-sum -> uniform rule, LBP.py:655-657), or nan_to_num acting inside a
+// constant product make the workgroup leave its graph untouched and raise bail[g]; the launcher
+// then runs the exact kernel (sweep_x64_fused_kernel) on the flagged graphs only.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));
+  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = __builtin_amdgcn_readlane((int)v, 32), e = __builtin_amdgcn_readlane((int)v, 48);
+  return max(max(a, b), max(c, e));
+}
+
+// High word of a double as an unsigned key: for finite non-negative doubles the key orders like the
+// value; a set sign bit or an all-ones exponent (negative, -0, inf, NaN) gives a key >= 0x7FF00000.
+__device__ __forceinline__ unsigned mag_key(double x) { return (unsigned)__double2hiint(x); }
+constexpr unsigned KEY_BAD = 0x7FF00000u;   // and above: negative or non-finite
+constexpr unsigned KEY_MIN = 0x00100000u;   // below: zero or subnormal maximum
+
+struct ScaleFreeDev {
+  const int32_t* image;      // as FusedDev::image, followed by the written-slot list
+  const int32_t* fsweeps;
+  uint8_t* bail;             // [B] set to 1 when the graph must be redone by the exact kernel
+  int32_t n_fops, n_psrcs, n_hoist, n_cprod, n_cpw, n_ext, n_written, init;
+};
+
+template <int NT>
+__global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x64_sf_kernel(SweepDev d, ScaleFreeDev f) {
+  extern __shared__ double lds[];
+  double* work = lds;                                       // [n_msgs + n_ext][64] scaled messages
+  double* gin = lds + (size_t)(d.n_msgs + f.n_ext) * 64;    // [4][64] per-wave contraction input
+  double* red0 = gin + 4 * 64;                              // 2 x [8][64] partial sums
+  int32_t* prog = reinterpret_cast<int32_t*>(red0 + 2 * 512);
+  const int32_t* psrcs = prog + f.n_fops * 8;
+  const int32_t* phoist = psrcs + f.n_psrcs;
+  const int32_t* pcp = phoist + 2 * f.n_hoist;
+  const int32_t* pwritten = pcp + f.n_cpw;
+  int32_t* tabidx = const_cast<int32_t*>(pwritten) + f.n_written;
+  int32_t* lflag = tabidx + d.P + d.U;                    // [1] set when the final pass finds a bad vector
+
+  ABLATE_DECL
+  const int g = blockIdx.x;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int rg = t >> 5, cp = t & 31;
+  double* gm = d.msgs + (size_t)g * d.n_msgs * 64;
+  double* gin_w = gin + wave * 64;
+  const double uniform = 1.0 / 64.0;
+  const const_i32p c_fsweeps = as_const(f.fsweeps);
+
+  // ---- phase A: table indices (range-checked), program image, messages ----
+  bool ok = true;
+  for (int i = t; i < d.P + d.U; i += WG) {
+    const int v = i < d.P ? d.pair_tab[(size_t)g * d.P + i] : d.unary_tab[(size_t)g * d.U + (i - d.P)];
+    ok &= (unsigned)v < (unsigned)(i < d.P ? d.n_pair_tables : d.n_unary_tables);
+    tabidx[i] = v;
+  }
+  unsigned bad_key = 0;
+  {
+    const int n_img = f.n_fops * 8 + f.n_psrcs + 2 * f.n_hoist + f.n_cpw + f.n_written;
+    for (int i = t; i < n_img; i += WG) prog[i] = f.image[i];
+    double2* dst = reinterpret_cast<double2*>(work);
+    if (f.init) {
+      for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = make_double2(uniform, uniform);
+    } else {
+      const double2* src = reinterpret_cast<const double2*>(gm);
+      for (int i = t; i < d.n_msgs * 32; i += WG) {
+        const double2 v = src[i];
+        bad_key = max(bad_key, max(mag_key(v.x), mag_key(v.y)));     // incoming messages must be clean too
+        dst[i] = v;
+      }
+    }
+    if (t < 32) dst[d.n_msgs * 32 + t] = make_double2(uniform, uniform);    // ext slot 0
+    if (t == 0) lflag[0] = 0;
+  }
+  if (!__syncthreads_and(ok ? 1 : 0)) {
+    if (t == 0) atomicExch(d.status, 1);
+    return;
+  }
+
+  // ---- phase B: tables + hoisted unary messages, all loads in flight together ----
+  double2 tab[NT][8];
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+    if (p < d.P) {
+      const int ti = __builtin_amdgcn_readfirstlane(tabidx[p]);
+      const double2* T = reinterpret_cast<const double2*>(d.pair_tables + (size_t)ti * 4096);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tab[p][k] = T[k * WG + t];
+    }
+  }
+  constexpr int HB = 8;
+  for (int h0 = wave; h0 < f.n_hoist; h0 += 4 * HB) {
+    double r[HB];
+#pragma unroll
+    for (int j = 0; j < HB; ++j) {
+      const int h = h0 + 4 * j;
+      r[j] = (h < f.n_hoist) ? d.unary_tables[(size_t)tabidx[d.P + phoist[2 * h]] * 64 + lane] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < HB; ++j) {
+      const int h = h0 + 4 * j;
+      if (h < f.n_hoist) {
+        const double s = wave_sum(r[j]);
+        const double m = renorm(r[j], s, uniform, true);        // exact, these are final values
+        bad_key = max(bad_key, mag_key(m));
+        work[phoist[2 * h + 1] * 64 + lane] = m;
+      }
+    }
+  }
+  wg_barrier();
+  {
+    int at = 0;
+    for (int k = 0; k < f.n_cprod; ++k) {
+      const int cnt = pcp[at];
+      if ((k & 3) == wave) {
+        double acc = uniform;
+        for (int q = 0; q < cnt; ++q) {
+          acc *= work[pcp[at + 1 + q] * 64 + lane];
+          bad_key = max(bad_key, mag_key(acc));               // non-finite intermediate => nan_to_num territory
+        }
+        work[(d.n_msgs + 1 + k) * 64 + lane] = acc;
+      }
+      at += 1 + cnt;
+    }
+  }
+  if (__syncthreads_or(bad_key >= KEY_BAD ? 1 : 0)) {
+    if (t == 0) f.bail[g] = 1;
+    return;
+  }
+
+  // ---- main loop: identical in all four waves; one barrier per pairwise update ----
+  int parity = 0;
+  for (int s = 0; s < d.n_sweeps; ++s) {
+    const int op0 = c_fsweeps[2 * s], nop = c_fsweeps[2 * s + 1];
+    for (int o = op0; o < op0 + nop; ++o) {
+      const int4 h0 = reinterpret_cast<const int4*>(prog)[2 * o];
+      const int4 h1 = reinterpret_cast<const int4*>(prog)[2 * o + 1];
+      const int kind = __builtin_amdgcn_readfirstlane(h0.x);
+      const int c = __builtin_amdgcn_readfirstlane(h0.w);
+      int pslot, dst;
+      double m;                                   // lane i = state i of the contraction's input vector
+      if (kind == FOP_VAR || kind == FOP_VAR_PAIR_TM || kind == FOP_VAR_PAIR_MT) {
+        const int a = __builtin_amdgcn_readfirstlane(h0.y), n = __builtin_amdgcn_readfirstlane(h0.z);
+        const int4 s4 = *reinterpret_cast<const int4*>(psrcs + a);
+        m = work[s4.x * 64 + lane];
+        if (n > 1) m *= work[s4.y * 64 + lane];
+        if (n > 2) m *= work[s4.z * 64 + lane];
+        if (n > 3) m *= work[s4.w * 64 + lane];
+        for (int q = 4; q < n; ++q) m *= work[psrcs[a + q] * 64 + lane];
+        work[c * 64 + lane] = m;                  // every wave stores its (identical) copy
+        if (kind == FOP_VAR) continue;
+        pslot = __builtin_amdgcn_readfirstlane(h1.x);
+        dst = __builtin_amdgcn_readfirstlane(h1.y);
+      } else {
+        pslot = __builtin_amdgcn_readfirstlane(h0.y);
+        m = work[__builtin_amdgcn_readfirstlane(h0.z) * 64 + lane];
+        dst = c;
+      }
+      const bool mt = (kind == FOP_PAIR_MT || kind == FOP_VAR_PAIR_MT);
+      gin_w[lane] = m;                            // own-wave exchange: each lane needs other states
+      double* red = red0 + parity * 512;
+      parity ^= 1;
+#pragma unroll
+      for (int p = 0; p < NT; ++p) {
+        if (p == pslot) {
+          if (mt) pair_partials<true>(tab[p], gin_w, red, rg, cp, lane);
+          else pair_partials<false>(tab[p], gin_w, red, rg, cp, lane);
+        }
+      }
+      wg_barrier();
+      double r;
+      if (mt) {
+        r = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r += red[q * 64 + lane];
+      } else {
+        r = red[lane] + red[64 + lane];
+      }
+      // exact power-of-two rescale (largest element -> [1,2)); anything the rescale cannot
+      // represent faithfully sends the graph to the exact kernel
+      const unsigned key = wave_max_u32(mag_key(r));
+      if (__builtin_expect(key >= KEY_BAD || key < KEY_MIN, 0)) {
+        if (t == 0) f.bail[g] = 1;
+        return;                                   // same decision in every wave: r is identical
+      }
+      work[dst * 64 + lane] = __builtin_ldexp(r, 1023 - (int)(key >> 20));
+    }
+  }
+  wg_barrier();
+  // ---- the deferred normalisations: exactly the slots the program wrote ----
+  for (int i = wave; i < f.n_written; i += 4) {
+    const int slot = pwritten[i];
+    const double v = work[slot * 64 + lane];
+    const unsigned key = wave_max_u32(mag_key(v));
+    if (key >= KEY_BAD || key < KEY_MIN) lflag[0] = 1;   // a variable product underflowed or vanished
+    work[slot * 64 + lane] = v / wave_sum(v);
+  }
+  wg_barrier();
+  if (lflag[0]) {                                 // messages of a bailed graph are not written back
+    if (t == 0) f.bail[g] = 1;
+    return;
+  }
+  {
+    const double2* src = reinterpret_cast<const double2*>(work);
     double2* dst = reinterpret_cast<double2*>(gm);
     for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = src[i];
   }
@@ -723,8 +970,9 @@ __global__ void log_posterior_kernel(const double* marg, const int32_t* labels, 
 
 // Fused program form (see sweep_x64_fused_kernel).  Input: the validated 4-word op list.
 struct FusedProgram {
-  std::vector<int32_t> fops, psrcs, fsweeps, hoist, cpw, pairseq;
+  std::vector<int32_t> fops, psrcs, fsweeps, hoist, cpw, pairseq, written;
   int n_cprod = 0;
+  bool has_unary_fops = false;
 };
 
 void build_fused_program(const int32_t* ops, const int32_t* srcs, const int32_t* sweeps, int n_sweeps, int n_msgs,
@@ -816,6 +1064,17 @@ void build_fused_program(const int32_t* ops, const int32_t* srcs, const int32_t*
     out.fsweeps.push_back((int)out.fops.size() / 8 - f0);
   }
   out.pairseq.push_back(-1);
+  {
+    std::vector<char> w(n_msgs, 0);
+    for (size_t i = 0; i < out.fops.size(); i += 8) {
+      const int kind = out.fops[i];
+      if (kind == FOP_UNARY) { out.has_unary_fops = true; continue; }
+      w[out.fops[i + 3]] = 1;                                            // VAR dst / standalone PAIR dst
+      if (kind == FOP_VAR_PAIR_TM || kind == FOP_VAR_PAIR_MT) w[out.fops[i + 5]] = 1;
+    }
+    for (int c = 0; c < n_msgs; ++c)
+      if (w[c]) out.written.push_back(c);
+  }
   for (int q = 0; q < 8; ++q) out.psrcs.push_back(n_msgs);   // tail padding for the int4 reads
   pad4();
   out.n_cprod = (int)cprods.size();
@@ -835,6 +1094,22 @@ int sweep_variant() {
     g_sweep_variant = e ? atoi(e) : 1;
   }
   return g_sweep_variant;
+}
+
+// hipFuncSetAttribute is a slow host call (~0.1 ms); remember the largest dynamic-LDS size already
+// granted per kernel and only call again when a launch needs more.
+int ensure_dynamic_lds(const void* fn, size_t bytes) {
+  static std::vector<std::pair<const void*, size_t>> granted;
+  for (auto& g : granted)
+    if (g.first == fn) {
+      if (g.second >= bytes) return MLBP_OK;
+      HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      g.second = bytes;
+      return MLBP_OK;
+    }
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  granted.push_back({fn, bytes});
+  return MLBP_OK;
 }
 
 int check_device() {
@@ -943,6 +1218,11 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
   image.insert(image.end(), fp.psrcs.begin(), fp.psrcs.end());
   image.insert(image.end(), fp.hoist.begin(), fp.hoist.end());
   image.insert(image.end(), fp.cpw.begin(), fp.cpw.end());
+  image.insert(image.end(), fp.written.begin(), fp.written.end());
+  p->n_written = (int)fp.written.size();
+  p->sf_ok = !fp.has_unary_fops;
+  p->d_bail = nullptr;
+  p->bail_cap = 0;
   if (e == hipSuccess) e = up(&p->d_fops, image.data(), image.size());
   if (e == hipSuccess) e = up(&p->d_fsweeps, fp.fsweeps.data(), fp.fsweeps.size());
   if (e == hipSuccess) e = up(&p->d_fpairseq, fp.pairseq.data(), fp.pairseq.size());
@@ -958,7 +1238,7 @@ int mlbp_program_destroy(mlbp_program* p) {
   if (!p) return MLBP_OK;
   (void)hipFree(p->d_ops); (void)hipFree(p->d_srcs); (void)hipFree(p->d_sweeps);
   (void)hipFree(p->d_pairseq); (void)hipFree(p->d_status);
-  (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq);
+  (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq); (void)hipFree(p->d_bail);
   delete p;
   return MLBP_OK;
 }
@@ -987,20 +1267,55 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   const int variant = sweep_variant();
   if (a->X == 64 && variant != 0) {
     const int n_ext = 1 + prog->n_cprod;
-    const size_t img_words = (size_t)prog->n_fops * 8 + prog->n_psrcs + 2 * prog->n_hoist + prog->n_cpw;
-    size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 64 + 512) * sizeof(double) +
-                 (img_words + prog->P + prog->U + 4) * sizeof(int32_t);
+    const size_t img_words = (size_t)prog->n_fops * 8 + prog->n_psrcs + 2 * prog->n_hoist + prog->n_cpw + prog->n_written;
+    // residency rule: tables stay in registers when the graph has at most 3 (4 for the scale-free
+    // kernel, whose smaller working set still fits 3 workgroups per CU) of them
+    int nt = (prog->P <= 3) ? prog->P : 0;
+    bool want_sf = norm && prog->sf_ok && prog->P >= 1 && prog->P <= 4 && variant != 3;
+    if (variant >= 10 && variant < 20) { nt = (prog->P <= variant - 10) ? variant - 10 : 0; want_sf = false; }
+    if (variant >= 20) { want_sf = want_sf && prog->P <= variant - 20; nt = variant - 20; }
+    else if (want_sf) nt = prog->P;
+    if (prog->P == 0 || (!want_sf && nt < prog->P)) nt = 0;
+    if (nt > 4) nt = 0;
+    const size_t lds_sf = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 64 + 2 * 512) * sizeof(double) +
+                          (img_words + prog->P + prog->U + 4) * sizeof(int32_t);
+    const size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 64 + 512) * sizeof(double) +
+                       (img_words + prog->P + prog->U + 4) * sizeof(int32_t);
+    if (lds_sf > LDS_MAX) want_sf = false;
     if (lds <= LDS_MAX) {
+      mlbp_program* mp = const_cast<mlbp_program*>(prog);
+      if (want_sf) {
+        if (mp->bail_cap < a->B) {            // grows only when a larger batch is seen
+          (void)hipFree(mp->d_bail);
+          mp->d_bail = nullptr;
+          HIP_TRY(hipMalloc(&mp->d_bail, (size_t)a->B));
+          mp->bail_cap = a->B;
+        }
+        HIP_TRY(hipMemsetAsync(mp->d_bail, 0, (size_t)a->B, st));
+        ScaleFreeDev sf;
+        sf.image = prog->d_fops; sf.fsweeps = prog->d_fsweeps; sf.bail = mp->d_bail;
+        sf.n_fops = prog->n_fops; sf.n_psrcs = prog->n_psrcs; sf.n_hoist = prog->n_hoist;
+        sf.n_cprod = prog->n_cprod; sf.n_cpw = prog->n_cpw; sf.n_ext = n_ext; sf.n_written = prog->n_written;
+        sf.init = a->init_messages;
+        void (*ks)(SweepDev, ScaleFreeDev) = nullptr;
+        switch (nt) {
+          case 1: ks = sweep_x64_sf_kernel<1>; break;
+          case 2: ks = sweep_x64_sf_kernel<2>; break;
+          case 3: ks = sweep_x64_sf_kernel<3>; break;
+          default: ks = sweep_x64_sf_kernel<4>; nt = 4; break;
+        }
+        if (int e = ensure_dynamic_lds((const void*)ks, lds_sf)) return e;
+        hipLaunchKernelGGL(ks, dim3(a->B), dim3(WG), lds_sf, st, d, sf);
+        HIP_TRY(hipGetLastError());
+      }
       FusedDev f;
+      f.only = want_sf ? mp->d_bail : nullptr;     // after the scale-free pass: flagged graphs only
       f.image = prog->d_fops; f.fsweeps = prog->d_fsweeps;
       f.n_fops = prog->n_fops; f.n_psrcs = prog->n_psrcs; f.n_hoist = prog->n_hoist;
       f.n_cprod = prog->n_cprod; f.n_cpw = prog->n_cpw; f.n_ext = n_ext;
       f.init = a->init_messages;
       d.pairseq = prog->d_fpairseq;
-      // register-resident tables when the graph has few enough of them; variant 2.. forces NT
-      int nt = (prog->P <= 3) ? prog->P : 0;
-      if (variant >= 10) nt = (variant - 10 <= 4 && prog->P <= variant - 10) ? variant - 10 : 0;
-      if (prog->P == 0) nt = 0;
+      if (want_sf && nt > 3) nt = (prog->P <= 3) ? prog->P : 0;   // exact kernel keeps its own rule
       void (*k)(SweepDev, FusedDev) = nullptr;
 #define MLBP_PICK(N) k = norm ? sweep_x64_fused_kernel<true, N> : sweep_x64_fused_kernel<false, N>
       switch (nt) {
@@ -1011,7 +1326,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
         default: MLBP_PICK(0); break;
       }
 #undef MLBP_PICK
-      HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (int e = ensure_dynamic_lds((const void*)k, lds)) return e;
       hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, st, d, f);
       HIP_TRY(hipGetLastError());
       return MLBP_OK;
@@ -1025,7 +1340,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     size_t lds = ((size_t)prog->n_msgs * 64 + 8 * 64) * sizeof(double);
     if (lds <= LDS_MAX) {
       auto k = norm ? sweep_x64_kernel<true> : sweep_x64_kernel<false>;
-      HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (int e = ensure_dynamic_lds((const void*)k, lds)) return e;
       hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, st, d);
       HIP_TRY(hipGetLastError());
       return MLBP_OK;
@@ -1044,6 +1359,13 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   return MLBP_OK;
 }
 
+#ifdef MLBP_ABLATE
+int mlbp_debug_set_ablate_mask(int mask) {
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_ablate_mask), &mask, sizeof(mask)));
+  return MLBP_OK;
+}
+#endif
+
 #ifdef MLBP_STAMPS
 int mlbp_debug_set_stamp_buffer(void* dev_ptr) {
   unsigned long long* p = (unsigned long long*)dev_ptr;
@@ -1053,7 +1375,8 @@ int mlbp_debug_set_stamp_buffer(void* dev_ptr) {
 #endif
 
 int mlbp_set_sweep_variant(int32_t variant) {
-  if (variant < 0 || (variant > 1 && (variant < 10 || variant > 14))) return fail(MLBP_EINVAL, "unknown sweep variant %d", variant);
+  const bool known = variant == 0 || variant == 1 || variant == 3 || (variant >= 10 && variant <= 14) || (variant >= 21 && variant <= 24);
+  if (!known) return fail(MLBP_EINVAL, "unknown sweep variant %d", variant);
   g_sweep_variant = variant;
   return MLBP_OK;
 }

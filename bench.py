@@ -194,10 +194,9 @@ def main():
     def step(i=None):
         if i is not None:
             ev[i][0].record()
-        fb.sweep(roots, init=True)       # initialize (uniform messages) is fused into the sweep launch
+        fb.sweep(roots, init=True, marginals=marg)   # initialize + marginal read-out fused into the launch
         if i is not None:
             ev[i][1].record()
-        fb.marginals(out=marg)
         _ffi.check(_ffi.lib.mlbp_log_posterior_f64(marg.data_ptr(), labels_d.data_ptr(), B, topo.n_vars, X,
                                                    lp.data_ptr(), _stream_ptr(dev)))
         stats[0] = lp.sum()

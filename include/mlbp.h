@@ -112,6 +112,12 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
                         mlbp_program** out);
 int mlbp_program_destroy(mlbp_program* p);
 
+/* Attaches the variable read-out tables to a program so that mlbp_sweep_f64 can write the
+ * variable marginals straight from the on-chip messages (mlbp_sweep_args.marginals): in_off
+ * [n_vars+1] / in_slots are HOST arrays, variable v multiplies the messages in slots
+ * in_slots[in_off[v] .. in_off[v+1]) in that (facset) order (LBP.py:394-396). */
+int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_off, const int32_t* in_slots);
+
 /* Synchronising read-and-reset of the program's device status word: 0 = clean; 1 = a kernel skipped
  * a graph because one of its table indices lay outside [0, n_*_tables) (instead of reading out of
  * bounds); negative = error code. */
@@ -141,6 +147,9 @@ typedef struct mlbp_sweep_args {
   int32_t normalize_messages; /* FactorGraph.normalize_messages (LBP.py:41)                       */
   int32_t init_messages;      /* non-zero: start from uniform 1/X messages (FactorGraph.initialize,
                                  LBP.py:211-216, fused into the launch) instead of reading msgs      */
+  double* marginals;          /* device [B][n_vars][X] or NULL: VariableNode.get_marginal of every
+                                 variable after the last sweep (LBP.py:392-400), read out in the same
+                                 launch; needs mlbp_program_set_readout                              */
 } mlbp_sweep_args;
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);

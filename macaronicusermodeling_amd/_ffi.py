@@ -42,7 +42,7 @@ class SweepArgs(C.Structure):
     _fields_ = [('B', C.c_int32), ('X', C.c_int32), ('n_pair_tables', C.c_int32),
                 ('n_unary_tables', C.c_int32), ('pair_tables', C.c_void_p), ('pair_tab', C.c_void_p),
                 ('unary_tables', C.c_void_p), ('unary_tab', C.c_void_p), ('msgs', C.c_void_p),
-                ('normalize_messages', C.c_int32), ('init_messages', C.c_int32)]
+                ('normalize_messages', C.c_int32), ('init_messages', C.c_int32), ('marginals', C.c_void_p)]
 
 
 _i32p = C.POINTER(C.c_int32)
@@ -62,6 +62,7 @@ SIGNATURES = {
     'mlbp_program_create': (C.c_int, [_i32p, _i32, _i32p, _i32, _i32p, _i32, _i32, _i32, _i32,
                                       C.POINTER(_vp)]),
     'mlbp_program_destroy': (C.c_int, [_vp]),
+    'mlbp_program_set_readout': (C.c_int, [_vp, _i32, _i32p, _i32p]),
     'mlbp_program_status': (C.c_int, [_vp]),
     'mlbp_set_sweep_variant': (C.c_int, [_i32]),
     'mlbp_sweep_f64': (C.c_int, [_vp, C.POINTER(SweepArgs), _vp]),

@@ -40,6 +40,7 @@ class Program:
                                                 _ffi.i32ptr(sw_c), len(sweeps), topo.n_msgs, topo.P, topo.U,
                                                 C.byref(h)))
         self.handle = h
+        _ffi.check(_ffi.lib.mlbp_program_set_readout(h, topo.n_vars, _ffi.i32ptr(topo.in_off), _ffi.i32ptr(topo.in_slots)))
 
     def status(self):
         return _ffi.check(_ffi.lib.mlbp_program_status(self.handle))
@@ -114,9 +115,11 @@ class FactorGraphBatch:
             self._programs[key] = Program(self.topo, key)
         return self._programs[key]
 
-    def sweep(self, roots, init=False):
+    def sweep(self, roots, init=False, marginals=None):
         """Runs len(roots) sweeps, sweep s rooted at variable id roots[s], on every graph, in one
-        launch.  init=True starts from uniform messages (initialize() fused into the launch)."""
+        launch.  init=True starts from uniform messages (initialize() fused into the launch);
+        marginals: optional [B][n_vars][X] device tensor that receives every variable's marginal
+        after the last sweep, read out of the on-chip messages in the same launch."""
         prog = self.program(roots)
         a = _ffi.SweepArgs()
         a.B, a.X = self.B, self.X
@@ -133,6 +136,10 @@ class FactorGraphBatch:
         a.msgs = self.msgs.data_ptr()
         a.normalize_messages = 1 if self.normalize_messages else 0
         a.init_messages = 1 if init else 0
+        if marginals is not None:
+            if tuple(marginals.shape) != (self.B, self.topo.n_vars, self.X) or marginals.dtype != torch.float64:
+                raise ValueError('marginals must be float64 [B][n_vars][X]')
+            a.marginals = marginals.data_ptr()
         _ffi.check(_ffi.lib.mlbp_sweep_f64(prog.handle, C.byref(a), _stream_ptr(self.device)))
         return prog
 

@@ -106,6 +106,10 @@ struct SweepDev {
   const int32_t* pairseq;
   int32_t* status;
   int32_t n_sweeps, n_msgs, P, U, X, n_pair_tables, n_unary_tables;
+  // optional fused read-out of the variable marginals (LBP.py:392-400) from the on-chip messages
+  double* marginals;           // [B][n_vars][X] or NULL
+  const int32_t* readout;      // device: in_off [n_vars+1] then in_slots
+  int32_t n_vars;
 };
 
 // Uniform check of the graph's table indices; an out-of-range index would be an out-of-bounds
@@ -298,6 +302,19 @@ __device__ int g_ablate_mask = 0;
 #define ABLATED(bit) 0
 #define ABLATE_DECL
 #endif
+
+// VariableNode.get_marginal (LBP.py:392-400) for every variable of the graph, straight from the
+// normalised messages in LDS: uniform x incoming messages in facset order, nan_to_num after each
+// product, renormalise.  Wave w takes variables w, w+4, ...
+__device__ __forceinline__ void marginals_from_lds_x64(const SweepDev& d, const double* msg, int g, int wave, int lane) {
+  if (!d.marginals) return;
+  const const_i32p off = as_const(d.readout), slots = as_const(d.readout + d.n_vars + 1);
+  for (int v = wave; v < d.n_vars; v += 4) {
+    double acc = 1.0 / 64.0;
+    for (int q = off[v]; q < off[v + 1]; ++q) acc = mul_nan_to_num(msg[slots[q] * 64 + lane], acc);
+    d.marginals[((size_t)g * d.n_vars + v) * 64 + lane] = renorm(acc, wave_sum(acc), 1.0 / 64.0, true);
+  }
+}
 
 enum { FOP_UNARY = 0, FOP_PAIR_TM = 1, FOP_PAIR_MT = 2, FOP_VAR = 3, FOP_VAR_PAIR_TM = 4, FOP_VAR_PAIR_MT = 5 };
 
@@ -617,6 +634,7 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
     double2* dst = reinterpret_cast<double2*>(gm);
     for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = src[i];
   }
+  if (NORM) marginals_from_lds_x64(d, msg, g, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -662,7 +680,7 @@ struct ScaleFreeDev {
 };
 
 template <int NT>
-__global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x64_sf_kernel(SweepDev d, ScaleFreeDev f) {
+__global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(SweepDev d, ScaleFreeDev f) {
   extern __shared__ double lds[];
   double* work = lds;                                       // [n_msgs + n_ext][64] scaled messages
   double* gin = lds + (size_t)(d.n_msgs + f.n_ext) * 64;    // [4][64] per-wave contraction input
@@ -843,6 +861,7 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
     double2* dst = reinterpret_cast<double2*>(gm);
     for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = src[i];
   }
+  marginals_from_lds_x64(d, work, g, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1223,6 +1242,8 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
   p->sf_ok = !fp.has_unary_fops;
   p->d_bail = nullptr;
   p->bail_cap = 0;
+  p->d_readout = nullptr;
+  p->n_vars = 0;
   if (e == hipSuccess) e = up(&p->d_fops, image.data(), image.size());
   if (e == hipSuccess) e = up(&p->d_fsweeps, fp.fsweeps.data(), fp.fsweeps.size());
   if (e == hipSuccess) e = up(&p->d_fpairseq, fp.pairseq.data(), fp.pairseq.size());
@@ -1238,7 +1259,7 @@ int mlbp_program_destroy(mlbp_program* p) {
   if (!p) return MLBP_OK;
   (void)hipFree(p->d_ops); (void)hipFree(p->d_srcs); (void)hipFree(p->d_sweeps);
   (void)hipFree(p->d_pairseq); (void)hipFree(p->d_status);
-  (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq); (void)hipFree(p->d_bail);
+  (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq); (void)hipFree(p->d_bail); (void)hipFree(p->d_readout);
   delete p;
   return MLBP_OK;
 }
@@ -1261,6 +1282,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   d.status = prog->d_status;
   d.n_sweeps = prog->n_sweeps; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U; d.X = a->X;
   d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables;
+  d.marginals = nullptr; d.readout = prog->d_readout; d.n_vars = prog->n_vars;
+  if (a->marginals && !prog->d_readout)
+    return fail(MLBP_EINVAL, "mlbp_sweep_f64: marginals requested but mlbp_program_set_readout was not called");
   hipStream_t st = (hipStream_t)stream;
   const bool norm = a->normalize_messages != 0;
   const size_t LDS_MAX = 160 * 1024;
@@ -1284,6 +1308,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     if (lds_sf > LDS_MAX) want_sf = false;
     if (lds <= LDS_MAX) {
       mlbp_program* mp = const_cast<mlbp_program*>(prog);
+      if (norm) d.marginals = a->marginals;         // read-out fused into the kernels' epilogue
       if (want_sf) {
         if (mp->bail_cap < a->B) {            // grows only when a larger batch is seen
           (void)hipFree(mp->d_bail);
@@ -1329,6 +1354,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       if (int e = ensure_dynamic_lds((const void*)k, lds)) return e;
       hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, st, d, f);
       HIP_TRY(hipGetLastError());
+      if (a->marginals && !norm)
+        return mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
+                                  prog->d_readout + prog->n_vars + 1, 0, a->marginals, stream);
       return MLBP_OK;
     }
   }
@@ -1343,6 +1371,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       if (int e = ensure_dynamic_lds((const void*)k, lds)) return e;
       hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, st, d);
       HIP_TRY(hipGetLastError());
+      if (a->marginals)
+        return mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
+                                  prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream);
       return MLBP_OK;
     }
   }
@@ -1356,6 +1387,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), base, st, d);
   }
   HIP_TRY(hipGetLastError());
+  if (a->marginals)
+    return mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
+                              prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream);
   return MLBP_OK;
 }
 
@@ -1373,6 +1407,25 @@ int mlbp_debug_set_stamp_buffer(void* dev_ptr) {
   return MLBP_OK;
 }
 #endif
+
+int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_off, const int32_t* in_slots) {
+  if (!p || n_vars <= 0 || !in_off || !in_slots) return fail(MLBP_EINVAL, "mlbp_program_set_readout: bad arguments");
+  if (in_off[0] != 0) return fail(MLBP_EINVAL, "in_off[0] must be 0");
+  for (int v = 0; v < n_vars; ++v)
+    if (in_off[v + 1] < in_off[v]) return fail(MLBP_EINVAL, "in_off must be non-decreasing");
+  const int n_in = in_off[n_vars];
+  for (int q = 0; q < n_in; ++q)
+    if (in_slots[q] < 0 || in_slots[q] >= p->n_msgs) return fail(MLBP_EINVAL, "in_slots[%d] = %d out of [0,%d)", q, in_slots[q], p->n_msgs);
+  std::vector<int32_t> img(in_off, in_off + n_vars + 1);
+  img.insert(img.end(), in_slots, in_slots + n_in);
+  img.push_back(0);
+  (void)hipFree(p->d_readout);
+  p->d_readout = nullptr;
+  HIP_TRY(hipMalloc(&p->d_readout, img.size() * sizeof(int32_t)));
+  HIP_TRY(hipMemcpy(p->d_readout, img.data(), img.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  p->n_vars = n_vars;
+  return MLBP_OK;
+}
 
 int mlbp_set_sweep_variant(int32_t variant) {
   const bool known = variant == 0 || variant == 1 || variant == 3 || (variant >= 10 && variant <= 14) || (variant >= 21 && variant <= 24);

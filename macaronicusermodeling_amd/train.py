@@ -95,9 +95,8 @@ class UserGraphTrainer:
         [sum_i grad_en_en (F_ee) | sum_i grad_en_de (F_ed) | sum_i log-posterior | instance count]."""
         fb = self.batch
         self.build_potentials()
-        fb.sweep(self.roots[:self.n_sweeps_run], init=True)
+        fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg)
         fb.gradient(self._g_ee, self._g_ed)
-        fb.marginals(out=self._marg)
         _ffi.check(_ffi.lib.mlbp_log_posterior_f64(self._marg.data_ptr(), fb._labels.data_ptr(), fb.B, self.topo.n_vars,
                                                    fb.X, self._lp.data_ptr(), _stream_ptr(self.device)))
         r = self._rows

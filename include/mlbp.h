@@ -118,6 +118,11 @@ int mlbp_program_destroy(mlbp_program* p);
  * in_slots[in_off[v] .. in_off[v+1]) in that (facset) order (LBP.py:394-396). */
 int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_off, const int32_t* in_slots);
 
+/* Synchronising: number of graphs (among the first B) that the last default-variant launch of this
+ * program handed from the scale-free kernel to the exact kernel (degenerate inputs: zero-sum
+ * messages, negative or non-finite entries).  Diagnostic; results are exact either way. */
+int mlbp_program_exact_count(const mlbp_program* p, int32_t B);
+
 /* Synchronising read-and-reset of the program's device status word: 0 = clean; 1 = a kernel skipped
  * a graph because one of its table indices lay outside [0, n_*_tables) (instead of reading out of
  * bounds); negative = error code. */

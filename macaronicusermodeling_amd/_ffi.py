@@ -63,6 +63,7 @@ SIGNATURES = {
                                       C.POINTER(_vp)]),
     'mlbp_program_destroy': (C.c_int, [_vp]),
     'mlbp_program_set_readout': (C.c_int, [_vp, _i32, _i32p, _i32p]),
+    'mlbp_program_exact_count': (C.c_int, [_vp, _i32]),
     'mlbp_program_status': (C.c_int, [_vp]),
     'mlbp_set_sweep_variant': (C.c_int, [_i32]),
     'mlbp_sweep_f64': (C.c_int, [_vp, C.POINTER(SweepArgs), _vp]),

@@ -45,6 +45,10 @@ class Program:
     def status(self):
         return _ffi.check(_ffi.lib.mlbp_program_status(self.handle))
 
+    def exact_count(self, B):
+        """Graphs of the last launch that needed the exact kernel (mlbp_program_exact_count)."""
+        return _ffi.check(_ffi.lib.mlbp_program_exact_count(self.handle, B))
+
     def __del__(self):
         h = getattr(self, 'handle', None)
         if h is not None and h.value:

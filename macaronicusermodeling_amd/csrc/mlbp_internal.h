@@ -26,7 +26,7 @@ struct mlbp_program {
   unsigned char* d_bail;  // [bail_cap] per-graph "redo with the exact kernel" flags
   int32_t bail_cap;
   int32_t* d_readout;     // in_off [n_vars+1] then in_slots (mlbp_program_set_readout), or NULL
-  int32_t n_vars;
+  int32_t n_vars, n_readout;
   int32_t* d_fops;        // one block: op headers [n_fops][8], source lists [n_psrcs], hoist list
                           // [n_hoist][2], constant-product lists [n_cpw]
   int32_t* d_fsweeps;     // [n_sweeps][2]

@@ -316,7 +316,8 @@ __device__ __forceinline__ void marginals_from_lds_x64(const SweepDev& d, const 
   }
 }
 
-enum { FOP_UNARY = 0, FOP_PAIR_TM = 1, FOP_PAIR_MT = 2, FOP_VAR = 3, FOP_VAR_PAIR_TM = 4, FOP_VAR_PAIR_MT = 5 };
+enum { FOP_UNARY = 0, FOP_PAIR_TM = 1, FOP_PAIR_MT = 2, FOP_VAR = 3, FOP_VAR_PAIR_TM = 4, FOP_VAR_PAIR_MT = 5,
+       FOP_BUNDLED = 0x100 /* flag: the next update touches disjoint slots and may share this one's barrier */ };
 
 struct FusedDev {
   const uint8_t* only;     // when non-NULL: run only graphs with only[g] != 0 (fix-up pass)
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
     for (int o = op0; o < op0 + nop; ++o) {
       const int4 h0 = reinterpret_cast<const int4*>(prog)[2 * o];
       const int4 h1 = reinterpret_cast<const int4*>(prog)[2 * o + 1];
-      const int kind = __builtin_amdgcn_readfirstlane(h0.x);
+      const int kind = __builtin_amdgcn_readfirstlane(h0.x) & 0xFF;
       STAMP(1)   // op header
       if (ABLATED(5)) continue;
       if (kind == FOP_UNARY) {
@@ -676,22 +677,72 @@ struct ScaleFreeDev {
   const int32_t* image;      // as FusedDev::image, followed by the written-slot list
   const int32_t* fsweeps;
   uint8_t* bail;             // [B] set to 1 when the graph must be redone by the exact kernel
-  int32_t n_fops, n_psrcs, n_hoist, n_cprod, n_cpw, n_ext, n_written, init;
+  int32_t n_fops, n_psrcs, n_hoist, n_cprod, n_cpw, n_ext, n_written, init, n_readout;
 };
+
+// ---- pieces of the scale-free main loop ----
+// Input vector of a pairwise update (lane i = state i).  Returns false for a lone variable update
+// (stored, nothing else to do).
+__device__ __forceinline__ bool sf_input(int kind, const int4& h0, const int4& h1, double* work, const int32_t* psrcs,
+                                         int lane, bool ablate, double& m, int& pslot, int& dst, bool& mt) {
+  const int c = __builtin_amdgcn_readfirstlane(h0.w);
+  if (kind == FOP_VAR || kind == FOP_VAR_PAIR_TM || kind == FOP_VAR_PAIR_MT) {
+    const int a = __builtin_amdgcn_readfirstlane(h0.y), n = __builtin_amdgcn_readfirstlane(h0.z);
+    const int4 s4 = *reinterpret_cast<const int4*>(psrcs + a);
+    m = ablate ? 1.0 / 64.0 : work[s4.x * 64 + lane];
+    if (n > 1 && !ablate) m *= work[s4.y * 64 + lane];
+    if (n > 2) m *= work[s4.z * 64 + lane];
+    if (n > 3) m *= work[s4.w * 64 + lane];
+    for (int q = 4; q < n; ++q) m *= work[psrcs[a + q] * 64 + lane];
+    work[c * 64 + lane] = m;                      // every wave stores its (identical) copy
+    if (kind == FOP_VAR) return false;
+    pslot = __builtin_amdgcn_readfirstlane(h1.x);
+    dst = __builtin_amdgcn_readfirstlane(h1.y);
+  } else {
+    pslot = __builtin_amdgcn_readfirstlane(h0.y);
+    m = work[__builtin_amdgcn_readfirstlane(h0.z) * 64 + lane];
+    dst = c;
+  }
+  mt = (kind == FOP_PAIR_MT || kind == FOP_VAR_PAIR_MT);
+  return true;
+}
+
+template <int NT>
+__device__ __forceinline__ void sf_partials(const double2 (&tab)[NT][8], int pslot, bool mt, const double* m, double* red,
+                                            int rg, int cp, int lane) {
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+    if (p == pslot) {
+      if (mt) pair_partials<true>(tab[p], m, red, rg, cp, lane);
+      else pair_partials<false>(tab[p], m, red, rg, cp, lane);
+    }
+  }
+}
+
+__device__ __forceinline__ double sf_gather(bool mt, const double* red, int lane) {
+  if (mt) {
+    double r = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) r += red[q * 64 + lane];
+    return r;
+  }
+  return red[lane] + red[64 + lane];
+}
 
 template <int NT>
 __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(SweepDev d, ScaleFreeDev f) {
   extern __shared__ double lds[];
   double* work = lds;                                       // [n_msgs + n_ext][64] scaled messages
-  double* gin = lds + (size_t)(d.n_msgs + f.n_ext) * 64;    // [4][64] per-wave contraction input
-  double* red0 = gin + 4 * 64;                              // 2 x [8][64] partial sums
-  int32_t* prog = reinterpret_cast<int32_t*>(red0 + 2 * 512);
+  double* gin = lds + (size_t)(d.n_msgs + f.n_ext) * 64;    // [4 waves][2][64] contraction inputs
+  double* red0 = gin + 4 * 128;                             // 2 parities x 2 bundle slots x [8][64]
+  int32_t* prog = reinterpret_cast<int32_t*>(red0 + 4 * 512);
   const int32_t* psrcs = prog + f.n_fops * 8;
   const int32_t* phoist = psrcs + f.n_psrcs;
   const int32_t* pcp = phoist + 2 * f.n_hoist;
   const int32_t* pwritten = pcp + f.n_cpw;
   int32_t* tabidx = const_cast<int32_t*>(pwritten) + f.n_written;
   int32_t* lflag = tabidx + d.P + d.U;                    // [1] set when the final pass finds a bad vector
+  int32_t* lread = lflag + 1;                             // read-out tables: in_off [n_vars+1], in_slots
 
   ABLATE_DECL
   const int g = blockIdx.x;
@@ -699,7 +750,7 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
   const int lane = t & 63, wave = t >> 6;
   const int rg = t >> 5, cp = t & 31;
   double* gm = d.msgs + (size_t)g * d.n_msgs * 64;
-  double* gin_w = gin + wave * 64;
+  double* gin_w = gin + wave * 128;
   const double uniform = 1.0 / 64.0;
   const const_i32p c_fsweeps = as_const(f.fsweeps);
 
@@ -727,6 +778,8 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
     }
     if (t < 32) dst[d.n_msgs * 32 + t] = make_double2(uniform, uniform);    // ext slot 0
     if (t == 0) lflag[0] = 0;
+    if (d.marginals)
+      for (int i = t; i < f.n_readout; i += WG) lread[i] = d.readout[i];
   }
   if (!__syncthreads_and(ok ? 1 : 0)) {
     if (t == 0) atomicExch(d.status, 1);
@@ -780,66 +833,65 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
     }
   }
   if (__syncthreads_or(bad_key >= KEY_BAD ? 1 : 0)) {
-    if (t == 0) f.bail[g] = 1;
+    if (t == 0) f.bail[g] = 1;                    // bail codes: 1 prologue, 2 main loop, 3 final pass
     return;
   }
 
-  // ---- main loop: identical in all four waves; one barrier per pairwise update ----
+  // ---- main loop: identical in all four waves; one barrier per BUNDLE of pairwise updates ----
+  // The host marks an update "bundled with the next" when the two touch disjoint message slots
+  // (e.g. the two directions of a loop-closing factor, or the two branches below a root): both
+  // run between the same pair of barriers, so their LDS round trips and reductions overlap.
   int parity = 0;
   for (int s = 0; s < d.n_sweeps; ++s) {
-    const int op0 = c_fsweeps[2 * s], nop = c_fsweeps[2 * s + 1];
-    for (int o = op0; o < op0 + nop; ++o) {
-      const int4 h0 = reinterpret_cast<const int4*>(prog)[2 * o];
-      const int4 h1 = reinterpret_cast<const int4*>(prog)[2 * o + 1];
-      const int kind = __builtin_amdgcn_readfirstlane(h0.x);
-      const int c = __builtin_amdgcn_readfirstlane(h0.w);
-      int pslot, dst;
-      double m;                                   // lane i = state i of the contraction's input vector
-      if (kind == FOP_VAR || kind == FOP_VAR_PAIR_TM || kind == FOP_VAR_PAIR_MT) {
-        const int a = __builtin_amdgcn_readfirstlane(h0.y), n = __builtin_amdgcn_readfirstlane(h0.z);
-        const int4 s4 = *reinterpret_cast<const int4*>(psrcs + a);
-        m = work[s4.x * 64 + lane];
-        if (n > 1) m *= work[s4.y * 64 + lane];
-        if (n > 2) m *= work[s4.z * 64 + lane];
-        if (n > 3) m *= work[s4.w * 64 + lane];
-        for (int q = 4; q < n; ++q) m *= work[psrcs[a + q] * 64 + lane];
-        work[c * 64 + lane] = m;                  // every wave stores its (identical) copy
-        if (kind == FOP_VAR) continue;
-        pslot = __builtin_amdgcn_readfirstlane(h1.x);
-        dst = __builtin_amdgcn_readfirstlane(h1.y);
-      } else {
-        pslot = __builtin_amdgcn_readfirstlane(h0.y);
-        m = work[__builtin_amdgcn_readfirstlane(h0.z) * 64 + lane];
-        dst = c;
+    const int op0 = c_fsweeps[2 * s], op1 = op0 + c_fsweeps[2 * s + 1];
+    int o = op0;
+    while (o < op1) {
+      const int4 hA0 = reinterpret_cast<const int4*>(prog)[2 * o];
+      const int4 hA1 = reinterpret_cast<const int4*>(prog)[2 * o + 1];
+      const int kindA = __builtin_amdgcn_readfirstlane(hA0.x);
+      const int two = (kindA >> 8) & 1;           // FOP_BUNDLED; kept as a scalar int on purpose
+      const int4 hB0 = reinterpret_cast<const int4*>(prog)[2 * (o + two)];
+      const int4 hB1 = reinterpret_cast<const int4*>(prog)[2 * (o + two) + 1];
+      int pslotA = 0, dstA = 0, pslotB = 0, dstB = 0;
+      bool mtA = false, mtB = false;
+      double mA = 0.0, mB = 0.0;
+      if (!sf_input(kindA & 0xFF, hA0, hA1, work, psrcs, lane, ABLATED(0), mA, pslotA, dstA, mtA)) {
+        ++o;                                      // a lone variable update: no contraction, no barrier
+        continue;
       }
-      const bool mt = (kind == FOP_PAIR_MT || kind == FOP_VAR_PAIR_MT);
-      gin_w[lane] = m;                            // own-wave exchange: each lane needs other states
-      double* red = red0 + parity * 512;
+      double* redA = red0 + parity * 1024;
+      double* redB = redA + 512;
       parity ^= 1;
-#pragma unroll
-      for (int p = 0; p < NT; ++p) {
-        if (p == pslot) {
-          if (mt) pair_partials<true>(tab[p], gin_w, red, rg, cp, lane);
-          else pair_partials<false>(tab[p], gin_w, red, rg, cp, lane);
-        }
+      gin_w[lane] = mA;                           // own-wave exchange: each lane needs other states
+      if (two != 0) {
+        sf_input(__builtin_amdgcn_readfirstlane(hB0.x) & 0xFF, hB0, hB1, work, psrcs, lane, ABLATED(0), mB, pslotB, dstB, mtB);
+        gin_w[64 + lane] = mB;
       }
-      wg_barrier();
-      double r;
-      if (mt) {
-        r = 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) r += red[q * 64 + lane];
-      } else {
-        r = red[lane] + red[64 + lane];
+      if (!ABLATED(1)) {
+        sf_partials<NT>(tab, pslotA, mtA, gin_w, redA, rg, cp, lane);
+        if (two != 0) sf_partials<NT>(tab, pslotB, mtB, gin_w + 64, redB, rg, cp, lane);
       }
-      // exact power-of-two rescale (largest element -> [1,2)); anything the rescale cannot
-      // represent faithfully sends the graph to the exact kernel
-      const unsigned key = wave_max_u32(mag_key(r));
-      if (__builtin_expect(key >= KEY_BAD || key < KEY_MIN, 0)) {
-        if (t == 0) f.bail[g] = 1;
-        return;                                   // same decision in every wave: r is identical
+      if (!ABLATED(4)) wg_barrier();
+      // exact power-of-two rescale (largest element -> [1,2)); anything the rescale cannot represent
+      // faithfully sends the graph to the exact kernel.  Same decision in every wave: r is identical.
+      double rA = 1.5, rB = 1.5;
+      unsigned keyA = 0x3FF00000u, keyB = 0x3FF00000u;
+      if (!ABLATED(2)) rA = sf_gather(mtA, redA, lane);
+      if (!ABLATED(3)) keyA = wave_max_u32(mag_key(rA));
+      if (two != 0) {
+        if (!ABLATED(2)) rB = sf_gather(mtB, redB, lane);
+        if (!ABLATED(3)) keyB = wave_max_u32(mag_key(rB));
       }
-      work[dst * 64 + lane] = __builtin_ldexp(r, 1023 - (int)(key >> 20));
+#ifdef MLBP_DEBUG_PRINT
+      if (g == 0 && t == 0) printf("o=%d kindA=%x two=%d pslotA=%d dstA=%d mtA=%d pslotB=%d dstB=%d keyA=%x keyB=%x rA=%g rB=%g\n", o, kindA, two, pslotA, dstA, (int)mtA, pslotB, dstB, keyA, keyB, rA, rB);
+#endif
+      if (__builtin_expect(keyA >= KEY_BAD || keyA < KEY_MIN || keyB >= KEY_BAD || keyB < KEY_MIN, 0)) {
+        if (t == 0) f.bail[g] = 2;
+        return;
+      }
+      work[dstA * 64 + lane] = __builtin_ldexp(rA, 1023 - (int)(keyA >> 20));
+      if (two != 0) work[dstB * 64 + lane] = __builtin_ldexp(rB, 1023 - (int)(keyB >> 20));
+      o += 1 + two;
     }
   }
   wg_barrier();
@@ -853,7 +905,7 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
   }
   wg_barrier();
   if (lflag[0]) {                                 // messages of a bailed graph are not written back
-    if (t == 0) f.bail[g] = 1;
+    if (t == 0) f.bail[g] = 3;
     return;
   }
   {
@@ -861,7 +913,13 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
     double2* dst = reinterpret_cast<double2*>(gm);
     for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = src[i];
   }
-  marginals_from_lds_x64(d, work, g, wave, lane);
+  if (d.marginals) {
+    for (int v = wave; v < d.n_vars; v += 4) {
+      double acc = uniform;
+      for (int q = lread[v]; q < lread[v + 1]; ++q) acc = mul_nan_to_num(work[lread[d.n_vars + 1 + q] * 64 + lane], acc);
+      d.marginals[((size_t)g * d.n_vars + v) * 64 + lane] = renorm(acc, wave_sum(acc), uniform, true);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1079,6 +1137,31 @@ void build_fused_program(const int32_t* ops, const int32_t* srcs, const int32_t*
         out.pairseq.push_back(a);
       }
     }
+    // bundle adjacent pairwise updates that touch disjoint message slots
+    {
+      const int f1 = (int)out.fops.size() / 8;
+      auto is_pair = [&](int i) { int kd = out.fops[8 * i] & 0xFF; return kd == FOP_PAIR_TM || kd == FOP_PAIR_MT || kd == FOP_VAR_PAIR_TM || kd == FOP_VAR_PAIR_MT; };
+      auto sets = [&](int i, std::vector<int>& rd, std::vector<int>& wr) {
+        const int32_t* w = &out.fops[8 * i];
+        const int kd = w[0] & 0xFF;
+        rd.clear(); wr.clear();
+        if (kd == FOP_PAIR_TM || kd == FOP_PAIR_MT) { rd.push_back(w[2]); wr.push_back(w[3]); }
+        else { for (int q = 0; q < w[7]; ++q) rd.push_back(out.psrcs[w[6] + q]); wr.push_back(w[3]); wr.push_back(w[5]); }
+      };
+      auto meets = [](const std::vector<int>& x, const std::vector<int>& y) {
+        for (int u : x) for (int v : y) if (u == v) return true;
+        return false;
+      };
+      std::vector<int> ra, wa, rb, wb;
+      const bool no_bundle = getenv("MLBP_NO_BUNDLE") != nullptr;     // A/B switch for measurements
+      for (int i = f0; i + 1 < f1 && !no_bundle; ++i) {
+        if (!is_pair(i) || !is_pair(i + 1)) continue;
+        sets(i, ra, wa); sets(i + 1, rb, wb);
+        if (meets(wa, rb) || meets(wb, ra) || meets(wa, wb)) continue;
+        out.fops[8 * i] |= FOP_BUNDLED;
+        ++i;                                       // bundles hold two updates
+      }
+    }
     out.fsweeps.push_back(f0);
     out.fsweeps.push_back((int)out.fops.size() / 8 - f0);
   }
@@ -1086,7 +1169,7 @@ void build_fused_program(const int32_t* ops, const int32_t* srcs, const int32_t*
   {
     std::vector<char> w(n_msgs, 0);
     for (size_t i = 0; i < out.fops.size(); i += 8) {
-      const int kind = out.fops[i];
+      const int kind = out.fops[i] & 0xFF;
       if (kind == FOP_UNARY) { out.has_unary_fops = true; continue; }
       w[out.fops[i + 3]] = 1;                                            // VAR dst / standalone PAIR dst
       if (kind == FOP_VAR_PAIR_TM || kind == FOP_VAR_PAIR_MT) w[out.fops[i + 5]] = 1;
@@ -1244,6 +1327,7 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
   p->bail_cap = 0;
   p->d_readout = nullptr;
   p->n_vars = 0;
+  p->n_readout = 0;
   if (e == hipSuccess) e = up(&p->d_fops, image.data(), image.size());
   if (e == hipSuccess) e = up(&p->d_fsweeps, fp.fsweeps.data(), fp.fsweeps.size());
   if (e == hipSuccess) e = up(&p->d_fpairseq, fp.pairseq.data(), fp.pairseq.size());
@@ -1301,8 +1385,8 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     else if (want_sf) nt = prog->P;
     if (prog->P == 0 || (!want_sf && nt < prog->P)) nt = 0;
     if (nt > 4) nt = 0;
-    const size_t lds_sf = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 64 + 2 * 512) * sizeof(double) +
-                          (img_words + prog->P + prog->U + 4) * sizeof(int32_t);
+    const size_t lds_sf = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 128 + 4 * 512) * sizeof(double) +
+                          (img_words + prog->P + prog->U + 4 + prog->n_readout) * sizeof(int32_t);
     const size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 64 + 512) * sizeof(double) +
                        (img_words + prog->P + prog->U + 4) * sizeof(int32_t);
     if (lds_sf > LDS_MAX) want_sf = false;
@@ -1322,6 +1406,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
         sf.n_fops = prog->n_fops; sf.n_psrcs = prog->n_psrcs; sf.n_hoist = prog->n_hoist;
         sf.n_cprod = prog->n_cprod; sf.n_cpw = prog->n_cpw; sf.n_ext = n_ext; sf.n_written = prog->n_written;
         sf.init = a->init_messages;
+        sf.n_readout = prog->n_readout;
         void (*ks)(SweepDev, ScaleFreeDev) = nullptr;
         switch (nt) {
           case 1: ks = sweep_x64_sf_kernel<1>; break;
@@ -1424,6 +1509,7 @@ int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_
   HIP_TRY(hipMalloc(&p->d_readout, img.size() * sizeof(int32_t)));
   HIP_TRY(hipMemcpy(p->d_readout, img.data(), img.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   p->n_vars = n_vars;
+  p->n_readout = (int)img.size();
   return MLBP_OK;
 }
 
@@ -1432,6 +1518,20 @@ int mlbp_set_sweep_variant(int32_t variant) {
   if (!known) return fail(MLBP_EINVAL, "unknown sweep variant %d", variant);
   g_sweep_variant = variant;
   return MLBP_OK;
+}
+
+int mlbp_program_exact_count(const mlbp_program* prog, int32_t B) {
+  // Synchronising: how many of the first B graphs of the last default-variant launch were handed
+  // to the exact kernel (0 when the scale-free kernel was not used).
+  if (!prog || B < 0) return fail(MLBP_EINVAL, "mlbp_program_exact_count: bad arguments");
+  if (!prog->d_bail || B == 0) return 0;
+  if (B > prog->bail_cap) B = prog->bail_cap;
+  std::vector<unsigned char> h((size_t)B);
+  HIP_TRY(hipMemcpy(h.data(), prog->d_bail, (size_t)B, hipMemcpyDeviceToHost));
+  int n = 0, hist[4] = {0, 0, 0, 0};
+  for (unsigned char c : h) { n += c ? 1 : 0; hist[c & 3]++; }
+  fail(0, "exact-kernel graphs by reason: prologue %d, main loop %d, final pass %d", hist[1], hist[2], hist[3]);
+  return n;
 }
 
 int mlbp_program_status(const mlbp_program* prog) {

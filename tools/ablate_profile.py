@@ -35,8 +35,9 @@ dev = torch.device('cuda:0')
 fb = FactorGraphBatch(topo, X, B, device=dev)
 fb.set_pair_tables(torch.rand(B * topo.P, X, X, dtype=torch.float64, device=dev) + 0.01)
 fb.set_unary_tables(torch.rand(B * topo.U, X, dtype=torch.float64, device=dev) + 0.01)
-masks = [(0, 'full kernel'), (1, '- variable product'), (2, '- contraction (partials)'), (4, '- gather + normalise'),
-         (8, '- wave-1 normalise/store'), (16, '- both barriers'), (31, '- all of the above (loop skeleton + prologue)')]
+masks = [(0, 'full kernel'), (1, '- variable product'), (2, '- contraction (partials)'), (4, '- gather of partial sums'),
+         (8, '- wave max / rescale key'), (15, '- all four (barrier kept)'), (16, '- barrier only (wrong results)'),
+         (32, '- whole op body')]
 times = {m: [] for m, _ in masks}
 for rnd in range(6):
     for m, _ in masks:
@@ -46,9 +47,9 @@ for rnd in range(6):
         if rnd:
             times[m].append(s.elapsed_time(e))
 if len(sys.argv) > 2:      # sweep-count scan of selected masks
-    for m in (31, 31 | 64, 31 | 64 | 128, 31 | 64 | 128 | 256, 63):
+    for m in (0, 15):
         ffi.check(ffi.lib.mlbp_debug_set_ablate_mask(m))
-        for ns in (6, 12):
+        for ns in (3, 12):
             rr = [roots[i % len(roots)] for i in range(ns)]
             ts = []
             for rnd in range(5):

@@ -999,6 +999,135 @@ __global__ __launch_bounds__(WG) void sweep_generic_kernel(SweepDev d) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// X in {128, 256, 512}, float64: every pairwise update streams a 128 KiB .. 2 MiB table, so the
+// kernel is organised around that stream.  Wave w of the workgroup owns rows i = w, w+4, ...; a row
+// is read by its wave as Q = X/128 fully coalesced 16-byte-per-lane loads (lane l, piece q holds
+// columns 128q + 2l, +1), four rows in flight per wave (16 KiB * Q per workgroup).
+//   out = T . m   (TM): the lane's 2Q message values stay in registers; per row one dot-product
+//                       partial per lane, four rows reduced together by a DPP butterfly.
+//   out = m^T . T (MT): the lane accumulates its 2Q columns over the wave's rows (m_i by LDS
+//                       broadcast); the four waves' accumulators meet in LDS once at the end.
+// Messages stay in global memory (L2 resident; 4 KiB against a 2 MiB table at X = 512).
+// Algorithmic bytes per pairwise update (X*X + 2X) * 8 -- HBM-bound.
+// ------------------------------------------------------------------------------------------------
+template <bool NORM, int Q>
+__global__ __launch_bounds__(WG) void sweep_wide_kernel(SweepDev d) {
+  constexpr int X = 128 * Q;
+  extern __shared__ double lds[];
+  double* vin = lds;             // [X] input message of the update in flight
+  double* raw = lds + X;         // [X] un-normalised result
+  double* part = lds + 2 * X;    // [4][X] per-wave column accumulators (MT)
+  double* scratch = part + 4 * X;  // [4]
+  const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (!tables_in_range(d, g)) return;
+  double* gm = d.msgs + (size_t)g * d.n_msgs * X;
+  const int32_t* ptab = d.pair_tab + (size_t)g * d.P;
+  const int32_t* utab = d.unary_tab + (size_t)g * d.U;
+  const double uniform = 1.0 / (double)X;
+  const const_i32p c_ops = as_const(d.ops), c_sweeps = as_const(d.sweeps), c_srcs = as_const(d.srcs);
+  for (int s = 0; s < d.n_sweeps; ++s) {
+    const int op0 = c_sweeps[2 * s], nop = c_sweeps[2 * s + 1];
+    for (int o = op0; o < op0 + nop; ++o) {
+      const int kind = c_ops[4 * o], a = c_ops[4 * o + 1], b = c_ops[4 * o + 2], c = c_ops[4 * o + 3];
+      if (kind == MLBP_OP_PAIR_TM || kind == MLBP_OP_PAIR_MT) {
+        const double* T = d.pair_tables + (size_t)ptab[a] * X * X;
+        const double* m = gm + (size_t)b * X;
+        for (int j = t; j < X; j += WG) vin[j] = m[j];
+        __syncthreads();
+        if (kind == MLBP_OP_PAIR_TM) {
+          double2 mj[Q];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) mj[q] = reinterpret_cast<const double2*>(vin)[64 * q + lane];
+          for (int i0 = wave; i0 < X; i0 += 16) {          // rows i0, i0+4, i0+8, i0+12 of this wave
+            double2 r[4][Q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int q = 0; q < Q; ++q)
+                r[u][q] = reinterpret_cast<const double2*>(T + (size_t)(i0 + 4 * u) * X)[64 * q + lane];
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              double acc = 0.0;
+#pragma unroll
+              for (int q = 0; q < Q; ++q) acc += r[u][q].x * mj[q].x + r[u][q].y * mj[q].y;
+              v[u] = acc;
+            }
+            // 4 values x 64 lanes -> 4 row sums: transposing butterfly inside each 16-lane row (4 -> 2
+            // -> 1 live values), then plain sums inside the row, then the four rows through readlane
+            {
+              const bool up = lane & 8;
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
+                const double send = up ? v[k] : v[k + 2], keep = up ? v[k + 2] : v[k];
+                v[k] = keep + dpp_mov<0x140>(send);
+              }
+            }
+            {
+              const bool up = lane & 4;
+              const double send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
+              v[0] = keep + dpp_mov<0x141>(send);
+            }
+            v[0] += dpp_mov<0x1B>(v[0]);
+            v[0] += dpp_mov<0xB1>(v[0]);
+            // lanes with equal (bit3, bit2) hold the same row u = 2*bit3 + bit2, summed over 16 lanes
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int src = ((u >> 1) << 3) | ((u & 1) << 2);
+              const double tot = (read_lane(v[0], src) + read_lane(v[0], 16 + src)) +
+                                 (read_lane(v[0], 32 + src) + read_lane(v[0], 48 + src));
+              if (lane == 0) raw[i0 + 4 * u] = tot;
+            }
+          }
+        } else {
+          double2 acc[Q];
+#pragma unroll
+          for (int q = 0; q < Q; ++q) acc[q] = make_double2(0.0, 0.0);
+          for (int i0 = wave; i0 < X; i0 += 16) {
+            double2 r[4][Q];
+            double mi[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              mi[u] = vin[i0 + 4 * u];
+#pragma unroll
+              for (int q = 0; q < Q; ++q)
+                r[u][q] = reinterpret_cast<const double2*>(T + (size_t)(i0 + 4 * u) * X)[64 * q + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+              for (int q = 0; q < Q; ++q) {
+                acc[q].x += mi[u] * r[u][q].x;
+                acc[q].y += mi[u] * r[u][q].y;
+              }
+          }
+#pragma unroll
+          for (int q = 0; q < Q; ++q) reinterpret_cast<double2*>(part + wave * X)[64 * q + lane] = acc[q];
+          __syncthreads();
+          for (int j = t; j < X; j += WG) raw[j] = (part[j] + part[X + j]) + (part[2 * X + j] + part[3 * X + j]);
+        }
+      } else if (kind == MLBP_OP_VAR) {
+        for (int j = t; j < X; j += WG) {
+          double acc = uniform;
+          for (int q = 0; q < b; ++q) acc = nan_to_num(gm[(size_t)c_srcs[a + q] * X + j] * acc);
+          raw[j] = acc;
+        }
+      } else {
+        const double* u = d.unary_tables + (size_t)utab[a] * X;
+        for (int j = t; j < X; j += WG) raw[j] = u[j];
+      }
+      __syncthreads();
+      double psum = 0.0;
+      for (int j = t; j < X; j += WG) psum += raw[j];
+      const double total = NORM ? block_sum(psum, scratch) : 0.0;
+      double* out = gm + (size_t)c * X;
+      for (int j = t; j < X; j += WG) out[j] = renorm(raw[j], total, uniform, NORM);
+      __syncthreads();
+    }
+  }
+}
+
 __global__ void fill_kernel(double* p, int64_t n, double v) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1461,6 +1590,19 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
                                   prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream);
       return MLBP_OK;
     }
+  }
+  if ((a->X == 128 || a->X == 256 || a->X == 512) && variant != 0) {
+    const size_t ldsw = ((size_t)6 * a->X + 4) * sizeof(double);
+    void (*kw)(SweepDev) = nullptr;
+    if (a->X == 128) kw = norm ? sweep_wide_kernel<true, 1> : sweep_wide_kernel<false, 1>;
+    else if (a->X == 256) kw = norm ? sweep_wide_kernel<true, 2> : sweep_wide_kernel<false, 2>;
+    else kw = norm ? sweep_wide_kernel<true, 4> : sweep_wide_kernel<false, 4>;
+    hipLaunchKernelGGL(kw, dim3(a->B), dim3(WG), ldsw, st, d);
+    HIP_TRY(hipGetLastError());
+    if (a->marginals)
+      return mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
+                                prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream);
+    return MLBP_OK;
   }
   size_t base = ((size_t)a->X + 4) * sizeof(double);
   size_t with_msgs = base + (size_t)prog->n_msgs * a->X * sizeof(double);

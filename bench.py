@@ -157,11 +157,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the engine has no CPU path')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # MLBP_BENCH_BACKEND=gloo is a REHEARSAL switch for a box with fewer GPUs than ranks (ranks then
+    # share devices and reduce through the host); the driver's real runs use RCCL ("nccl").
+    backend = os.environ.get('MLBP_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank if backend == 'nccl' else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     spec, roots, sweeps, seed = workload_spec(a.workload)
     if a.sweeps:
@@ -178,7 +185,11 @@ def main():
     fb.set_unary_tables(unary)
     labels = np.tile(np.array([dict(zip(spec['var_ids'], spec['labels']))[v] for v in topo.var_ids]), (B, 1))
     labels_d = torch.from_numpy(labels.astype(np.int32)).to(dev)
-    stats = torch.zeros(16, dtype=torch.float64, device=dev)
+    # two statistics buffers: the all-reduce of step i is asynchronous and overlaps step i+1's sweeps
+    # (the reference's accumulate callback is asynchronous too, train_mp.py:405-424, 636-647)
+    stats = [torch.zeros(16, dtype=torch.float64, device=dev) for _ in range(2)]
+    pending = [None, None]
+    step_no = [0]
     marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)
     lp = torch.empty(B, dtype=torch.float64, device=dev)
     import ctypes as C
@@ -199,9 +210,13 @@ def main():
             ev[i][1].record()
         _ffi.check(_ffi.lib.mlbp_log_posterior_f64(marg.data_ptr(), labels_d.data_ptr(), B, topo.n_vars, X,
                                                    lp.data_ptr(), _stream_ptr(dev)))
-        stats[0] = lp.sum()
-        if world > 1:
-            dist.all_reduce(stats)          # the outer-loop reduction of train_mp.py:405-424 (one per step)
+        k = step_no[0] & 1
+        step_no[0] += 1
+        if pending[k] is not None:
+            pending[k].wait()               # the all-reduce issued two steps ago (long finished)
+        stats[k][0] = lp.sum()
+        if world > 1:                       # the outer-loop reduction of train_mp.py:405-424: one per step
+            pending[k] = dist.all_reduce(stats[k], async_op=True)
 
     for _ in range(a.warmup):
         step()
@@ -212,6 +227,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
+    for w in pending:
+        if w is not None:
+            w.wait()                        # every step's reduction completes inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -248,7 +266,8 @@ def main():
                                    % (a.workload, B, X, topo.P, topo.U, sweeps),
                        'graphs_per_gpu': B, 'X': X, 'sweeps_per_step': sweeps, 'roots': list(roots),
                        'graph_sweeps_per_s': world * B * sweeps * a.steps / elapsed,
-                       'parallelism': 'graphs sharded over %d GPU(s), no data-path collective' % world},
+                       'parallelism': 'graphs sharded over %d GPU(s), no data-path collective; one all-reduce of the '
+                                      'step statistics per step (%s)' % (world, backend if world > 1 else 'n/a')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': ('sweep_x64_sf_kernel (timed region = hipMemsetAsync of the flag bytes + this kernel + the ~6 us fix-up '

@@ -144,3 +144,38 @@ def test_train_step_matches_sum_of_reference_steps():
     np.testing.assert_allclose(t_ee.cpu().numpy(), (inputs['theta_en_en'] + s_ee).reshape(-1), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(t_ed.cpu().numpy(), (inputs['theta_en_de'] + s_ed).reshape(-1), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(mean_lp, lp / B, rtol=1e-10)
+
+
+def test_synthetic_ti_dir_bucket_through_the_trainer(tmp_path):
+    """TI_DIR files -> parsed instances -> shape buckets -> UserGraphTrainer statistics, against the
+    oracle run per instance on the spec that instance implies."""
+    import copy
+    from macaronicusermodeling_amd import tidir
+    from macaronicusermodeling_amd.train import UserGraphTrainer
+    paths = tidir.synthesize(str(tmp_path), n_instances=60, X=64, Vde=64, sent_len=(5, 7), n_predicted=(3, 3), seed=5)
+    en, de = tidir.read_vocab(paths['end']), tidir.read_vocab(paths['ded'])
+    phi_ee, phi_w1, phi_ed = tidir.load_features(paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'], paths['phi_ped'])
+    buckets = tidir.bucket_instances(tidir.read_instances(paths['ti']), en, de)
+    key, b = max(buckets.items(), key=lambda kv: len(kv[1]['rows']))
+    rs = np.random.RandomState(1)
+    theta_ee, theta_ed = rs.randn(1, 3) * 0.3, rs.randn(1, 6) * 0.3
+    roots = [key[1][0], key[1][1], key[1][2]]
+    tr = UserGraphTrainer(b['spec'], b['var_labels'], b['unary_obs'], phi_ee, phi_w1, phi_ed, theta_ee, theta_ed, roots=roots)
+    stats = tr.local_statistics().cpu().numpy()
+    inputs = dict(phi_en_en=phi_ee, phi_en_en_w1=phi_w1, phi_en_de=phi_ed, theta_en_en=theta_ee, theta_en_de=theta_ed,
+                  pot_en_en=np.exp(phi_ee.dot(theta_ee.T).reshape(64, 64)),
+                  pot_en_en_w1=np.exp(phi_w1.dot(theta_ee.T).reshape(64, 64)),
+                  pot_en_de=np.exp(phi_ed.dot(theta_ed.T).reshape(64, 64)))
+    want = np.zeros(3 + 6 + 2)
+    unary = [f for f in sorted(b['spec']['factors'], key=lambda f: f['id']) if len(f['vars']) == 1]
+    for i in range(len(b['rows'])):
+        s = copy.deepcopy(b['spec'])
+        s['labels'] = [int(v) for v in b['var_labels'][i]]
+        for u, f in enumerate(unary):
+            s['factors'][f['id']]['observed_dim'] = int(b['unary_obs'][i, u])
+        g = O.Graph(s)
+        msgs = O.init_messages(g)
+        O.treelike_inference(g, inputs, msgs, 3, roots, O.has_loops(g, roots[0]))
+        ee, ed = O.unregularized_gradient(g, inputs, msgs)
+        want[:3] += ee.reshape(-1); want[3:9] += ed.reshape(-1); want[9] += O.log_posterior(g, msgs); want[10] += 1
+    np.testing.assert_allclose(stats, want, rtol=1e-8, atol=1e-10)

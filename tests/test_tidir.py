@@ -1,0 +1,86 @@
+"""Data formats around the hot path (macaronicusermodeling_amd.tidir): TI JSON schema and
+normalisation rules, vocab / feature files, the instance -> shape compiler, params file round trip.
+Host-side only (no GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases as C
+from macaronicusermodeling_amd import tidir
+
+
+def test_guess_and_node_normalisation_rules():
+    # training_classes.py:97-110
+    assert tidir.normalize_guess('  ') == '__blank__'
+    assert tidir.normalize_guess('__UNK__') == '__UNK__'              # kept verbatim
+    assert tidir.normalize_guess("Don't") == 'dont'
+    assert tidir.normalize_guess('the quick fox') == 'quick'          # longest token of a phrasal guess
+    assert tidir.normalize_guess('word*') == 'word'
+    assert tidir.normalize_guess('*') == '*'
+    n = tidir.parse_node(dict(sent_id=3, id=[3, 1], l2_word="It's", l1_parent='X', position='2', lang='en'))
+    assert n['l2_word'] == 'its' and n['position'] == 2 and n['id'] == (3, 1) and n['l1_parent'] == 'X'
+    n = tidir.parse_node(dict(sent_id=3, id=[3, 2], l2_word='Haus', l1_parent="House's", position=0, lang='de'))
+    assert n['l2_word'] == 'Haus' and n['l1_parent'] == 'houses'
+
+
+def test_shape_spec_equals_the_case_generator():
+    """Two independent restatements of train_mp.py:257-299 must agree on ids, order, gaps."""
+    for L, pred in [(10, [1, 4, 7]), (6, [0, 3]), (5, [2]), (9, [0, 1, 3, 5, 7])]:
+        a = tidir.shape_spec(L, pred, 16, 12)
+        b = C.user_spec(L, pred, 16, 12)
+        assert a['var_ids'] == b['var_ids']
+        for fa, fb in zip(a['factors'], b['factors']):
+            for k in ('id', 'vars', 'dims', 'factor_type', 'gap', 'obs_size', 'position'):
+                assert fa[k] == fb[k], (k, fa, fb)
+        assert len(a['factors']) == len(b['factors'])
+
+
+def test_synthetic_ti_dir_round_trip(tmp_path):
+    paths = tidir.synthesize(str(tmp_path), n_instances=40, X=16, Vde=12, seed=3)
+    en, de = tidir.read_vocab(paths['end']), tidir.read_vocab(paths['ded'])
+    assert len(en) == 16 and len(de) == 12
+    phi_ee, phi_w1, phi_ed = tidir.load_features(paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'], paths['phi_ped'])
+    assert phi_ee.shape == (16, 16, 3) and phi_w1.shape == (16, 16, 3) and phi_ed.shape == (16, 12, 6)
+    assert np.all(phi_ee[:, :, 1] == 0) and np.all(phi_ee[:, :, 2] == 1)          # train_mp.py:602-603
+    assert np.all(phi_ed[:, :, 2:5] == 0) and np.all(phi_ed[:, :, 5] == 1)        # train_mp.py:614-619
+    inst = tidir.read_instances(paths['ti'])
+    assert len(inst) == 40
+    buckets = tidir.bucket_instances(inst, en, de)
+    assert sum(len(b['rows']) for b in buckets.values()) == 40
+    for (L, pred), b in buckets.items():
+        spec = b['spec']
+        n_given = L - len(pred)
+        U = len(pred) * (1 + n_given)
+        assert b['var_labels'].shape == (len(b['rows']), len(pred))
+        assert b['unary_obs'].shape == (len(b['rows']), U)
+        assert len([f for f in spec['factors'] if len(f['vars']) == 2]) == len(pred) * (len(pred) - 1) // 2
+        # observed columns: en_de factors index the de vocabulary, en_en ones the en vocabulary
+        unary = [f for f in spec['factors'] if len(f['vars']) == 1]
+        for u, f in enumerate(unary):
+            lim = 12 if f['factor_type'] == 'en_de' else 16
+            assert b['unary_obs'][:, u].min() >= 0 and b['unary_obs'][:, u].max() < lim
+    # one instance by hand
+    raw = json.loads(open(paths['ti']).readline())
+    key, rec = tidir.instance_shape(tidir.parse_instance(raw), {w: i for i, w in enumerate(en)},
+                                    {w: i for i, w in enumerate(de)})
+    guessed = sorted(n['position'] for n in raw['current_sent']
+                     if any(g['id'] == n['id'] for g in raw['current_guesses']))
+    assert list(key[1]) == guessed and key[0] == len(raw['current_sent'])
+
+
+def test_params_file_round_trip(tmp_path):
+    p = os.path.join(str(tmp_path), 'params')
+    ee = np.array([[0.125, -1.5, 2.0]])
+    ed = np.array([[0.1, 0.2, 0.3, -0.4, 0.5, 0.000001]])
+    d2t = {('en_en', 'u1'): ee * 2, ('en_de', 'u1'): ed * 3}
+    tidir.save_params(p, ee, ed, d2t=d2t)
+    lines = open(p).read().split('\n')
+    assert lines[0] == 'EE_F:\tpmi\tpmi_w1\tbias'                                     # train_mp.py:81
+    assert lines[1] == 'Original'.ljust(15) + '\t0.125000\t-1.500000\t2.000000'        # train_mp.py:82-84
+    een, eet, edn, edt, got = tidir.read_params(p)
+    assert een == tidir.EE_NAMES and edn == tidir.ED_NAMES
+    np.testing.assert_allclose(eet, ee, atol=1e-6); np.testing.assert_allclose(edt, ed, atol=1e-6)
+    np.testing.assert_allclose(got['en_en', 'u1'], ee * 2, atol=1e-6)
+    np.testing.assert_allclose(got['en_de', 'u1'], ed * 3, atol=1e-6)

@@ -270,6 +270,10 @@ int mlbp_normalize_f64(const double* in, double* out, int32_t batch, int64_t n, 
  * text of NumPy's error, "kth(=K-1) out of bounds (n)". */
 int mlbp_topk_f64(const double* v, int64_t stride, int32_t n, int32_t K, int32_t* idx, void* stream);
 
+/* The same selection for every row of a contiguous [rows][n] matrix (idx: device int32 [rows][K]):
+ * VariableNode.get_max_vocab for a batch of marginals (LBP.py:402-411). */
+int mlbp_topk_rows_f64(const double* v, int64_t rows, int32_t n, int32_t K, int32_t* idx, void* stream);
+
 /* au.sparse_vec_mat_dot (c_array_utils.pyx:193-205) given the selected indices:
  *   vec_is_row = 0: out[i] = sum_q mat[i][idx[q]] * vec[idx[q]]     (mat[:, idx] . vec[idx])
  *   vec_is_row = 1: out[j] = sum_q vec[idx[q]] * mat[idx[q]][j]     (vec[0, idx] . mat[idx, :])

@@ -79,6 +79,7 @@ SIGNATURES = {
     'mlbp_pointwise_multiply_f64': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     'mlbp_normalize_f64': (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _vp]),
     'mlbp_topk_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    'mlbp_topk_rows_f64': (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp]),
     'mlbp_sparse_vec_mat_dot_f64': (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _i32, _i32, _vp, _vp]),
     'mlbp_sparse_dot_f64': (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     'mlbp_sparse_pointwise_multiply_f64': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp]),

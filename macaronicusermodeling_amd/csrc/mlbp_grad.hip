@@ -30,8 +30,8 @@ constexpr int FMAX = 8;
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);   // one v_mov_b32_dpp each (update_dpp adds a copy)
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double read_lane(double v, int lane) {

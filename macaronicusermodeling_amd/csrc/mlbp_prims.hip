@@ -103,8 +103,11 @@ __global__ __launch_bounds__(256) void normalize_kernel(const double* in, double
 // idx[rank], i.e. in descending value order.  O(n^2 / 256) compares per thread -- n is a vocabulary
 // size (hundreds to a few thousand).  NaNs compare false everywhere and rank first among equals;
 // the reference's np.argpartition leaves their place unspecified.
-__global__ __launch_bounds__(256) void topk_kernel(const double* v, int64_t stride, int n, int K, int32_t* idx) {
+__global__ __launch_bounds__(256) void topk_kernel(const double* v0, int64_t stride, int n, int K, int32_t* idx0,
+                                                   int64_t row_stride) {
   extern __shared__ double sv[];
+  const double* v = v0 + (int64_t)blockIdx.x * row_stride;      // one workgroup per row
+  int32_t* idx = idx0 + (int64_t)blockIdx.x * K;
   for (int i = threadIdx.x; i < n; i += 256) sv[i] = v[(int64_t)i * stride];
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += 256) {
@@ -249,7 +252,20 @@ int mlbp_topk_f64(const double* v, int64_t stride, int32_t n, int32_t K, int32_t
   if (int e = need_device()) return e;
   size_t lds = (size_t)n * sizeof(double);
   if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, v, stride, n, K, idx);
+  hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, v, stride, n, K, idx, (int64_t)0);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_topk_rows_f64(const double* v, int64_t rows, int32_t n, int32_t K, int32_t* idx, void* stream) {
+  if (!v || !idx || rows <= 0 || n <= 0 || K <= 0) return fail(MLBP_EINVAL, "mlbp_topk_rows_f64: bad arguments");
+  if (K > n) return fail(MLBP_EINVAL, "kth(=%d) out of bounds (%d)", n - K, n);
+  if (n > 16384) return fail(MLBP_EUNSUPPORTED, "mlbp_topk_rows_f64: n=%d > 16384", n);
+  if (rows > 0x7fffffff) return fail(MLBP_EINVAL, "mlbp_topk_rows_f64: too many rows");
+  if (int e = need_device()) return e;
+  size_t lds = (size_t)n * sizeof(double);
+  if (lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(topk_kernel, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream, v, (int64_t)1, n, K, idx, (int64_t)n);
   HIP_TRY(hipGetLastError());
   return MLBP_OK;
 }

@@ -50,8 +50,8 @@ __device__ __forceinline__ double nan_to_num(double x) {
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);   // one v_mov_b32_dpp each (update_dpp adds a copy)
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -658,10 +658,10 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
 // then runs the exact kernel (sweep_x64_fused_kernel) on the flagged graphs only.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));
-  v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true));
   const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
   const unsigned c = __builtin_amdgcn_readlane((int)v, 32), e = __builtin_amdgcn_readlane((int)v, 48);
   return max(max(a, b), max(c, e));
@@ -809,8 +809,8 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
     for (int j = 0; j < HB; ++j) {
       const int h = h0 + 4 * j;
       if (h < f.n_hoist) {
-        const double s = wave_sum(r[j]);
-        const double m = renorm(r[j], s, uniform, true);        // exact, these are final values
+        const double s = ABLATED(9) ? 1.0 : wave_sum(r[j]);
+        const double m = ABLATED(9) ? r[j] : renorm(r[j], s, uniform, true);        // exact, these are final values
         bad_key = max(bad_key, mag_key(m));
         work[phoist[2 * h + 1] * 64 + lane] = m;
       }
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
     int at = 0;
     for (int k = 0; k < f.n_cprod; ++k) {
       const int cnt = pcp[at];
-      if ((k & 3) == wave) {
+      if ((k & 3) == wave && !ABLATED(10)) {
         double acc = uniform;
         for (int q = 0; q < cnt; ++q) {
           acc *= work[pcp[at + 1 + q] * 64 + lane];
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
   }
   wg_barrier();
   // ---- the deferred normalisations: exactly the slots the program wrote ----
-  for (int i = wave; i < f.n_written; i += 4) {
+  for (int i = wave; i < f.n_written && !ABLATED(11); i += 4) {
     const int slot = pwritten[i];
     const double v = work[slot * 64 + lane];
     const unsigned key = wave_max_u32(mag_key(v));
@@ -911,9 +911,9 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
   {
     const double2* src = reinterpret_cast<const double2*>(work);
     double2* dst = reinterpret_cast<double2*>(gm);
-    for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = src[i];
+    for (int i = t; i < d.n_msgs * 32 && !ABLATED(13); i += WG) dst[i] = src[i];
   }
-  if (d.marginals) {
+  if (d.marginals && !ABLATED(12)) {
     for (int v = wave; v < d.n_vars; v += 4) {
       double acc = uniform;
       for (int q = lread[v]; q < lread[v + 1]; ++q) acc = mul_nan_to_num(work[lread[d.n_vars + 1 + q] * 64 + lane], acc);

@@ -58,8 +58,11 @@ class UserGraphTrainer:
         self.Vde = int(fb.phi_en_de.shape[1])
         self.F_ee, self.F_ed = int(fb.phi_en_en.shape[2]), int(fb.phi_en_de.shape[2])
         dev = self.device
-        self.theta_en_en = torch.as_tensor(np.asarray(theta_en_en, dtype=np.float64).reshape(-1)).to(dev)
-        self.theta_en_de = torch.as_tensor(np.asarray(theta_en_de, dtype=np.float64).reshape(-1)).to(dev)
+        # theta may be passed as device tensors so that several shape buckets share one parameter vector
+        self.theta_en_en = theta_en_en if isinstance(theta_en_en, torch.Tensor) else \
+            torch.as_tensor(np.asarray(theta_en_en, dtype=np.float64).reshape(-1)).to(dev)
+        self.theta_en_de = theta_en_de if isinstance(theta_en_de, torch.Tensor) else \
+            torch.as_tensor(np.asarray(theta_en_de, dtype=np.float64).reshape(-1)).to(dev)
         # pots: [pot_en_en, pot_en_en_w1] as pairwise tables; their transposes + pot_en_de^T as unary rows
         self.pair_tables = torch.empty(2, X, X, dtype=torch.float64, device=dev)
         self.unary_tables = torch.empty(2 * X + self.Vde, X, dtype=torch.float64, device=dev)
@@ -115,6 +118,32 @@ class UserGraphTrainer:
         apply_update(self.theta_en_en, self.theta_en_de, stats, self.F_ee, self.F_ed, learning_rate, reg_param)
         return float(stats[-2].item() / stats[-1].item()), self.theta_en_en, self.theta_en_de
 
+    def predict(self, top=50):
+        """batch_predictions for the shard (train_mp.py:310-343): runs inference and returns
+        (log-posterior per instance [B] (host), top-`top` word indices per predicted variable
+        [B][n_vars][top] in descending probability (device top-K), their log-probabilities, and the
+        precision counts (p@0, p@25, p@50, total) of FactorGraph.get_precision_counts, LBP.py:80-106)."""
+        fb, topo = self.batch, self.topo
+        self.build_potentials()
+        fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg)
+        st = _stream_ptr(self.device)
+        _ffi.check(_ffi.lib.mlbp_log_posterior_f64(self._marg.data_ptr(), fb._labels.data_ptr(), fb.B, topo.n_vars, fb.X,
+                                                   self._lp.data_ptr(), st))
+        idx = torch.empty(fb.B, topo.n_vars, top, dtype=torch.int32, device=self.device)
+        _ffi.check(_ffi.lib.mlbp_topk_rows_f64(self._marg.data_ptr(), fb.B * topo.n_vars, fb.X, top, idx.data_ptr(), st))
+        logm = torch.empty_like(self._marg)
+        _ffi.check(_ffi.lib.mlbp_log_f64(self._marg.data_ptr(), logm.data_ptr(), self._marg.numel(), st))
+        idx_h = idx.cpu().numpy().astype(np.int64)
+        logs = np.take_along_axis(logm.cpu().numpy(), idx_h, axis=2)
+        labels = fb._labels.cpu().numpy()
+        # integer work: rank of the user's label among the top words of every en_de factor's variable
+        by_id = {f['id']: f for f in self.spec['factors']}
+        ed_vars = [int(topo.fac_var[2 * j]) for j in topo.unary_factors if by_id[topo.factor_ids[j]]['factor_type'] == 'en_de']
+        hit = idx_h[:, ed_vars, :] == labels[:, ed_vars, None]
+        rank = np.where(hit.any(-1), hit.argmax(-1), 10 ** 6)
+        counts = (int((rank == 0).sum()), int((rank < 26).sum()), int((rank < 51).sum()), int(rank.size))
+        return self._lp.cpu().numpy(), idx_h, logs, counts
+
 
 def apply_update(theta_en_en, theta_en_de, stats, F_ee, F_ed, learning_rate, reg_param):
     """theta += sum_i lr (g_i - reg theta) = lr (sum_i g_i - n reg theta): the sum of the per-instance
@@ -124,3 +153,61 @@ def apply_update(theta_en_en, theta_en_de, stats, F_ee, F_ed, learning_rate, reg
     theta_en_en += learning_rate * (stats[:F_ee] - n * reg_param * theta_en_en)
     theta_en_de += learning_rate * (stats[F_ee:F_ee + F_ed] - n * reg_param * theta_en_de)
     return theta_en_en, theta_en_de
+
+
+class TiDirTrainer:
+    """The outer loop of train_mp.py's __main__ (train_mp.py:560-690) over files in the reference's
+    formats: vocabularies, feature matrices, JSON training instances -> one UserGraphTrainer per
+    sentence shape sharing theta; per epoch one fused statistics buffer, one all-reduce, one update;
+    params written in the reference's text format."""
+
+    def __init__(self, ti_path, en_vocab, de_vocab, phi_pmi, phi_pmi_w1, phi_ed, phi_ped, device='cuda:0', sweeps=3,
+                 rank=0, world=1):
+        from . import tidir
+        self.en, self.de = tidir.read_vocab(en_vocab), tidir.read_vocab(de_vocab)
+        phi_ee, phi_w1, phi_ed_t = tidir.load_features(phi_pmi, phi_pmi_w1, phi_ed, phi_ped)
+        instances = tidir.read_instances(ti_path)
+        self.n_total = len(instances)
+        lo, hi = mdist.shard_range(len(instances), rank, world)
+        self.buckets = tidir.bucket_instances(instances[lo:hi], self.en, self.de)
+        dev = torch.device(device)
+        self.theta_en_en = torch.zeros(len(tidir.EE_NAMES), dtype=torch.float64, device=dev)   # train_mp.py:519-523
+        self.theta_en_de = torch.zeros(len(tidir.ED_NAMES), dtype=torch.float64, device=dev)
+        self.trainers = {}
+        for key, b in sorted(self.buckets.items()):
+            roots = [key[1][i % len(key[1])] for i in range(sweeps)]
+            self.trainers[key] = UserGraphTrainer(b['spec'], b['var_labels'], b['unary_obs'], phi_ee, phi_w1, phi_ed_t,
+                                                  self.theta_en_en, self.theta_en_de, device=device, sweeps=sweeps, roots=roots)
+        self.stats = torch.zeros(len(tidir.EE_NAMES) + len(tidir.ED_NAMES) + 2, dtype=torch.float64, device=dev)
+
+    def epoch(self, learning_rate, reg_param):
+        self.stats.zero_()
+        for tr in self.trainers.values():
+            self.stats += tr.local_statistics()
+        mdist.all_reduce_sum_(self.stats)
+        apply_update(self.theta_en_en, self.theta_en_de, self.stats, len(self.theta_en_en), len(self.theta_en_de),
+                     learning_rate, reg_param)
+        return float(self.stats[-2].item() / max(self.stats[-1].item(), 1.0))
+
+    def train(self, epochs=3, reg_param=0.2, save_params=None):
+        """lr = 0.1 / (1 + 0.3 epoch) (train_mp.py:627-630); regularisation reg_param / N (train_mp.py:160);
+        params saved as <save_params>.iter<epoch> and <save_params> (train_mp.py:654-656, 688-690)."""
+        from . import tidir
+        history = []
+        for epoch in range(epochs):
+            history.append(self.epoch(0.1 / (1.0 + 0.3 * epoch), float(reg_param) / float(self.n_total)))
+            if save_params:
+                tidir.save_params('%s.iter%d' % (save_params, epoch), self.theta_en_en.cpu().numpy().reshape(1, -1),
+                                  self.theta_en_de.cpu().numpy().reshape(1, -1))
+        if save_params:
+            tidir.save_params(save_params, self.theta_en_en.cpu().numpy().reshape(1, -1),
+                              self.theta_en_de.cpu().numpy().reshape(1, -1))
+        return history
+
+    def predict(self):
+        """-> (mean log-posterior, (p@0, p@25, p@50, total)) over this rank's instances (train_mp.py:666-684)."""
+        lp, counts, n = 0.0, np.zeros(4, dtype=np.int64), 0
+        for tr in self.trainers.values():
+            l, _, _, c = tr.predict(top=min(50, tr.batch.X))
+            lp += float(l.sum()); counts += np.array(c); n += len(l)
+        return lp / max(n, 1), tuple(int(v) for v in counts)

@@ -1,5 +1,7 @@
 """Batched beliefs / gradient kernels and the train_mp-shaped step against reference fixtures and
 the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -179,3 +181,57 @@ def test_synthetic_ti_dir_bucket_through_the_trainer(tmp_path):
         ee, ed = O.unregularized_gradient(g, inputs, msgs)
         want[:3] += ee.reshape(-1); want[3:9] += ed.reshape(-1); want[9] += O.log_posterior(g, msgs); want[10] += 1
     np.testing.assert_allclose(stats, want, rtol=1e-8, atol=1e-10)
+
+
+def test_tidir_trainer_epochs_and_predictions(tmp_path):
+    """End to end over files: three epochs of TiDirTrainer (all shape buckets, shared theta) against
+    the same loop driven by the oracle; params file written in the reference's format; prediction
+    counts against the oracle's precision counts."""
+    import copy
+    from macaronicusermodeling_amd import tidir
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    paths = tidir.synthesize(str(tmp_path), n_instances=24, X=64, Vde=64, sent_len=(4, 6), n_predicted=(1, 3), seed=9)
+    tt = TiDirTrainer(paths['ti'], paths['end'], paths['ded'], paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'],
+                      paths['phi_ped'], sweeps=3)
+    assert sum(len(b['rows']) for b in tt.buckets.values()) == 24 and len(tt.buckets) > 1
+    save = os.path.join(str(tmp_path), 'params')
+    hist = tt.train(epochs=2, reg_param=0.2, save_params=save)
+    # the oracle's version of the same two epochs
+    phi_ee, phi_w1, phi_ed = tidir.load_features(paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'], paths['phi_ped'])
+    th_ee, th_ed = np.zeros((1, 3)), np.zeros((1, 6))
+
+    def oracle_pass(th_ee, th_ed, want_counts=False):
+        inputs = dict(phi_en_en=phi_ee, phi_en_en_w1=phi_w1, phi_en_de=phi_ed, theta_en_en=th_ee, theta_en_de=th_ed,
+                      pot_en_en=np.exp(phi_ee.dot(th_ee.T).reshape(64, 64)), pot_en_en_w1=np.exp(phi_w1.dot(th_ee.T).reshape(64, 64)),
+                      pot_en_de=np.exp(phi_ed.dot(th_ed.T).reshape(64, 64)))
+        tot = np.zeros(11); counts = np.zeros(4, dtype=np.int64)
+        for key, b in sorted(tt.buckets.items()):
+            unary = [f for f in sorted(b['spec']['factors'], key=lambda f: f['id']) if len(f['vars']) == 1]
+            roots = [key[1][i % len(key[1])] for i in range(3)]
+            for i in range(len(b['rows'])):
+                s = copy.deepcopy(b['spec'])
+                s['labels'] = [int(v) for v in b['var_labels'][i]]
+                for u, f in enumerate(unary):
+                    s['factors'][f['id']]['observed_dim'] = int(b['unary_obs'][i, u])
+                g = O.Graph(s); msgs = O.init_messages(g)
+                O.treelike_inference(g, inputs, msgs, 3, roots, O.has_loops(g, roots[0]))
+                ee, ed = O.unregularized_gradient(g, inputs, msgs)
+                tot[:3] += ee.reshape(-1); tot[3:9] += ed.reshape(-1); tot[9] += O.log_posterior(g, msgs); tot[10] += 1
+                if want_counts:
+                    counts += np.array(O.precision_counts(g, msgs))
+        return tot, counts
+    for epoch in range(2):
+        lr, reg = 0.1 / (1 + 0.3 * epoch), 0.2 / 24
+        tot, _ = oracle_pass(th_ee, th_ed)
+        np.testing.assert_allclose(hist[epoch], tot[9] / 24, rtol=1e-9)
+        th_ee = th_ee + lr * (tot[:3] - 24 * reg * th_ee)
+        th_ed = th_ed + lr * (tot[3:9] - 24 * reg * th_ed)
+    np.testing.assert_allclose(tt.theta_en_en.cpu().numpy(), th_ee.reshape(-1), rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(tt.theta_en_de.cpu().numpy(), th_ed.reshape(-1), rtol=1e-8, atol=1e-11)
+    een, eet, edn, edt, _ = tidir.read_params(save)
+    np.testing.assert_allclose(eet.reshape(-1), th_ee.reshape(-1), atol=1e-6)
+    assert os.path.exists(save + '.iter0') and os.path.exists(save + '.iter1')
+    mean_lp, counts = tt.predict()
+    tot, want_counts = oracle_pass(th_ee, th_ed, want_counts=True)
+    np.testing.assert_allclose(mean_lp, tot[9] / 24, rtol=1e-9)
+    assert counts == tuple(int(v) for v in want_counts)

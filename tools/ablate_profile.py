@@ -35,15 +35,17 @@ dev = torch.device('cuda:0')
 fb = FactorGraphBatch(topo, X, B, device=dev)
 fb.set_pair_tables(torch.rand(B * topo.P, X, X, dtype=torch.float64, device=dev) + 0.01)
 fb.set_unary_tables(torch.rand(B * topo.U, X, dtype=torch.float64, device=dev) + 0.01)
+marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)
 masks = [(0, 'full kernel'), (1, '- variable product'), (2, '- contraction (partials)'), (4, '- gather of partial sums'),
          (8, '- wave max / rescale key'), (15, '- all four (barrier kept)'), (16, '- barrier only (wrong results)'),
-         (32, '- whole op body')]
+         (1 << 9, '- hoisted unary normalisation'), (1 << 10, '- constant products'), (1 << 11, '- final normalisation pass'),
+         (1 << 12, '- marginal read-out'), (1 << 13, '- message write-back'), (15 | (31 << 9), '- all of the above')]
 times = {m: [] for m, _ in masks}
 for rnd in range(6):
     for m, _ in masks:
         ffi.check(ffi.lib.mlbp_debug_set_ablate_mask(m))
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record(); fb.sweep(roots, init=True); e.record(); torch.cuda.synchronize()
+        s.record(); fb.sweep(roots, init=True, marginals=marg); e.record(); torch.cuda.synchronize()
         if rnd:
             times[m].append(s.elapsed_time(e))
 if len(sys.argv) > 2:      # sweep-count scan of selected masks

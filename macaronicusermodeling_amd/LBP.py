@@ -197,32 +197,18 @@ class FactorGraph():
                  phi_en_en_w1,
                  phi_en_en,
                  phi_en_de):
-        self.theta_en_en = theta_en_en
-        self.theta_en_de = theta_en_de
-        self.theta_en_en_names = theta_en_en_names
-        self.theta_en_de_names = theta_en_de_names
-        self.phi_en_en = phi_en_en
-        self.phi_en_en_w1 = phi_en_en_w1
-        self.phi_en_de = phi_en_de
-        self.pot_en_en = None
-        self.pot_en_en_w1 = None
-        self.pot_en_de = None
-        self.variables = {}
-        self.factors = []
-        self.messages = {}
-        self.normalize_messages = True
-        self.isLoopy = None
-        self.regularization_param = 0.01
-        self.learning_rate = 0.1
-        self.report_times = False
-        self.bb_times = []
-        self.ub_times = []
-        self.it_times = []
-        self.gg_times = []
-        self.sgg_times = []
-        self.active_domains = {}
-        self.use_approx_inference = False
-        self.use_approx_beliefs = False
+        # caller-visible state, same names and defaults as LBP.py:28-57 (the reference's accidental
+        # 1-tuples around the *_names arguments are unwrapped there too, so plain lists are kept)
+        self.__dict__.update(
+            theta_en_en=theta_en_en, theta_en_de=theta_en_de,
+            theta_en_en_names=theta_en_en_names, theta_en_de_names=theta_en_de_names,
+            phi_en_en=phi_en_en, phi_en_en_w1=phi_en_en_w1, phi_en_de=phi_en_de,
+            pot_en_en=None, pot_en_en_w1=None, pot_en_de=None,
+            variables={}, factors=[], messages={}, active_domains={},
+            normalize_messages=True, isLoopy=None, regularization_param=0.01, learning_rate=0.1,
+            report_times=False, use_approx_inference=False, use_approx_beliefs=False)
+        for timer in ('bb_times', 'ub_times', 'it_times', 'gg_times', 'sgg_times'):
+            setattr(self, timer, [])
         self._engine = None
 
     def display_timing_info(self):
@@ -240,47 +226,45 @@ class FactorGraph():
 
     def get_precision_counts(self):
         """LBP.py:80-106."""
-        p_at_0 = p_at_25 = p_at_50 = totals = 0
-        for f in self.factors:
-            if f.factor_type == 'en_de':
-                sl, slp, prediction = f.varset[0].get_max_vocab(50)
-                totals += 1
-                for rank, (p_label, p_prob) in enumerate(prediction):
-                    if sl == p_label:
-                        if rank == 0:
-                            p_at_0 += 1; p_at_25 += 1; p_at_50 += 1
-                        elif rank < 26:
-                            p_at_25 += 1; p_at_50 += 1
-                        elif rank < 51:
-                            p_at_50 += 1
-        return p_at_0, p_at_25, p_at_50, totals
+        hits = [0, 0, 0]                                   # rank 0 / rank < 26 / rank < 51
+        totals = 0
+        for f in (f for f in self.factors if f.factor_type == 'en_de'):
+            label, _, ranked = f.varset[0].get_max_vocab(50)
+            totals += 1
+            for rank, (word, _) in enumerate(ranked):      # every occurrence counts, as in the reference
+                if word == label:
+                    for slot, limit in enumerate((1, 26, 51)):
+                        hits[slot] += rank < limit
+        return hits[0], hits[1], hits[2], totals
 
     def to_string(self):
         """LBP.py:109-123."""
-        position_factors = sorted([(f.position, f.id, f) for f in self.factors if f.position is not None])
-        fg_dct = {}
-        for p, _, f in position_factors:
+        lines = {}
+        for f in self._positioned():
             if f.factor_type == 'en_de':
-                sl, slp, pred = f.varset[0].get_max_vocab(50)
-                pred = ' '.join([p1 + ' ' + p2 for p1, p2 in pred])
-                fg_dct[p] = ' '.join([f.word_label, sl, slp, pred])
+                label, label_lp, ranked = f.varset[0].get_max_vocab(50)
+                lines[f.position] = ' '.join([f.word_label, label, label_lp] + [w + ' ' + lp for w, lp in ranked])
             if f.factor_type == 'en_en':
-                fg_dct[p] = ' '.join(['', f.word_label, ''])
-        return [fg_dct[k] for k in sorted(fg_dct)]
+                lines[f.position] = ' ' + f.word_label + ' '
+        return [lines[k] for k in sorted(lines)]
+
+    def _positioned(self):
+        """Factors that carry a sentence position, by (position, id) -- Python 3 cannot order
+        FactorNode objects the way LBP.py:110,127 relies on."""
+        return [f for _, _, f in sorted((f.position, f.id, f) for f in self.factors if f.position is not None)]
 
     def to_dist(self):
-        """LBP.py:125-143."""
-        factor_dist = []
-        position_factors = sorted([(f.position, f.id, f) for f in self.factors if f.position is not None])
-        for p, _, f in position_factors:
-            if f.factor_type == 'en_de':
-                v = f.varset[0]
-                truth = v.truth_label if v.truth_label is not None else 'None'
-                guess = v.supervised_label if v.supervised_label is not None else 'None'
-                logs = _dev_log(v.get_marginal().m)
-                i = ' '.join(['%0.6f' % x for x in logs.reshape(-1)])
-                factor_dist.append(' ||| '.join([truth, guess, i]))
-        return '\n'.join(factor_dist)
+        """LBP.py:125-143: `truth ||| guess ||| log-marginals (%0.6f)` per en_de factor."""
+        rows = []
+        for f in self._positioned():
+            if f.factor_type != 'en_de':
+                continue
+            v = f.varset[0]
+            logs = _dev_log(v.get_marginal().m).reshape(-1)
+            rows.append(' ||| '.join([v.truth_label if v.truth_label is not None else 'None',
+                                      v.supervised_label if v.supervised_label is not None else 'None',
+                                      ' '.join('%0.6f' % x for x in logs)]))
+        return '\n'.join(rows)
 
     def add_factor(self, fac):
         """LBP.py:145-153."""
@@ -492,18 +476,10 @@ class FactorNode():
 
     def __init__(self, id, factor_type=None, observed_domain_type=None, observed_value=None, observed_domain_size=None):
         if __debug__: assert isinstance(id, int)
-        self.id = id
-        self.varset = []
-        self.potential_table = None
-        self.factor_type = factor_type
-        self.graph = None
-        self.observed_domain_type = observed_domain_type
-        self.observed_value = observed_value
-        self.observed_domain_size = observed_domain_size
-        self.position = None
-        self.word_label = None
-        self.gap = None
-        self.connect_type = None
+        self.__dict__.update(id=id, varset=[], potential_table=None, factor_type=factor_type, graph=None,
+                             observed_domain_type=observed_domain_type, observed_value=observed_value,
+                             observed_domain_size=observed_domain_size,
+                             position=None, word_label=None, gap=None, connect_type=None)   # set by callers
 
     def __str__(self):
         return 'F_' + str(self.id)
@@ -533,42 +509,35 @@ class FactorNode():
         ptable.add_factor(self)
         self.potential_table = ptable
 
-    def get_pot(self):
-        """LBP.py:456-467."""
+    def _graph_level(self, prefix, distance_error, type_error):
+        """Which graph-level array this factor uses: en_en by word distance (gap > 1 / gap == 1),
+        en_de otherwise; anything else raises like LBP.py:456-480."""
         if self.factor_type == 'en_en':
             if self.gap > 1:
-                return self.graph.pot_en_en
-            elif self.gap == 1:
-                return self.graph.pot_en_en_w1
-            else:
-                raise BaseException("only 2 kinds of distances are supported ...")
-        elif self.factor_type == 'en_de':
-            return self.graph.pot_en_de
-        else:
-            raise BaseException("only two kinds of potentials are supported...")
+                return getattr(self.graph, prefix + '_en_en')
+            if self.gap == 1:
+                return getattr(self.graph, prefix + '_en_en_w1')
+            raise BaseException(distance_error)
+        if self.factor_type == 'en_de':
+            return getattr(self.graph, prefix + '_en_de')
+        raise BaseException(type_error)
+
+    def get_pot(self):
+        """LBP.py:456-467."""
+        return self._graph_level('pot', "only 2 kinds of distances are supported ...",
+                                 "only two kinds of potentials are supported...")
 
     def get_phi(self):
         """LBP.py:469-480."""
-        if self.factor_type == 'en_en':
-            if self.gap > 1:
-                return self.graph.phi_en_en
-            elif self.gap == 1:
-                return self.graph.phi_en_en_w1
-            else:
-                raise BaseException("only 2 distances supported at the moment")
-        elif self.factor_type == 'en_de':
-            return self.graph.phi_en_de
-        else:
-            raise BaseException("only 2 feature value types are supported right now..")
+        return self._graph_level('phi', "only 2 distances supported at the moment",
+                                 "only 2 feature value types are supported right now..")
 
     def get_shape(self):
         """LBP.py:482-488."""
-        if len(self.varset) == 1:
-            return len(self.varset[0].domain), self.observed_domain_size
-        elif len(self.varset) == 2:
-            return len(self.varset[0].domain), len(self.varset[1].domain)
-        else:
+        if len(self.varset) not in (1, 2):
             raise BaseException("only unary or binary factors are supported...")
+        rows = len(self.varset[0].domain)
+        return (rows, self.observed_domain_size) if len(self.varset) == 1 else (rows, len(self.varset[1].domain))
 
     def update_message_to(self, var):
         """LBP.py:490-526.  Exact: one device op (UNARY / PAIR_TM / PAIR_MT).  Approximate
@@ -597,32 +566,27 @@ class FactorNode():
 
     def get_factor_beliefs(self):
         """LBP.py:528-574."""
-        r = None
-        c = None
+        g = self.graph
+        t0 = time.time() if g.report_times else None
         if len(self.varset) == 1:
-            if self.graph.report_times: ub = time.time()
             beliefs = au.normalize(self.potential_table.table)
-            if self.graph.report_times: self.graph.ub_times.append(time.time() - ub)
+            if g.report_times: g.ub_times.append(time.time() - t0)
+            return beliefs
+        by_axis = {}
+        for v in self.varset:
+            axis = self.potential_table.var_id2dim[v.id]
+            if axis not in (0, 1):
+                raise NotImplementedError("only supports pairwise factors..")
+            by_axis[axis] = g.messages[str(v), str(self)].m
+        c = np.reshape(by_axis[0], (-1, 1))               # message of the dim-0 variable as a column
+        r = np.reshape(by_axis[1], (1, -1))               # message of the dim-1 variable as a row
+        if g.use_approx_beliefs:
+            outer, c_idx, r_idx = au.sparse_dot(c, r)
+            beliefs = au.sparse_normalize(au.sparse_pointwise_multiply(outer, c_idx, r_idx, self.potential_table.table),
+                                          c_idx, r_idx)
         else:
-            if self.graph.report_times: bb = time.time()
-            for v in self.varset:
-                vd = self.potential_table.var_id2dim[v.id]
-                m = self.graph.messages[str(v), str(self)]
-                if vd == 0:
-                    c = np.reshape(m.m, (np.size(m.m), 1))
-                elif vd == 1:
-                    r = np.reshape(m.m, (1, np.size(m.m)))
-                else:
-                    raise NotImplementedError("only supports pairwise factors..")
-            if self.graph.use_approx_beliefs:
-                approx_marginals, c_idx, r_idx = au.sparse_dot(c, r)
-                beliefs = au.sparse_pointwise_multiply(approx_marginals, c_idx, r_idx, self.potential_table.table)
-                beliefs = au.sparse_normalize(beliefs, c_idx, r_idx)
-            else:
-                marginals = au.dense_dot(c, r)
-                beliefs = au.dense_pointwise_multiply(marginals, self.potential_table.table)
-                beliefs = au.normalize(beliefs)
-            if self.graph.report_times: self.graph.bb_times.append(time.time() - bb)
+            beliefs = au.normalize(au.dense_pointwise_multiply(au.dense_dot(c, r), self.potential_table.table))
+        if g.report_times: g.bb_times.append(time.time() - t0)
         return beliefs
 
     def get_observed_factor_as_array(self):
@@ -720,35 +684,28 @@ class PotentialTable():
     """LBP.py:670-715 (host-side indexing only)."""
 
     def __init__(self, v_id2dim, table=None, observed_dim=None):
-        self.factor = None
-        self.observed_dim = observed_dim
-        self.var_id2dim = v_id2dim
-        if table is not None:
-            if __debug__: assert isinstance(table, np.ndarray)
-            if observed_dim is not None:
-                if __debug__: assert len(v_id2dim) == 1
-                if v_id2dim[list(v_id2dim.keys())[0]] == 0:
-                    self.table = np.reshape(table[:, observed_dim], (np.shape(table)[0], 1))
-                else:
-                    raise NotImplementedError("a unary factor should always be a column vector")
-            else:
-                self.table = table
-            if self.table.dtype != DTYPE:
-                self.table = self.table.astype(DTYPE)
-            if len(np.shape(self.table)) > 1:
-                if __debug__: assert np.shape(self.table)[0] == np.shape(self.table)[1] or np.shape(self.table)[1] == 1
+        self.factor, self.observed_dim, self.var_id2dim = None, observed_dim, v_id2dim
+        if table is None:
+            return                                          # filled later by slice_potentials()
+        if __debug__: assert isinstance(table, np.ndarray)
+        if observed_dim is not None:
+            if __debug__: assert len(v_id2dim) == 1
+            if next(iter(v_id2dim.values())) != 0:
+                raise NotImplementedError("a unary factor should always be a column vector")
+        self._adopt(table)
+
+    def _adopt(self, table):
+        """Common tail of the constructor and slice_potentials (LBP.py:678-691, 702-710): an observed
+        unary factor keeps one COLUMN as (X,1); tables are float64; square or column shaped."""
+        if self.observed_dim is not None:
+            table = np.reshape(table[:, self.observed_dim], (np.shape(table)[0], 1))
+        self.table = table if table.dtype == DTYPE else table.astype(DTYPE)
+        if self.table.ndim > 1:
+            if __debug__: assert self.table.shape[0] == self.table.shape[1] or self.table.shape[1] == 1
 
     def slice_potentials(self):
         """LBP.py:695-710: pairwise tables alias the graph-level pot array (no copy)."""
-        table = self.factor.get_pot()
-        table = np.reshape(table, self.factor.get_shape())
-        if self.observed_dim is not None:
-            table = np.reshape(table[:, self.observed_dim], (np.shape(table)[0], 1))
-        self.table = table
-        if self.table.dtype != DTYPE:
-            self.table = self.table.astype(DTYPE)
-        if len(np.shape(self.table)) > 1:
-            if __debug__: assert np.shape(self.table)[0] == np.shape(self.table)[1] or np.shape(self.table)[1] == 1
+        self._adopt(np.reshape(self.factor.get_pot(), self.factor.get_shape()))
 
     def add_factor(self, factor):
         if __debug__: assert isinstance(factor, FactorNode)

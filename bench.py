@@ -271,8 +271,9 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': ('sweep_x64_sf_kernel (timed region = hipMemsetAsync of the flag bytes + this kernel + the ~6 us fix-up '
-                                    'pass of sweep_x64_fused_kernel)') if X == 64 and a.variant in (None, 1) else
-                                   ('sweep_x64_fused_kernel' if X == 64 else 'sweep_generic_kernel'),
+                                    'pass of sweep_x64_fused_kernel)') if X == 64 and a.variant in (None, 1) and 1 <= topo.P <= 4 else
+                                   ('sweep_x64_fused_kernel' if X == 64 else
+                                    ('sweep_wide_kernel' if X in (128, 256, 512) else 'sweep_generic_kernel')),
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': avg_ms,
                          'min_launch_ms': sweep_ms[0], 'max_launch_ms': sweep_ms[-1]},
             'cpu_baseline': cpu,

@@ -112,6 +112,11 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
                         mlbp_program** out);
 int mlbp_program_destroy(mlbp_program* p);
 
+/* Pre-allocates the per-graph flag bytes the default X = 64 path needs for batches of up to
+ * max_graphs graphs, so that mlbp_sweep_f64 itself performs no allocation (stream capture).  Without
+ * it the first launch with a larger batch allocates. */
+int mlbp_program_reserve(mlbp_program* p, int32_t max_graphs);
+
 /* Attaches the variable read-out tables to a program so that mlbp_sweep_f64 can write the
  * variable marginals straight from the on-chip messages (mlbp_sweep_args.marginals): in_off
  * [n_vars+1] / in_slots are HOST arrays, variable v multiplies the messages in slots
@@ -234,6 +239,23 @@ typedef struct mlbp_gradient_args {
 } mlbp_gradient_args;
 int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream);
 int mlbp_gradient_status(void); /* synchronising read-and-reset: 1 = some factor was skipped        */
+
+/* Per-instance sparse feature planes (train_mp.py:178-217: 'correct', 'full_history', 'hit_history'
+ * are written into phi_en_de per instance and are non-zero in a few cells).  Row r of `out` becomes a
+ * private copy of base table row base_row[r] with
+ *     out[r][x] = base[x] * exp( sum over items q of row r with item_x[q] == x of theta[item_k[q]] * item_val[q] )
+ * items of row r are item_off[r] .. item_off[r+1].  All index arrays are DEVICE arrays the caller has
+ * range-checked (base_row < rows of base_tables, item_x < X, item_k < length of theta). */
+int mlbp_patch_unary_tables_f64(const double* base_tables, const int32_t* base_row, const int32_t* item_off,
+                                const int32_t* item_x, const int32_t* item_k, const double* item_val,
+                                const double* theta, int32_t n_rows, int32_t X, double* out, void* stream);
+
+/* Gradient share of those cells, ADDED to grad[row_graph[r]][item_k]:
+ *     val * ( [item_x == row_label[r]] - t[item_x] / sum(t) ),   t = private row r
+ * (FactorNode.get_gradient on the patched cells, LBP.py:600-603).  grad: device [B][F]. */
+int mlbp_patch_gradient_f64(const double* priv_tables, const int32_t* item_off, const int32_t* item_x,
+                            const int32_t* item_k, const double* item_val, const int32_t* row_graph,
+                            const int32_t* row_label, int32_t n_rows, int32_t X, int32_t F, double* grad, void* stream);
 
 /* out[j] = sum over rows of in[rows][cols], fixed summation order (bitwise reproducible): the
  * device half of batch_sgd_accumulate (train_mp.py:405-424). */

@@ -62,6 +62,7 @@ SIGNATURES = {
     'mlbp_program_create': (C.c_int, [_i32p, _i32, _i32p, _i32, _i32p, _i32, _i32, _i32, _i32,
                                       C.POINTER(_vp)]),
     'mlbp_program_destroy': (C.c_int, [_vp]),
+    'mlbp_program_reserve': (C.c_int, [_vp, _i32]),
     'mlbp_program_set_readout': (C.c_int, [_vp, _i32, _i32p, _i32p]),
     'mlbp_program_exact_count': (C.c_int, [_vp, _i32]),
     'mlbp_program_status': (C.c_int, [_vp]),
@@ -73,6 +74,8 @@ SIGNATURES = {
     'mlbp_pair_beliefs_f64': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     'mlbp_gradient_f64': (C.c_int, [C.POINTER(GradientArgs), _vp]),
     'mlbp_gradient_status': (C.c_int, []),
+    'mlbp_patch_unary_tables_f64': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    'mlbp_patch_gradient_f64': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     'mlbp_sum_rows_f64': (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     'mlbp_dense_dot_f64': (C.c_int, [_i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _vp, _i64, _i64,
                                      _i64, _vp, _i64, _i64, _vp]),

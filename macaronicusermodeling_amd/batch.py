@@ -27,7 +27,7 @@ def _stream_ptr(device):
 class Program:
     """Validated device-resident op list for one root sequence (mlbp_program_create)."""
 
-    def __init__(self, topo, roots):
+    def __init__(self, topo, roots, max_graphs=0):
         self.roots = tuple(int(r) for r in roots)
         ops, srcs, sweeps = topo.compile_program(self.roots)
         self.n_ops = len(ops)
@@ -41,6 +41,8 @@ class Program:
                                                 C.byref(h)))
         self.handle = h
         _ffi.check(_ffi.lib.mlbp_program_set_readout(h, topo.n_vars, _ffi.i32ptr(topo.in_off), _ffi.i32ptr(topo.in_slots)))
+        if max_graphs > 0:
+            _ffi.check(_ffi.lib.mlbp_program_reserve(h, int(max_graphs)))
 
     def status(self):
         return _ffi.check(_ffi.lib.mlbp_program_status(self.handle))
@@ -51,8 +53,9 @@ class Program:
 
     def __del__(self):
         h = getattr(self, 'handle', None)
-        if h is not None and h.value:
-            _ffi.lib.mlbp_program_destroy(h)
+        lib = getattr(_ffi, 'lib', None) if _ffi is not None else None      # module may be gone at interpreter exit
+        if h is not None and h.value and lib is not None:
+            lib.mlbp_program_destroy(h)
             self.handle = None
 
 
@@ -116,7 +119,7 @@ class FactorGraphBatch:
     def program(self, roots):
         key = tuple(int(r) for r in roots)
         if key not in self._programs:
-            self._programs[key] = Program(self.topo, key)
+            self._programs[key] = Program(self.topo, key, max_graphs=self.B)
         return self._programs[key]
 
     def sweep(self, roots, init=False, marginals=None):

@@ -223,6 +223,49 @@ __global__ __launch_bounds__(WG) void sum_rows_kernel(const double* in, int64_t 
   }
 }
 
+
+// ---- per-instance sparse feature planes (train_mp.py:178-217) ---------------------------------------
+// The reference rewrites three planes of phi_en_de per instance ('correct', 'full_history',
+// 'hit_history'); they are non-zero in a handful of cells.  Only cells in the observed column of one
+// of the instance's predicted words reach the graph, so each affected (instance, en_de factor) gets a
+// PRIVATE copy of its table row:  t[x] = base[x] * exp(sum_items theta[k] * val)   (one wave per row).
+__global__ __launch_bounds__(64) void patch_tables_kernel(const double* base_tables, const int32_t* base_row,
+                                                          const int32_t* item_off, const int32_t* item_x,
+                                                          const int32_t* item_k, const double* item_val,
+                                                          const double* theta, int X, double* out) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const double* b = base_tables + (size_t)base_row[r] * X;
+  double* o = out + (size_t)r * X;
+  for (int x = lane; x < X; x += 64) {
+    double e = 0.0;
+    for (int q = item_off[r]; q < item_off[r + 1]; ++q)
+      if (item_x[q] == x) e += theta[item_k[q]] * item_val[q];
+    o[x] = b[x] * exp(e);
+  }
+}
+
+// Their gradient share: for every item (x, k, val) of a private row
+//   grad_en_de[graph][k] += val * ( [x == label] - t[x] / sum(t) )       (LBP.py:600-603 on those cells)
+__global__ __launch_bounds__(64) void patch_gradient_kernel(const double* priv_tables, const int32_t* item_off,
+                                                            const int32_t* item_x, const int32_t* item_k,
+                                                            const double* item_val, const int32_t* row_graph,
+                                                            const int32_t* row_label, int X, int F, double* grad) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const double* t = priv_tables + (size_t)r * X;
+  double part = 0.0;
+  for (int x = lane; x < X; x += 64) part += t[x];
+  const double Z = wave_sum(part);
+  if (lane == 0) {
+    const int lab = row_label[r];
+    double* g = grad + (size_t)row_graph[r] * F;
+    for (int q = item_off[r]; q < item_off[r + 1]; ++q) {
+      const int x = item_x[q];
+      const double belief = Z > 0.0 ? t[x] / Z : 0.0;
+      atomicAdd(&g[item_k[q]], item_val[q] * ((x == lab ? 1.0 : 0.0) - belief));
+    }
+  }
+}
+
 int32_t* g_status = nullptr;
 int status_word(int32_t** out) {
   if (!g_status) {
@@ -289,6 +332,31 @@ int mlbp_sum_rows_f64(const double* in, int64_t rows, int32_t cols, double* out,
   if (!in || !out || rows <= 0 || cols <= 0) return fail(MLBP_EINVAL, "mlbp_sum_rows_f64: bad arguments");
   if (int e = need_device()) return e;
   hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(WG), 0, (hipStream_t)stream, in, rows, cols, out);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_patch_unary_tables_f64(const double* base_tables, const int32_t* base_row, const int32_t* item_off,
+                                const int32_t* item_x, const int32_t* item_k, const double* item_val,
+                                const double* theta, int32_t n_rows, int32_t X, double* out, void* stream) {
+  if (!base_tables || !base_row || !item_off || !item_x || !item_k || !item_val || !theta || !out || n_rows <= 0 || X <= 0)
+    return fail(MLBP_EINVAL, "mlbp_patch_unary_tables_f64: bad arguments");
+  if (int e = need_device()) return e;
+  hipLaunchKernelGGL(patch_tables_kernel, dim3(n_rows), dim3(64), 0, (hipStream_t)stream, base_tables, base_row, item_off,
+                     item_x, item_k, item_val, theta, X, out);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_patch_gradient_f64(const double* priv_tables, const int32_t* item_off, const int32_t* item_x,
+                            const int32_t* item_k, const double* item_val, const int32_t* row_graph,
+                            const int32_t* row_label, int32_t n_rows, int32_t X, int32_t F, double* grad, void* stream) {
+  if (!priv_tables || !item_off || !item_x || !item_k || !item_val || !row_graph || !row_label || !grad || n_rows <= 0 ||
+      X <= 0 || F <= 0)
+    return fail(MLBP_EINVAL, "mlbp_patch_gradient_f64: bad arguments");
+  if (int e = need_device()) return e;
+  hipLaunchKernelGGL(patch_gradient_kernel, dim3(n_rows), dim3(64), 0, (hipStream_t)stream, priv_tables, item_off, item_x,
+                     item_k, item_val, row_graph, row_label, X, F, grad);
   HIP_TRY(hipGetLastError());
   return MLBP_OK;
 }

@@ -18,6 +18,7 @@
 
 #include <cfloat>
 #include <cstdlib>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -1331,6 +1332,8 @@ int sweep_variant() {
 // granted per kernel and only call again when a launch needs more.
 int ensure_dynamic_lds(const void* fn, size_t bytes) {
   static std::vector<std::pair<const void*, size_t>> granted;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   for (auto& g : granted)
     if (g.first == fn) {
       if (g.second >= bytes) return MLBP_OK;
@@ -1523,12 +1526,8 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       mlbp_program* mp = const_cast<mlbp_program*>(prog);
       if (norm) d.marginals = a->marginals;         // read-out fused into the kernels' epilogue
       if (want_sf) {
-        if (mp->bail_cap < a->B) {            // grows only when a larger batch is seen
-          (void)hipFree(mp->d_bail);
-          mp->d_bail = nullptr;
-          HIP_TRY(hipMalloc(&mp->d_bail, (size_t)a->B));
-          mp->bail_cap = a->B;
-        }
+        if (mp->bail_cap < a->B)              // not reserved for this batch size: allocate now (a stream-
+          if (int e = mlbp_program_reserve(mp, a->B)) return e;   // capturing caller reserves up front instead)
         HIP_TRY(hipMemsetAsync(mp->d_bail, 0, (size_t)a->B, st));
         ScaleFreeDev sf;
         sf.image = prog->d_fops; sf.fsweeps = prog->d_fsweeps; sf.bail = mp->d_bail;
@@ -1634,6 +1633,17 @@ int mlbp_debug_set_stamp_buffer(void* dev_ptr) {
   return MLBP_OK;
 }
 #endif
+
+int mlbp_program_reserve(mlbp_program* p, int32_t max_graphs) {
+  if (!p || max_graphs <= 0) return fail(MLBP_EINVAL, "mlbp_program_reserve: bad arguments");
+  if (p->bail_cap >= max_graphs) return MLBP_OK;
+  (void)hipFree(p->d_bail);
+  p->d_bail = nullptr;
+  p->bail_cap = 0;
+  HIP_TRY(hipMalloc(&p->d_bail, (size_t)max_graphs));
+  p->bail_cap = max_graphs;
+  return MLBP_OK;
+}
 
 int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_off, const int32_t* in_slots) {
   if (!p || n_vars <= 0 || !in_off || !in_slots) return fail(MLBP_EINVAL, "mlbp_program_set_readout: bad arguments");

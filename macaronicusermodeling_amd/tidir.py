@@ -14,8 +14,8 @@
 
 A synthetic TI_DIR generator with the same schema stands in for the reference's data, which is not in
 its repository (README:3).  The per-instance feature planes `correct` / `full_history` /
-`hit_history` (train_mp.py:178-217) are parsed into sparse (i, j, value) lists per instance; the
-batched trainer does not consume them yet.
+`hit_history` (train_mp.py:178-217) are parsed into sparse (i, j, value) lists per instance and applied
+by the batched trainer through private table rows (mlbp_patch_unary_tables_f64 / mlbp_patch_gradient_f64).
 """
 import codecs
 import json
@@ -262,7 +262,15 @@ def synthesize(directory, n_instances=64, X=64, Vde=64, sent_len=(6, 10), n_pred
                                      lang='en'))
             past = [dict(id=[s, 100 + k], guess=en[int(rs.randint(X))], revealed=False, l2_word=de[int(rs.randint(Vde))],
                          reference=None) for k in range(int(rs.randint(0, 3)))]
+            tried = []
+            for g in guesses:                  # history that concerns words of THIS sentence (reaches the graph)
+                if rs.rand() < 0.5:
+                    past.append(dict(id=[s, 200 + len(past)], guess=en[int(rs.randint(X))], revealed=False,
+                                     l2_word=g['l2_word'], reference=None))
+                if rs.rand() < 0.5:
+                    tried.append(dict(id=g['id'], guess=en[int(rs.randint(X))], revealed=bool(rs.rand() < 0.2),
+                                      l2_word=g['l2_word'], reference=g['reference']))
             f.write(json.dumps(dict(user_id='u%d' % int(rs.randint(5)), past_correct_guesses=past, past_sentences_seen=[],
-                                    past_guesses_for_current_sent=[], current_sent=sent,
+                                    past_guesses_for_current_sent=tried, current_sent=sent,
                                     current_revealed_guesses=revealed, current_guesses=guesses)) + '\n')
     return paths

@@ -29,9 +29,12 @@ from .topology import GraphTopology
 
 class UserGraphTrainer:
     def __init__(self, spec, var_labels, unary_obs, phi_en_en, phi_en_en_w1, phi_en_de, theta_en_en, theta_en_de,
-                 device='cuda:0', sweeps=3, roots=None):
+                 device='cuda:0', sweeps=3, roots=None, planes=None):
         """spec: a 'trainmp'-style spec (tests/golden/cases.py: factors carry factor_type / gap);
-        var_labels [B][n_vars], unary_obs [B][U]: this rank's shard of instances."""
+        var_labels [B][n_vars], unary_obs [B][U]: this rank's shard of instances.
+        planes: optional per-instance sparse feature planes, a list (one entry per instance) of
+        {(i, j, k): value} -- cell (i, j) of phi_en_de[:, :, k] for this instance only
+        (train_mp.py:178-217 writes k = 2 'correct', 3 'full_history', 4 'hit_history')."""
         self.spec = spec
         self.topo = topo = GraphTopology.from_spec(spec)
         by_id = {f['id']: f for f in spec['factors']}
@@ -65,13 +68,19 @@ class UserGraphTrainer:
             torch.as_tensor(np.asarray(theta_en_de, dtype=np.float64).reshape(-1)).to(dev)
         # pots: [pot_en_en, pot_en_en_w1] as pairwise tables; their transposes + pot_en_de^T as unary rows
         self.pair_tables = torch.empty(2, X, X, dtype=torch.float64, device=dev)
-        self.unary_tables = torch.empty(2 * X + self.Vde, X, dtype=torch.float64, device=dev)
+        obs_np = np.asarray(unary_obs, dtype=np.int64).reshape(B, topo.U)
+        self._plan_patches(planes, unary_kind, obs_np, np.asarray(var_labels, dtype=np.int64).reshape(B, topo.n_vars))
+        self.n_shared_rows = 2 * X + self.Vde
+        self.unary_tables = torch.empty(self.n_shared_rows + self.n_priv, X, dtype=torch.float64, device=dev)
         fb.pair_tables = self.pair_tables
         fb.pair_tab = torch.from_numpy(np.tile(np.array(pair_phi or [0], dtype=np.int32), (B, 1))).to(dev)
-        obs = np.asarray(unary_obs, dtype=np.int64).reshape(B, topo.U)
+        obs = obs_np
         base = np.array([0, X, 2 * X], dtype=np.int64)[np.array(unary_kind, dtype=np.int64)] if topo.U else np.zeros(0)
         fb.unary_tables = self.unary_tables
-        fb.unary_tab = torch.from_numpy((obs + base[None, :]).astype(np.int32)).to(dev)
+        utab = obs + base[None, :]
+        for r, (b_i, u) in enumerate(self._priv_rows):          # patched factors read their private row
+            utab[b_i, u] = self.n_shared_rows + r
+        fb.unary_tab = torch.from_numpy(utab.astype(np.int32)).to(dev)
         self.sweeps = int(sweeps)
         self.roots = list(roots) if roots is not None else [topo.var_ids[i % topo.n_vars] for i in range(self.sweeps)]
         fb.is_loopy = topo.has_loops(self.roots[0])
@@ -83,6 +92,52 @@ class UserGraphTrainer:
         self._rows = torch.empty(B, self.F_ee + self.F_ed + 2, dtype=torch.float64, device=dev)
         self.stats = torch.zeros(self.F_ee + self.F_ed + 2, dtype=torch.float64, device=dev)
 
+    def _plan_patches(self, planes, unary_kind, obs, labels):
+        """Host-side integer work: which (instance, en_de factor) pairs see a plane cell in their
+        observed column, and the CSR item lists the two patch kernels consume."""
+        topo, X = self.topo, self.spec['X']
+        rows, off, ix, ik, iv, rgraph, rlabel, rbase = [], [0], [], [], [], [], [], []
+        if planes is not None:
+            ed_slots = [u for u in range(topo.U) if unary_kind[u] == 2]
+            for b_i, cells in enumerate(planes):
+                if not cells:
+                    continue
+                for u in ed_slots:
+                    col = int(obs[b_i, u])
+                    items = [(i, k, v) for (i, j, k), v in sorted(cells.items()) if j == col and v != 0.0]
+                    if not items:
+                        continue
+                    for i, k, v in items:
+                        if not (0 <= i < X and 0 <= k < self.F_ed):
+                            raise IndexError('feature-plane cell out of range')
+                        ix.append(i); ik.append(k); iv.append(float(v))
+                    rows.append((b_i, u)); off.append(len(ix))
+                    rgraph.append(b_i); rbase.append(2 * X + col)
+                    rlabel.append(int(labels[b_i, topo.fac_var[2 * topo.unary_factors[u]]]))
+        self._priv_rows, self.n_priv = rows, len(rows)
+        if self.n_priv:
+            dev = self.device
+            as_i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)          # noqa: E731
+            self._p_off, self._p_x, self._p_k = as_i32(off), as_i32(ix), as_i32(ik)
+            self._p_val = torch.tensor(iv, dtype=torch.float64, device=dev)
+            self._p_graph, self._p_label, self._p_base = as_i32(rgraph), as_i32(rlabel), as_i32(rbase)
+
+    def _patch_tables(self):
+        if self.n_priv:
+            priv = self.unary_tables[self.n_shared_rows:]
+            _ffi.check(_ffi.lib.mlbp_patch_unary_tables_f64(
+                self.unary_tables.data_ptr(), self._p_base.data_ptr(), self._p_off.data_ptr(), self._p_x.data_ptr(),
+                self._p_k.data_ptr(), self._p_val.data_ptr(), self.theta_en_de.data_ptr(), self.n_priv, self.spec['X'],
+                priv.data_ptr(), _stream_ptr(self.device)))
+
+    def _patch_gradient(self):
+        if self.n_priv:
+            priv = self.unary_tables[self.n_shared_rows:]
+            _ffi.check(_ffi.lib.mlbp_patch_gradient_f64(
+                priv.data_ptr(), self._p_off.data_ptr(), self._p_x.data_ptr(), self._p_k.data_ptr(), self._p_val.data_ptr(),
+                self._p_graph.data_ptr(), self._p_label.data_ptr(), self.n_priv, self.spec['X'], self.F_ed,
+                self._g_ed.data_ptr(), _stream_ptr(self.device)))
+
     def build_potentials(self):
         fb, X, st = self.batch, self.spec['X'], _stream_ptr(self.device)
         ut = self.unary_tables
@@ -92,6 +147,7 @@ class UserGraphTrainer:
                                                 self.pair_tables[1].data_ptr(), ut[X:2 * X].data_ptr(), st))
         _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_de.data_ptr(), self.theta_en_de.data_ptr(), X, self.Vde,
                                                 self.F_ed, None, ut[2 * X:].data_ptr(), st))
+        self._patch_tables()
 
     def local_statistics(self):
         """Runs inference on this rank's shard and returns the fused statistics buffer (device):
@@ -100,6 +156,7 @@ class UserGraphTrainer:
         self.build_potentials()
         fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg)
         fb.gradient(self._g_ee, self._g_ed)
+        self._patch_gradient()
         _ffi.check(_ffi.lib.mlbp_log_posterior_f64(self._marg.data_ptr(), fb._labels.data_ptr(), fb.B, self.topo.n_vars,
                                                    fb.X, self._lp.data_ptr(), _stream_ptr(self.device)))
         r = self._rows
@@ -162,7 +219,7 @@ class TiDirTrainer:
     params written in the reference's text format."""
 
     def __init__(self, ti_path, en_vocab, de_vocab, phi_pmi, phi_pmi_w1, phi_ed, phi_ped, device='cuda:0', sweeps=3,
-                 rank=0, world=1):
+                 rank=0, world=1, use_planes=True):
         from . import tidir
         self.en, self.de = tidir.read_vocab(en_vocab), tidir.read_vocab(de_vocab)
         phi_ee, phi_w1, phi_ed_t = tidir.load_features(phi_pmi, phi_pmi_w1, phi_ed, phi_ped)
@@ -176,8 +233,20 @@ class TiDirTrainer:
         self.trainers = {}
         for key, b in sorted(self.buckets.items()):
             roots = [key[1][i % len(key[1])] for i in range(sweeps)]
+            planes = None
+            if use_planes:
+                feat = {'correct': tidir.ED_NAMES.index('correct'), 'full_history': tidir.ED_NAMES.index('full_history'),
+                        'hit_history': tidir.ED_NAMES.index('hit_history')}
+                planes = []
+                for r in b['rows']:
+                    cells = {}
+                    for name, k in feat.items():
+                        for i, j, v in r['planes'][name]:
+                            cells[(i, j, k)] = cells.get((i, j, k), 0.0) + v      # the reference accumulates (+=)
+                    planes.append(cells)
             self.trainers[key] = UserGraphTrainer(b['spec'], b['var_labels'], b['unary_obs'], phi_ee, phi_w1, phi_ed_t,
-                                                  self.theta_en_en, self.theta_en_de, device=device, sweeps=sweeps, roots=roots)
+                                                  self.theta_en_en, self.theta_en_de, device=device, sweeps=sweeps, roots=roots,
+                                                  planes=planes)
         self.stats = torch.zeros(len(tidir.EE_NAMES) + len(tidir.ED_NAMES) + 2, dtype=torch.float64, device=dev)
 
     def epoch(self, learning_rate, reg_param):

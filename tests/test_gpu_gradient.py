@@ -200,11 +200,11 @@ def test_tidir_trainer_epochs_and_predictions(tmp_path):
     phi_ee, phi_w1, phi_ed = tidir.load_features(paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'], paths['phi_ped'])
     th_ee, th_ed = np.zeros((1, 3)), np.zeros((1, 6))
 
+    feat = {'correct': 2, 'full_history': 3, 'hit_history': 4}
+
     def oracle_pass(th_ee, th_ed, want_counts=False):
-        inputs = dict(phi_en_en=phi_ee, phi_en_en_w1=phi_w1, phi_en_de=phi_ed, theta_en_en=th_ee, theta_en_de=th_ed,
-                      pot_en_en=np.exp(phi_ee.dot(th_ee.T).reshape(64, 64)), pot_en_en_w1=np.exp(phi_w1.dot(th_ee.T).reshape(64, 64)),
-                      pot_en_de=np.exp(phi_ed.dot(th_ed.T).reshape(64, 64)))
-        tot = np.zeros(11); counts = np.zeros(4, dtype=np.int64)
+        pot_ee = np.exp(phi_ee.dot(th_ee.T).reshape(64, 64)); pot_w1 = np.exp(phi_w1.dot(th_ee.T).reshape(64, 64))
+        tot = np.zeros(11); counts = np.zeros(4, dtype=np.int64); n_cells = 0
         for key, b in sorted(tt.buckets.items()):
             unary = [f for f in sorted(b['spec']['factors'], key=lambda f: f['id']) if len(f['vars']) == 1]
             roots = [key[1][i % len(key[1])] for i in range(3)]
@@ -213,12 +213,22 @@ def test_tidir_trainer_epochs_and_predictions(tmp_path):
                 s['labels'] = [int(v) for v in b['var_labels'][i]]
                 for u, f in enumerate(unary):
                     s['factors'][f['id']]['observed_dim'] = int(b['unary_obs'][i, u])
+                # the reference writes the three planes into phi_en_de for this instance (train_mp.py:178-217)
+                phi_i = phi_ed.copy()
+                for name, k in feat.items():
+                    plane = np.zeros((64, 64))
+                    for ci, cj, cv in b['rows'][i]['planes'][name]:
+                        plane[ci, cj] += cv; n_cells += 1
+                    phi_i[:, :, k] = plane
+                inputs = dict(phi_en_en=phi_ee, phi_en_en_w1=phi_w1, phi_en_de=phi_i, theta_en_en=th_ee, theta_en_de=th_ed,
+                              pot_en_en=pot_ee, pot_en_en_w1=pot_w1, pot_en_de=np.exp(phi_i.dot(th_ed.T).reshape(64, 64)))
                 g = O.Graph(s); msgs = O.init_messages(g)
                 O.treelike_inference(g, inputs, msgs, 3, roots, O.has_loops(g, roots[0]))
                 ee, ed = O.unregularized_gradient(g, inputs, msgs)
                 tot[:3] += ee.reshape(-1); tot[3:9] += ed.reshape(-1); tot[9] += O.log_posterior(g, msgs); tot[10] += 1
                 if want_counts:
                     counts += np.array(O.precision_counts(g, msgs))
+        assert n_cells > 0
         return tot, counts
     for epoch in range(2):
         lr, reg = 0.1 / (1 + 0.3 * epoch), 0.2 / 24
@@ -228,6 +238,7 @@ def test_tidir_trainer_epochs_and_predictions(tmp_path):
         th_ed = th_ed + lr * (tot[3:9] - 24 * reg * th_ed)
     np.testing.assert_allclose(tt.theta_en_en.cpu().numpy(), th_ee.reshape(-1), rtol=1e-8, atol=1e-11)
     np.testing.assert_allclose(tt.theta_en_de.cpu().numpy(), th_ed.reshape(-1), rtol=1e-8, atol=1e-11)
+    assert sum(tr.n_priv for tr in tt.trainers.values()) > 0 and abs(th_ed[0, 2]) > 0     # the planes were live
     een, eet, edn, edt, _ = tidir.read_params(save)
     np.testing.assert_allclose(eet.reshape(-1), th_ee.reshape(-1), atol=1e-6)
     assert os.path.exists(save + '.iter0') and os.path.exists(save + '.iter1')

@@ -144,6 +144,8 @@ int mlbp_program_status(const mlbp_program* p);
  * (LBP.py:649-657), au.dense_dot / au.normalize / au.pointwise_multiply
  * (c_array_utils.pyx:90-91, 29-40, 12-16).
  * ------------------------------------------------------------------------------------------- */
+struct mlbp_gradient_args;   /* defined below */
+
 typedef struct mlbp_sweep_args {
   int32_t B;                  /* graphs                                                           */
   int32_t X;                  /* states per variable (len(v.domain))                              */
@@ -160,6 +162,13 @@ typedef struct mlbp_sweep_args {
   double* marginals;          /* device [B][n_vars][X] or NULL: VariableNode.get_marginal of every
                                  variable after the last sweep (LBP.py:392-400), read out in the same
                                  launch; needs mlbp_program_set_readout                              */
+  const struct mlbp_gradient_args* gradient;
+                              /* HOST pointer or NULL: when set, the per-graph gradients of
+                                 FactorGraph.get_unregularized_gradeint (LBP.py:301-320) are written
+                                 after the last sweep -- inside the same launch (tables still in
+                                 registers, messages in LDS) when X = 64, F = (3,6), at most 3
+                                 pairwise factors and the transposed feature tensors are given;
+                                 otherwise by mlbp_gradient_f64 enqueued behind the sweeps            */
 } mlbp_sweep_args;
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
@@ -234,6 +243,12 @@ typedef struct mlbp_gradient_args {
   const double* phi_en_en;      /* [X][X][F_ee]                                                     */
   const double* phi_en_en_w1;   /* [X][X][F_ee]                                                     */
   const double* phi_en_de;      /* [X][Vde][F_ed]                                                   */
+  const double* phi_en_en_t;    /* optional (may be NULL): the same tensors with the first two axes  */
+  const double* phi_en_en_w1_t; /* swapped, [column][x][F], so that a unary factor's feature column  */
+  const double* phi_en_de_t;    /* phi[:, observed_dim, :] (LBP.py:602) is one contiguous slab        */
+  const double* phi_en_en_p;    /* optional (may be NULL): feature-major ("planar") copies [F][X][X]  */
+  const double* phi_en_en_w1_p; /* of the two en_en tensors; a pairwise factor then reads each feature */
+                                /* plane with the same 16-byte-per-lane pattern as its table           */
   double* grad_en_en;           /* out [B][F_ee]                                                    */
   double* grad_en_de;           /* out [B][F_ed]                                                    */
 } mlbp_gradient_args;

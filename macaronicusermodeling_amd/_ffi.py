@@ -35,14 +35,16 @@ class GradientArgs(C.Structure):
                 ('pair_phi', C.c_void_p), ('pair_label', C.c_void_p), ('unary_tables', C.c_void_p),
                 ('unary_tab', C.c_void_p), ('unary_kind', C.c_void_p), ('unary_obs', C.c_void_p),
                 ('unary_label', C.c_void_p), ('phi_en_en', C.c_void_p), ('phi_en_en_w1', C.c_void_p),
-                ('phi_en_de', C.c_void_p), ('grad_en_en', C.c_void_p), ('grad_en_de', C.c_void_p)]
+                ('phi_en_de', C.c_void_p), ('phi_en_en_t', C.c_void_p), ('phi_en_en_w1_t', C.c_void_p),
+                ('phi_en_de_t', C.c_void_p), ('phi_en_en_p', C.c_void_p), ('phi_en_en_w1_p', C.c_void_p),
+                ('grad_en_en', C.c_void_p), ('grad_en_de', C.c_void_p)]
 
 
 class SweepArgs(C.Structure):
     _fields_ = [('B', C.c_int32), ('X', C.c_int32), ('n_pair_tables', C.c_int32),
                 ('n_unary_tables', C.c_int32), ('pair_tables', C.c_void_p), ('pair_tab', C.c_void_p),
                 ('unary_tables', C.c_void_p), ('unary_tab', C.c_void_p), ('msgs', C.c_void_p),
-                ('normalize_messages', C.c_int32), ('init_messages', C.c_int32), ('marginals', C.c_void_p)]
+                ('normalize_messages', C.c_int32), ('init_messages', C.c_int32), ('marginals', C.c_void_p), ('gradient', C.c_void_p)]
 
 
 _i32p = C.POINTER(C.c_int32)

@@ -122,11 +122,13 @@ class FactorGraphBatch:
             self._programs[key] = Program(self.topo, key, max_graphs=self.B)
         return self._programs[key]
 
-    def sweep(self, roots, init=False, marginals=None):
+    def sweep(self, roots, init=False, marginals=None, gradient=None):
         """Runs len(roots) sweeps, sweep s rooted at variable id roots[s], on every graph, in one
         launch.  init=True starts from uniform messages (initialize() fused into the launch);
         marginals: optional [B][n_vars][X] device tensor that receives every variable's marginal
-        after the last sweep, read out of the on-chip messages in the same launch."""
+        after the last sweep, read out of the on-chip messages in the same launch; gradient: optional
+        (out_ee [B][F_ee], out_ed [B][F_ed]) device tensors that receive the per-graph gradients
+        (set_features / set_observations first), fused into the launch when the kernel allows."""
         prog = self.program(roots)
         a = _ffi.SweepArgs()
         a.B, a.X = self.B, self.X
@@ -147,6 +149,9 @@ class FactorGraphBatch:
             if tuple(marginals.shape) != (self.B, self.topo.n_vars, self.X) or marginals.dtype != torch.float64:
                 raise ValueError('marginals must be float64 [B][n_vars][X]')
             a.marginals = marginals.data_ptr()
+        if gradient is not None:
+            ga = self._gradient_args(*gradient)
+            a.gradient = C.addressof(ga)
         _ffi.check(_ffi.lib.mlbp_sweep_f64(prog.handle, C.byref(a), _stream_ptr(self.device)))
         return prog
 
@@ -217,6 +222,9 @@ class FactorGraphBatch:
         self.phi_en_en = torch.as_tensor(phi_en_en, dtype=torch.float64).to(dev).contiguous()
         self.phi_en_en_w1 = torch.as_tensor(phi_en_en_w1, dtype=torch.float64).to(dev).contiguous()
         self.phi_en_de = torch.as_tensor(phi_en_de, dtype=torch.float64).to(dev).contiguous()
+        # transposed copies [column][x][F] (a layout change only): contiguous feature slabs for unary factors
+        self._phi_t = tuple(p.permute(1, 0, 2).contiguous() for p in (self.phi_en_en, self.phi_en_en_w1, self.phi_en_de))
+        self._phi_p = tuple(p.permute(2, 0, 1).contiguous() for p in (self.phi_en_en, self.phi_en_en_w1))   # [F][X][X]
         X = self.X
         if tuple(self.phi_en_en.shape[:2]) != (X, X) or self.phi_en_en_w1.shape != self.phi_en_en.shape or \
                 self.phi_en_de.shape[0] != X:
@@ -256,15 +264,11 @@ class FactorGraphBatch:
         self._unary_label = torch.from_numpy(ul).to(dev)
         self._unary_obs = torch.from_numpy(np.ascontiguousarray(obs if topo.U else np.zeros((B, 1))).astype(np.int32)).to(dev)
 
-    def gradient(self, out_ee=None, out_ed=None):
-        """Per-graph unregularised gradients ([B][F_ee], [B][F_ed]):
-        FactorGraph.get_unregularized_gradeint (LBP.py:301-320), beliefs fused in."""
+    def _gradient_args(self, out_ee, out_ed):
         topo = self.topo
         F_ee, F_ed = int(self.phi_en_en.shape[2]), int(self.phi_en_de.shape[2])
-        if out_ee is None:
-            out_ee = torch.empty(self.B, F_ee, dtype=torch.float64, device=self.device)
-        if out_ed is None:
-            out_ed = torch.empty(self.B, F_ed, dtype=torch.float64, device=self.device)
+        if tuple(out_ee.shape) != (self.B, F_ee) or tuple(out_ed.shape) != (self.B, F_ed):
+            raise ValueError('gradient outputs must be [B][F_ee] and [B][F_ed]')
         c, r = self._pair_slots()
         a = _ffi.GradientArgs()
         a.B, a.X, a.n_msgs, a.P, a.U = self.B, self.X, topo.n_msgs, topo.P, topo.U
@@ -282,7 +286,22 @@ class FactorGraphBatch:
             a.unary_label = self._unary_label.data_ptr()
         a.phi_en_en, a.phi_en_en_w1 = self.phi_en_en.data_ptr(), self.phi_en_en_w1.data_ptr()
         a.phi_en_de = self.phi_en_de.data_ptr()
+        a.phi_en_en_t, a.phi_en_en_w1_t, a.phi_en_de_t = (p.data_ptr() for p in self._phi_t)
+        if getattr(self, 'use_planar', True):
+            a.phi_en_en_p, a.phi_en_en_w1_p = (p.data_ptr() for p in self._phi_p)
         a.grad_en_en, a.grad_en_de = out_ee.data_ptr(), out_ed.data_ptr()
+        return a
+
+    def gradient(self, out_ee=None, out_ed=None):
+        """Per-graph unregularised gradients ([B][F_ee], [B][F_ed]) from the messages in memory:
+        FactorGraph.get_unregularized_gradeint (LBP.py:301-320), beliefs fused in.  (sweep(...,
+        gradient=(out_ee, out_ed)) produces the same numbers inside the sweep launch.)"""
+        F_ee, F_ed = int(self.phi_en_en.shape[2]), int(self.phi_en_de.shape[2])
+        if out_ee is None:
+            out_ee = torch.empty(self.B, F_ee, dtype=torch.float64, device=self.device)
+        if out_ed is None:
+            out_ed = torch.empty(self.B, F_ed, dtype=torch.float64, device=self.device)
+        a = self._gradient_args(out_ee, out_ed)
         _ffi.check(_ffi.lib.mlbp_gradient_f64(C.byref(a), _stream_ptr(self.device)))
         return out_ee, out_ed
 

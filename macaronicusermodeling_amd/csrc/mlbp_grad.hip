@@ -176,6 +176,130 @@ __global__ __launch_bounds__(WG) void gradient_kernel(GradDev d) {
   }
 }
 
+// ---- X = 64 specialisation ----------------------------------------------------------------------------
+// Same thread <-> table-element map as the sweep kernel (thread t: rows 8k + (t>>5), columns
+// 2(t&31), +1; every load instruction of the workgroup covers 4 KiB of the table).  The feature
+// tensor is read in the matching order: for one row and column pair the 2F feature values are
+// contiguous (2F*8 bytes per lane, consecutive lanes consecutive), so phi streams from L2 coalesced
+// while T streams from HBM.  Unary factors: one wave each, the table row (512 B) and -- when the
+// caller supplies the transposed feature tensors [column][x][F] -- a contiguous 64*F*8-byte slab of
+// phi; without them the strided column gather of the generic kernel is used.
+template <int F>
+__device__ __forceinline__ void pair_gradient_x64(const GradDev& d, int g, int p, double* scratch, double* out) {
+  const mlbp_gradient_args& a = d.a;
+  const int t = threadIdx.x, rg = t >> 5, cp = t & 31;
+  const int tab = a.pair_tab[(size_t)g * a.P + p];
+  const int l0 = a.pair_label[((size_t)g * a.P + p) * 2], l1 = a.pair_label[((size_t)g * a.P + p) * 2 + 1];
+  const bool ok = (unsigned)tab < (unsigned)a.n_pair_tables && (unsigned)l0 < 64u && (unsigned)l1 < 64u;
+  if (!ok) {
+    if (t == 0) atomicExch(d.status, 1);
+    return;
+  }
+  const double2* T = reinterpret_cast<const double2*>(a.pair_tables + (size_t)tab * 4096);
+  const double* phi = a.pair_phi[p] ? a.phi_en_en_w1 : a.phi_en_en;
+  const double* c = a.msgs + ((size_t)g * a.n_msgs + a.pair_c_slot[p]) * 64;
+  const double* r = a.msgs + ((size_t)g * a.n_msgs + a.pair_r_slot[p]) * 64;
+  double2 tv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) tv[k] = T[k * WG + t];
+  const double2 rj = reinterpret_cast<const double2*>(r)[cp];
+  const double* planar = a.pair_phi[p] ? a.phi_en_en_w1_p : a.phi_en_en_p;     // [F][64][64] or NULL
+  double acc[F + 1];
+#pragma unroll
+  for (int k = 0; k <= F; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = 8 * k + rg;
+    const double ci = c[i];
+    const double w0 = (ci * rj.x) * tv[k].x, w1 = (ci * rj.y) * tv[k].y;     // (c.r) * T, LBP.py:566-568
+    acc[0] += w0 + w1;
+    if (planar) {                                                            // table-like 16-byte-per-lane reads
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const double2 q = reinterpret_cast<const double2*>(planar)[f * 2048 + k * WG + t];
+        acc[1 + f] += w0 * q.x + w1 * q.y;
+      }
+    } else {
+      const double* ph = phi + ((size_t)i * 64 + 2 * cp) * F;                // 2F contiguous doubles
+#pragma unroll
+      for (int f = 0; f < F; ++f) acc[1 + f] += w0 * ph[f] + w1 * ph[F + f];
+    }
+  }
+  block_sums<F + 1>(acc, scratch);
+  const double Z = acc[0];
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    const double expect = Z > 0.0 ? acc[1 + f] / Z : 0.0;
+    out[f] += phi[((size_t)l0 * 64 + l1) * F + f] - expect;
+  }
+}
+
+template <int F>
+__device__ __forceinline__ void unary_gradient_x64(const GradDev& d, int g, int u, const double* phi, const double* phi_t,
+                                                   int cols, double* out) {
+  const mlbp_gradient_args& a = d.a;
+  const int lane = threadIdx.x & 63;
+  const int tab = a.unary_tab[(size_t)g * a.U + u];
+  const int obs = a.unary_obs[(size_t)g * a.U + u];
+  const int lab = a.unary_label[(size_t)g * a.U + u];
+  const bool ok = (unsigned)tab < (unsigned)a.n_unary_tables && (unsigned)obs < (unsigned)cols && (unsigned)lab < 64u;
+  if (!ok) {
+    if (lane == 0) atomicExch(d.status, 1);
+    return;
+  }
+  const double w = a.unary_tables[(size_t)tab * 64 + lane];
+  const double* ph = phi_t ? phi_t + ((size_t)obs * 64 + lane) * F : phi + ((size_t)lane * cols + obs) * F;
+  double acc[F + 1];
+  acc[0] = w;
+#pragma unroll
+  for (int f = 0; f < F; ++f) acc[1 + f] = w * ph[f];
+#pragma unroll
+  for (int f = 0; f <= F; ++f) acc[f] = wave_sum(acc[f]);
+  const double Z = acc[0];
+  const double* pl = phi_t ? phi_t + ((size_t)obs * 64 + lab) * F : phi + ((size_t)lab * cols + obs) * F;
+#pragma unroll
+  for (int f = 0; f < F; ++f) out[f] += pl[f] - (Z > 0.0 ? acc[1 + f] / Z : 0.0);
+}
+
+template <int FEE, int FED>
+__global__ __launch_bounds__(WG) void gradient_x64_kernel(GradDev d) {
+  __shared__ double scratch[4 * (FMAX + 1)];
+  __shared__ double wave_out[4][2 * FMAX];
+  const mlbp_gradient_args& a = d.a;
+  const int g = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double gee[FEE];
+#pragma unroll
+  for (int k = 0; k < FEE; ++k) gee[k] = 0.0;
+  for (int p = 0; p < a.P; ++p) pair_gradient_x64<FEE>(d, g, p, scratch, gee);
+  double uee[FEE], ued[FED];
+#pragma unroll
+  for (int k = 0; k < FEE; ++k) uee[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < FED; ++k) ued[k] = 0.0;
+  for (int u = wave; u < a.U; u += 4) {
+    const int kind = a.unary_kind[u];
+    if (kind == 2) unary_gradient_x64<FED>(d, g, u, a.phi_en_de, a.phi_en_de_t, a.Vde, ued);
+    else unary_gradient_x64<FEE>(d, g, u, kind ? a.phi_en_en_w1 : a.phi_en_en, kind ? a.phi_en_en_w1_t : a.phi_en_en_t, 64, uee);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < FEE; ++k) wave_out[wave][k] = uee[k];
+#pragma unroll
+    for (int k = 0; k < FED; ++k) wave_out[wave][FMAX + k] = ued[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < FEE; ++k)
+      a.grad_en_en[(size_t)g * FEE + k] = gee[k] + ((wave_out[0][k] + wave_out[1][k]) + (wave_out[2][k] + wave_out[3][k]));
+#pragma unroll
+    for (int k = 0; k < FED; ++k)
+      a.grad_en_de[(size_t)g * FED + k] =
+          (wave_out[0][FMAX + k] + wave_out[1][FMAX + k]) + (wave_out[2][FMAX + k] + wave_out[3][FMAX + k]);
+  }
+}
+
 // beliefs of every pairwise factor, materialised: out[b][p][i][j]
 __global__ __launch_bounds__(WG) void pair_beliefs_kernel(const double* msgs, int n_msgs, int X, int P,
                                                           const double* tables, const int32_t* pair_tab,
@@ -307,6 +431,13 @@ int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream) {
   d.a = *a;
   if (int e = status_word(&d.status)) return e;
   hipStream_t st = (hipStream_t)stream;
+  if (a->X == 64) {
+    if (a->F_ee == 3) hipLaunchKernelGGL((gradient_x64_kernel<3, 6>), dim3(a->B), dim3(WG), 0, st, d);
+    else if (a->F_ee == 2) hipLaunchKernelGGL((gradient_x64_kernel<2, 2>), dim3(a->B), dim3(WG), 0, st, d);
+    else hipLaunchKernelGGL((gradient_x64_kernel<1, 1>), dim3(a->B), dim3(WG), 0, st, d);
+    HIP_TRY(hipGetLastError());
+    return MLBP_OK;
+  }
   if (a->F_ee == 3) hipLaunchKernelGGL((gradient_kernel<3, 6>), dim3(a->B), dim3(WG), 0, st, d);
   else if (a->F_ee == 2) hipLaunchKernelGGL((gradient_kernel<2, 2>), dim3(a->B), dim3(WG), 0, st, d);
   else hipLaunchKernelGGL((gradient_kernel<1, 1>), dim3(a->B), dim3(WG), 0, st, d);

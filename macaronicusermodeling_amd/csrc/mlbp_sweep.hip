@@ -383,6 +383,145 @@ __device__ __forceinline__ void pair_partials(const double2 (&T)[8], const doubl
   }
 }
 
+// ---- gradient fused into the sweep epilogue (X = 64, F = (3, 6), tables resident) --------------------
+// After the last sweep the workgroup still holds what FactorGraph.get_unregularized_gradeint needs
+// (LBP.py:301-320): the pairwise tables in registers, the normalised messages in LDS -- and a unary
+// factor's normalised message IS its belief vector au.normalize(table) whenever the table's total is
+// positive (LBP.py:540 vs 494-498).  Only the shared feature tensors come from L2.  Saves the
+// standalone gradient kernel's second pass over every table in HBM.
+struct GradFusedDev {
+  const int32_t* pair_c_slot; const int32_t* pair_r_slot; const int32_t* pair_phi; const int32_t* pair_label;
+  const int32_t* unary_kind; const int32_t* unary_obs; const int32_t* unary_label;
+  const double* phi_en_en; const double* phi_en_en_w1;
+  const double* phi_en_en_t; const double* phi_en_en_w1_t; const double* phi_en_de_t;
+  double* grad_en_en; double* grad_en_de;
+  int32_t Vde, enabled;
+};
+
+// umsg[u] = message slot of unary slot u's factor->variable message, upos[u] = 1 when its table total
+// was positive (both filled in the prologue from the hoist list).  scratch: >= 4*24 doubles of LDS.
+template <int NT>
+__device__ __forceinline__ void gradient_epilogue_x64(const SweepDev& d, const GradFusedDev& gf, const double2 (&tab)[NT][8],
+                                                      const double* msg, const int32_t* umsg, const int32_t* upos,
+                                                      double* scratch, int g) {
+  const int32_t* ukind = upos + d.U;      // staged by the prologue right behind upos: kind, observed
+  const int32_t* uobs = ukind + d.U;      // column and label of every unary factor of this graph
+  const int32_t* ulab = uobs + d.U;
+  constexpr int FEE = 3, FED = 6;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, rg = t >> 5, cp = t & 31;
+  double pacc[NT][FEE + 1];
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+#pragma unroll
+    for (int f = 0; f <= FEE; ++f) pacc[p][f] = 0.0;
+    if (p < d.P) {
+      const double* c = msg + gf.pair_c_slot[p] * 64;
+      const double* r = msg + gf.pair_r_slot[p] * 64;
+      // interleaved [64][64][F] features: measured faster here than the planar copies the standalone
+      // gradient kernel prefers (0.517 vs 0.55 ms per fused launch, tools/time_train_step.py)
+      const double* phi = gf.pair_phi[p] ? gf.phi_en_en_w1 : gf.phi_en_en;
+      const double2 rj = reinterpret_cast<const double2*>(r)[cp];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double ci = c[8 * k + rg];
+        const double w0 = (ci * rj.x) * tab[p][k].x, w1 = (ci * rj.y) * tab[p][k].y;
+        pacc[p][0] += w0 + w1;
+        const double* ph = phi + ((size_t)(8 * k + rg) * 64 + 2 * cp) * FEE;
+#pragma unroll
+        for (int f = 0; f < FEE; ++f) pacc[p][1 + f] += w0 * ph[f] + w1 * ph[FEE + f];
+      }
+#pragma unroll
+      for (int f = 0; f <= FEE; ++f) pacc[p][f] = wave_sum(pacc[p][f]);
+    }
+  }
+  // unary factors: wave w takes slots w, w+4, ...; belief = normalised message (zero when the table
+  // total was <= 0).  kind / observed column / label were staged in LDS by the prologue; the feature
+  // slabs of a whole batch of factors are requested before the first reduction.
+  double uee[FEE] = {0.0, 0.0, 0.0}, ued[FED] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  bool bad = false;
+  constexpr int UB = 3;
+  for (int u0 = wave; u0 < d.U; u0 += 4 * UB) {
+    double b[UB], pv[UB][FED];
+    int kd[UB], at[UB];                       // kind and scalar offset of the label's feature row
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      const int u = u0 + 4 * j;
+      kd[j] = -1;
+      if (u < d.U) {
+        const int kind = __builtin_amdgcn_readfirstlane(ukind[u]), obs = __builtin_amdgcn_readfirstlane(uobs[u]);
+        const int lab = __builtin_amdgcn_readfirstlane(ulab[u]);
+        const int cols = kind == 2 ? gf.Vde : 64;
+        if ((unsigned)obs >= (unsigned)cols || (unsigned)lab >= 64u) { bad = true; continue; }
+        kd[j] = kind;
+        b[j] = upos[u] ? msg[umsg[u] * 64 + lane] : 0.0;
+        if (kind == 2) {
+          const double* ph = gf.phi_en_de_t + ((size_t)obs * 64 + lane) * FED;
+          at[j] = (obs * 64 + lab) * FED;
+#pragma unroll
+          for (int f = 0; f < FED; ++f) pv[j][f] = ph[f];
+        } else {
+          const double* ph = (kind ? gf.phi_en_en_w1_t : gf.phi_en_en_t) + ((size_t)obs * 64 + lane) * FEE;
+          at[j] = (obs * 64 + lab) * FEE;
+#pragma unroll
+          for (int f = 0; f < FEE; ++f) pv[j][f] = ph[f];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      if (kd[j] == 2) {
+#pragma unroll
+        for (int f = 0; f < FED; ++f) ued[f] += gf.phi_en_de_t[at[j] + f] - wave_sum(b[j] * pv[j][f]);
+      } else if (kd[j] >= 0) {
+        const double* base = kd[j] ? gf.phi_en_en_w1_t : gf.phi_en_en_t;
+#pragma unroll
+        for (int f = 0; f < FEE; ++f) uee[f] += base[at[j] + f] - wave_sum(b[j] * pv[j][f]);
+      }
+    }
+  }
+  if (bad && lane == 0) atomicExch(d.status, 1);
+  // combine the four waves: per wave NT*(FEE+1) pair sums + FEE + FED unary sums
+  constexpr int PER = NT * (FEE + 1) + FEE + FED;
+  if (lane == 0) {
+    double* o = scratch + wave * PER;
+#pragma unroll
+    for (int p = 0; p < NT; ++p)
+#pragma unroll
+      for (int f = 0; f <= FEE; ++f) o[p * (FEE + 1) + f] = pacc[p][f];
+#pragma unroll
+    for (int f = 0; f < FEE; ++f) o[NT * (FEE + 1) + f] = uee[f];
+#pragma unroll
+    for (int f = 0; f < FED; ++f) o[NT * (FEE + 1) + FEE + f] = ued[f];
+  }
+  wg_barrier();
+  if (t == 0) {
+    double tot[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) tot[q] = (scratch[q] + scratch[PER + q]) + (scratch[2 * PER + q] + scratch[3 * PER + q]);
+    double gee[FEE];
+#pragma unroll
+    for (int f = 0; f < FEE; ++f) gee[f] = tot[NT * (FEE + 1) + f];
+    bool lbad = false;
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+      if (p < d.P) {
+        const int l0 = gf.pair_label[((size_t)g * d.P + p) * 2], l1 = gf.pair_label[((size_t)g * d.P + p) * 2 + 1];
+        if ((unsigned)l0 >= 64u || (unsigned)l1 >= 64u) { lbad = true; continue; }
+        const double* phi = gf.pair_phi[p] ? gf.phi_en_en_w1 : gf.phi_en_en;
+        const double Z = tot[p * (FEE + 1)];
+#pragma unroll
+        for (int f = 0; f < FEE; ++f)
+          gee[f] += phi[((size_t)l0 * 64 + l1) * FEE + f] - (Z > 0.0 ? tot[p * (FEE + 1) + 1 + f] / Z : 0.0);
+      }
+    }
+    if (lbad) atomicExch(d.status, 1);
+#pragma unroll
+    for (int f = 0; f < FEE; ++f) gf.grad_en_en[(size_t)g * FEE + f] = gee[f];
+#pragma unroll
+    for (int f = 0; f < FED; ++f) gf.grad_en_de[(size_t)g * FED + f] = tot[NT * (FEE + 1) + FEE + f];
+  }
+}
+
 // Register budget: the resident tables take 32 VGPRs each; the waves-per-SIMD floor keeps the
 // allocator at 3 workgroups per CU with 3 resident tables (<= 168 VGPRs) and 4 otherwise (<= 128).
 //
@@ -394,8 +533,8 @@ __device__ __forceinline__ void pair_partials(const double2 (&T)[8], const doubl
 //   red   [8][64]           partial sums of the contraction
 //   prog  int32             fused op headers [n_fops][8], source lists, hoist / constant-product
 //                           lists, the graph's table indices
-template <bool NORM, int NT>
-__global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x64_fused_kernel(SweepDev d, FusedDev f) {
+template <bool NORM, int NT, bool GRAD>
+__global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x64_fused_kernel(SweepDev d, FusedDev f, GradFusedDev gf) {
   extern __shared__ double lds[];
   double* msg = lds;
   double* gin = lds + (size_t)(d.n_msgs + f.n_ext) * 64;
@@ -406,6 +545,8 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
   const int32_t* pcp = phoist + 2 * f.n_hoist;          // [n_cpw] constant-product lists: count, slots...
   int32_t* tabidx = const_cast<int32_t*>(pcp) + f.n_cpw;  // [P + U] this graph's table indices
   int32_t* flags = tabidx + d.P + d.U;                  // [0] = vector wave already stored the v->f message
+  int32_t* umsg = flags + 4;                            // [U] message slot of each unary factor's message
+  int32_t* upos = umsg + d.U;                           // [U] 1 when that factor's table total was positive
 
   STAMP_DECL
   ABLATE_DECL
@@ -438,6 +579,13 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
     }
     if (t < 32) dst[d.n_msgs * 32 + t] = make_double2(uniform, uniform);    // ext slot 0
     if (t == 0) flags[0] = 0;
+    if (GRAD)
+      for (int i = t; i < d.U; i += WG) {
+        umsg[i] = -1; upos[i] = 0;
+        upos[d.U + i] = gf.unary_kind[i];
+        upos[2 * d.U + i] = gf.unary_obs[(size_t)g * d.U + i];
+        upos[3 * d.U + i] = gf.unary_label[(size_t)g * d.U + i];
+      }
   }
   if (!__syncthreads_and(ok ? 1 : 0)) {       // an out-of-range table index: skip the graph, raise the status word
     if (t == 0) atomicExch(d.status, 1);
@@ -479,7 +627,11 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
 #pragma unroll
     for (int j = 0; j < HB; ++j) {
       const int h = h0 + 4 * j;
-      if (h < f.n_hoist) msg[phoist[2 * h + 1] * 64 + lane] = renorm(r[j], wave_sum(r[j]), uniform, NORM);
+      if (h < f.n_hoist) {
+        const double tot = wave_sum(r[j]);
+        msg[phoist[2 * h + 1] * 64 + lane] = renorm(r[j], tot, uniform, NORM);
+        if (GRAD && lane == 0) { umsg[phoist[2 * h]] = phoist[2 * h + 1]; upos[phoist[2 * h]] = tot > 0.0 ? 1 : 0; }
+      }
     }
   }
   wg_barrier();
@@ -637,6 +789,7 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
     for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = src[i];
   }
   if (NORM) marginals_from_lds_x64(d, msg, g, wave, lane);
+  if (GRAD && NT > 0) gradient_epilogue_x64<(NT > 0 ? NT : 1)>(d, gf, tab, msg, umsg, upos, red, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -730,8 +883,8 @@ __device__ __forceinline__ double sf_gather(bool mt, const double* red, int lane
   return red[lane] + red[64 + lane];
 }
 
-template <int NT>
-__global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(SweepDev d, ScaleFreeDev f) {
+template <int NT, bool GRAD>
+__global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(SweepDev d, ScaleFreeDev f, GradFusedDev gf) {
   extern __shared__ double lds[];
   double* work = lds;                                       // [n_msgs + n_ext][64] scaled messages
   double* gin = lds + (size_t)(d.n_msgs + f.n_ext) * 64;    // [4 waves][2][64] contraction inputs
@@ -744,6 +897,8 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
   int32_t* tabidx = const_cast<int32_t*>(pwritten) + f.n_written;
   int32_t* lflag = tabidx + d.P + d.U;                    // [1] set when the final pass finds a bad vector
   int32_t* lread = lflag + 1;                             // read-out tables: in_off [n_vars+1], in_slots
+  int32_t* umsg = lread + f.n_readout;                    // [U] message slot of each unary factor's message
+  int32_t* upos = umsg + d.U;                             // [U] 1 when that factor's table total was positive
 
   ABLATE_DECL
   const int g = blockIdx.x;
@@ -781,6 +936,13 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
     if (t == 0) lflag[0] = 0;
     if (d.marginals)
       for (int i = t; i < f.n_readout; i += WG) lread[i] = d.readout[i];
+    if (GRAD)
+      for (int i = t; i < d.U; i += WG) {
+        umsg[i] = -1; upos[i] = 0;
+        upos[d.U + i] = gf.unary_kind[i];
+        upos[2 * d.U + i] = gf.unary_obs[(size_t)g * d.U + i];
+        upos[3 * d.U + i] = gf.unary_label[(size_t)g * d.U + i];
+      }
   }
   if (!__syncthreads_and(ok ? 1 : 0)) {
     if (t == 0) atomicExch(d.status, 1);
@@ -814,6 +976,7 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
         const double m = ABLATED(9) ? r[j] : renorm(r[j], s, uniform, true);        // exact, these are final values
         bad_key = max(bad_key, mag_key(m));
         work[phoist[2 * h + 1] * 64 + lane] = m;
+        if (GRAD && lane == 0) { umsg[phoist[2 * h]] = phoist[2 * h + 1]; upos[phoist[2 * h]] = s > 0.0 ? 1 : 0; }
       }
     }
   }
@@ -921,6 +1084,7 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
       d.marginals[((size_t)g * d.n_vars + v) * 64 + lane] = renorm(acc, wave_sum(acc), uniform, true);
     }
   }
+  if (GRAD) gradient_epilogue_x64<NT>(d, gf, tab, work, umsg, upos, red0, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1518,13 +1682,31 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     if (prog->P == 0 || (!want_sf && nt < prog->P)) nt = 0;
     if (nt > 4) nt = 0;
     const size_t lds_sf = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 128 + 4 * 512) * sizeof(double) +
-                          (img_words + prog->P + prog->U + 4 + prog->n_readout) * sizeof(int32_t);
+                          (img_words + prog->P + 6 * prog->U + 8 + prog->n_readout) * sizeof(int32_t);
     const size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 64 + 512) * sizeof(double) +
-                       (img_words + prog->P + prog->U + 4) * sizeof(int32_t);
+                       (img_words + prog->P + 6 * prog->U + 8) * sizeof(int32_t);
     if (lds_sf > LDS_MAX) want_sf = false;
     if (lds <= LDS_MAX) {
       mlbp_program* mp = const_cast<mlbp_program*>(prog);
       if (norm) d.marginals = a->marginals;         // read-out fused into the kernels' epilogue
+      // gradient fused into the epilogue when the tables end up in registers in BOTH kernels
+      GradFusedDev gf = {};
+      const mlbp_gradient_args* ga = a->gradient;
+      bool grad_fused = false;
+      if (ga) {
+        if (ga->B != a->B || ga->X != a->X || ga->P != prog->P || ga->U != prog->U || ga->n_msgs != prog->n_msgs || ga->msgs != a->msgs)
+          return fail(MLBP_EINVAL, "mlbp_sweep_f64: gradient arguments do not describe the same batch");
+        grad_fused = norm && ga->F_ee == 3 && ga->F_ed == 6 && prog->P >= 1 && prog->P <= 3 && nt == prog->P &&
+                     prog->n_hoist == prog->U && ga->phi_en_en_t && ga->phi_en_en_w1_t && ga->phi_en_de_t &&
+                     (variant == 1 || variant == 3 || variant >= 20 || variant == 10 + prog->P);
+        if (grad_fused) {
+          gf.pair_c_slot = ga->pair_c_slot; gf.pair_r_slot = ga->pair_r_slot; gf.pair_phi = ga->pair_phi; gf.pair_label = ga->pair_label;
+          gf.unary_kind = ga->unary_kind; gf.unary_obs = ga->unary_obs; gf.unary_label = ga->unary_label;
+          gf.phi_en_en = ga->phi_en_en; gf.phi_en_en_w1 = ga->phi_en_en_w1;
+          gf.phi_en_en_t = ga->phi_en_en_t; gf.phi_en_en_w1_t = ga->phi_en_en_w1_t; gf.phi_en_de_t = ga->phi_en_de_t;
+          gf.grad_en_en = ga->grad_en_en; gf.grad_en_de = ga->grad_en_de; gf.Vde = ga->Vde; gf.enabled = 1;
+        }
+      }
       if (want_sf) {
         if (mp->bail_cap < a->B)              // not reserved for this batch size: allocate now (a stream-
           if (int e = mlbp_program_reserve(mp, a->B)) return e;   // capturing caller reserves up front instead)
@@ -1535,15 +1717,15 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
         sf.n_cprod = prog->n_cprod; sf.n_cpw = prog->n_cpw; sf.n_ext = n_ext; sf.n_written = prog->n_written;
         sf.init = a->init_messages;
         sf.n_readout = prog->n_readout;
-        void (*ks)(SweepDev, ScaleFreeDev) = nullptr;
+        void (*ks)(SweepDev, ScaleFreeDev, GradFusedDev) = nullptr;
         switch (nt) {
-          case 1: ks = sweep_x64_sf_kernel<1>; break;
-          case 2: ks = sweep_x64_sf_kernel<2>; break;
-          case 3: ks = sweep_x64_sf_kernel<3>; break;
-          default: ks = sweep_x64_sf_kernel<4>; nt = 4; break;
+          case 1: ks = grad_fused ? sweep_x64_sf_kernel<1, true> : sweep_x64_sf_kernel<1, false>; break;
+          case 2: ks = grad_fused ? sweep_x64_sf_kernel<2, true> : sweep_x64_sf_kernel<2, false>; break;
+          case 3: ks = grad_fused ? sweep_x64_sf_kernel<3, true> : sweep_x64_sf_kernel<3, false>; break;
+          default: ks = sweep_x64_sf_kernel<4, false>; nt = 4; break;
         }
         if (int e = ensure_dynamic_lds((const void*)ks, lds_sf)) return e;
-        hipLaunchKernelGGL(ks, dim3(a->B), dim3(WG), lds_sf, st, d, sf);
+        hipLaunchKernelGGL(ks, dim3(a->B), dim3(WG), lds_sf, st, d, sf, gf);
         HIP_TRY(hipGetLastError());
       }
       FusedDev f;
@@ -1554,19 +1736,23 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       f.init = a->init_messages;
       d.pairseq = prog->d_fpairseq;
       if (want_sf && nt > 3) nt = (prog->P <= 3) ? prog->P : 0;   // exact kernel keeps its own rule
-      void (*k)(SweepDev, FusedDev) = nullptr;
-#define MLBP_PICK(N) k = norm ? sweep_x64_fused_kernel<true, N> : sweep_x64_fused_kernel<false, N>
+      void (*k)(SweepDev, FusedDev, GradFusedDev) = nullptr;
+#define MLBP_PICK(N) k = norm ? sweep_x64_fused_kernel<true, N, false> : sweep_x64_fused_kernel<false, N, false>
+#define MLBP_PICKG(N) k = grad_fused ? sweep_x64_fused_kernel<true, N, true> : (norm ? sweep_x64_fused_kernel<true, N, false> : sweep_x64_fused_kernel<false, N, false>)
       switch (nt) {
-        case 1: MLBP_PICK(1); break;
-        case 2: MLBP_PICK(2); break;
-        case 3: MLBP_PICK(3); break;
+        case 1: MLBP_PICKG(1); break;
+        case 2: MLBP_PICKG(2); break;
+        case 3: MLBP_PICKG(3); break;
         case 4: MLBP_PICK(4); break;
         default: MLBP_PICK(0); break;
       }
 #undef MLBP_PICK
+#undef MLBP_PICKG
       if (int e = ensure_dynamic_lds((const void*)k, lds)) return e;
-      hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, st, d, f);
+      hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, st, d, f, gf);
       HIP_TRY(hipGetLastError());
+      if (ga && !grad_fused)
+        if (int e = mlbp_gradient_f64(ga, stream)) return e;
       if (a->marginals && !norm)
         return mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
                                   prog->d_readout + prog->n_vars + 1, 0, a->marginals, stream);
@@ -1585,8 +1771,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, st, d);
       HIP_TRY(hipGetLastError());
       if (a->marginals)
-        return mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
-                                  prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream);
+        if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
+                                       prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;
+      if (a->gradient) return mlbp_gradient_f64(a->gradient, stream);
       return MLBP_OK;
     }
   }
@@ -1599,8 +1786,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     hipLaunchKernelGGL(kw, dim3(a->B), dim3(WG), ldsw, st, d);
     HIP_TRY(hipGetLastError());
     if (a->marginals)
-      return mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
-                                prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream);
+      if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
+                                     prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;
+    if (a->gradient) return mlbp_gradient_f64(a->gradient, stream);
     return MLBP_OK;
   }
   size_t base = ((size_t)a->X + 4) * sizeof(double);
@@ -1614,8 +1802,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   }
   HIP_TRY(hipGetLastError());
   if (a->marginals)
-    return mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
-                              prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream);
+    if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
+                                   prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;
+  if (a->gradient) return mlbp_gradient_f64(a->gradient, stream);
   return MLBP_OK;
 }
 

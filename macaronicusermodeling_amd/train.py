@@ -154,8 +154,7 @@ class UserGraphTrainer:
         [sum_i grad_en_en (F_ee) | sum_i grad_en_de (F_ed) | sum_i log-posterior | instance count]."""
         fb = self.batch
         self.build_potentials()
-        fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg)
-        fb.gradient(self._g_ee, self._g_ed)
+        fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg, gradient=(self._g_ee, self._g_ed))
         self._patch_gradient()
         _ffi.check(_ffi.lib.mlbp_log_posterior_f64(self._marg.data_ptr(), fb._labels.data_ptr(), fb.B, self.topo.n_vars,
                                                    fb.X, self._lp.data_ptr(), _stream_ptr(self.device)))

@@ -57,6 +57,14 @@ def test_batched_gradient_and_beliefs(case):
     g_ee, g_ed = fb.gradient()
     assert _ffi.lib.mlbp_gradient_status() == 0
     g_ee, g_ed = g_ee.cpu().numpy(), g_ed.cpu().numpy()
+    # the same gradients produced inside the sweep launch (fused when tables are register-resident)
+    f_ee = torch.full((nb, 3), float('nan'), dtype=torch.float64, device=fb.device)
+    f_ed = torch.full((nb, 6), float('nan'), dtype=torch.float64, device=fb.device)
+    fb.initialize(case['roots'][0])
+    prog = fb.sweep((case['roots'] * 10)[:n], gradient=(f_ee, f_ed))
+    assert prog.status() == 0
+    np.testing.assert_allclose(f_ee.cpu().numpy(), g_ee, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(f_ed.cpu().numpy(), g_ed, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(g_ee[0], gold['grad_unreg_en_en'].reshape(-1), rtol=1e-8, atol=1e-11)
     np.testing.assert_allclose(g_ed[0], gold['grad_unreg_en_de'].reshape(-1), rtol=1e-8, atol=1e-11)
     g = O.Graph(spec)

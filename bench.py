@@ -35,11 +35,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix spec (= FP64 vector; 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz); the guide's
+                                # MFMA table has no f64 row
 
 
 def workload_spec(name):
     import cases as C
-    if name == 'user_k3':
+    if name in ('user_k3', 'user_k3_shared'):
         return C.user_spec(10, [1, 4, 7], 64, 64, seed=1), [1, 4, 7], 3, 1236
     if name == 'chain8':
         return C.chain_spec(8, 64), [0] * 10, 10, 1235
@@ -128,7 +130,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'chain8', 'ring8', 'ring8_x512'])
+    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'chain8', 'ring8', 'ring8_x512'],
+                    help='user_k3_shared = the same graphs with the reference\'s table layout: all graphs share the two '
+                         'en_en pots (MFMA kernel, reported against the f64 matrix peak)')
+    ap.add_argument('--no-writeback', action='store_true', help='shared workload: skip the message write-back (read-out only)')
     ap.add_argument('--batch', type=int, default=8192, help='graphs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sweeps', type=int, default=None, help='override sweeps per step (roots cycle)')
@@ -179,9 +184,16 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed + 7919 * rank)
     fb = FactorGraphBatch(topo, X, B, device=dev)
-    pair = torch.rand(B * topo.P, X, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
+    shared = a.workload.endswith('_shared')
     unary = torch.rand(B * topo.U, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
-    fb.set_pair_tables(pair)
+    if shared:      # LBP.py:456-467: pot_en_en behind the gap > 1 factors, pot_en_en_w1 behind the gap == 1 ones
+        pair = torch.rand(2, X, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
+        by_id = {f['id']: f for f in spec['factors']}
+        which = [0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1 for j in topo.pair_factors]
+        fb.set_pair_tables(pair, np.tile(np.array(which), (B, 1)))
+    else:
+        pair = torch.rand(B * topo.P, X, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
+        fb.set_pair_tables(pair)
     fb.set_unary_tables(unary)
     labels = np.tile(np.array([dict(zip(spec['var_ids'], spec['labels']))[v] for v in topo.var_ids]), (B, 1))
     labels_d = torch.from_numpy(labels.astype(np.int32)).to(dev)
@@ -205,7 +217,7 @@ def main():
     def step(i=None):
         if i is not None:
             ev[i][0].record()
-        fb.sweep(roots, init=True, marginals=marg)   # initialize + marginal read-out fused into the launch
+        fb.sweep(roots, init=True, marginals=marg, keep_messages=not a.no_writeback)   # initialize + marginal read-out fused into the launch
         if i is not None:
             ev[i][1].record()
         _ffi.check(_ffi.lib.mlbp_log_posterior_f64(marg.data_ptr(), labels_d.data_ptr(), B, topo.n_vars, X,
@@ -256,19 +268,29 @@ def main():
         avg_ms = sum(sweep_ms) / len(sweep_ms)
         alg_bytes = algorithmic_bytes_per_graph(topo, roots, X) * B
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        used_mfma = shared and _ffi.lib.mlbp_last_sweep_kernel() == 3
+        if used_mfma:      # shared-table mode is priced in flops, 2 X^2 per pairwise update and graph
+            n_pair = sum(int(np.isin(topo.compile_sweep(r)[0][:, 0], (_ffi.OP_PAIR_TM, _ffi.OP_PAIR_MT)).sum()) for r in roots)
+            alg_flops = 2.0 * X * X * n_pair * B
         out = {
             'metric': 'LBP sweep iters/sec (whole node), batch=8192 graphs |X|=64',
             'value': iters_per_s, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': '%s: %d graphs/GPU, |X|=%d, P=%d pairwise + U=%d unary factors, unique f64 '
-                                   'table per (graph,factor), step = initialize + %d sweeps + posterior read-out'
-                                   % (a.workload, B, X, topo.P, topo.U, sweeps),
+                                   'table per (graph,factor)%s, step = initialize + %d sweeps + posterior read-out'
+                                   % (a.workload, B, X, topo.P, topo.U, ' EXCEPT the pairwise tables: two pots shared by all graphs' if shared else '', sweeps),
                        'graphs_per_gpu': B, 'X': X, 'sweeps_per_step': sweeps, 'roots': list(roots),
                        'graph_sweeps_per_s': world * B * sweeps * a.steps / elapsed,
                        'parallelism': 'graphs sharded over %d GPU(s), no data-path collective; one all-reduce of the '
                                       'step statistics per step (%s)' % (world, backend if world > 1 else 'n/a')},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'roofline': {'bound': 'mfma', 'achieved': alg_flops / (avg_ms * 1e-3) / 1e12, 'peak': F64_MFMA_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': alg_flops / (avg_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                         'traffic_source': traffic_src, 'kernel': 'sweep_x64_shared_kernel (v_mfma_f64_16x16x4_f64; timed region also holds '
+                         'the flag memset and the fix-up pass)', 'algorithmic_flops_per_launch': alg_flops,
+                         'avg_launch_ms': avg_ms, 'min_launch_ms': sweep_ms[0], 'max_launch_ms': sweep_ms[-1],
+                         'hbm_equivalent_GBps_if_tables_were_unique': achieved} if used_mfma else
+                        {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'kernel': ('sweep_x64_sf_kernel (timed region = hipMemsetAsync of the flag bytes + this kernel + the ~6 us fix-up '
                                     'pass of sweep_x64_fused_kernel)') if X == 64 and a.variant in (None, 1) and 1 <= topo.P <= 4 else

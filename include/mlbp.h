@@ -169,7 +169,20 @@ typedef struct mlbp_sweep_args {
                                  registers, messages in LDS) when X = 64, F = (3,6), at most 3
                                  pairwise factors and the transposed feature tensors are given;
                                  otherwise by mlbp_gradient_f64 enqueued behind the sweeps            */
+  int32_t flags;              /* MLBP_SWEEP_* bits, 0 = none                                        */
 } mlbp_sweep_args;
+
+/* flags: the caller states that pair_tab[b][p] is the same for every graph b (the reference's own
+ * layout: one pot_en_en / pot_en_en_w1 array behind all pairwise factors, LBP.py:456-467, and one
+ * theta per minibatch, train_mp.py:178-255).  With X = 64, init_messages and normalize_messages set,
+ * at most two distinct tables and a working set that fits LDS, 16 graphs then share a workgroup
+ * and the factor->variable updates run as float64 MFMA contractions T[64x64] . M[64x16]
+ * (mlbp_shared.hip).  The statement is checked on the device: groups of graphs for which it does not
+ * hold, and degenerate graphs, are computed by the exact kernel instead. */
+#define MLBP_SWEEP_SHARED_PAIR_TABLES 1
+/* flags: with MLBP_SWEEP_SHARED_PAIR_TABLES and a fused read-out (marginals != NULL) the messages
+ * need not be written back to msgs (ignored when a gradient is requested, which reads them). */
+#define MLBP_SWEEP_NO_MESSAGE_WRITEBACK 2
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
 
@@ -180,10 +193,22 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
  *         followed by the exact fused kernel on the graphs it flagged as degenerate;
  *   3     exact fused kernel only (normalises after every update like the reference);
  *   0     first-generation kernel;   10+N  exact fused kernel with N register-resident tables
- *         (N = 0 streams);           20+N  scale-free kernel with N resident tables (N = 1..4).
+ *         (N = 0 streams);           20+N  scale-free kernel with N resident tables (N = 1..4);
+ *   30    as 1 (kept distinct for A/B scripts): shared-table MFMA kernel when the launch qualifies.
+ * Variants other than 1 and 30 never use the shared-table kernel.
  * All variants perform the same updates in the same order; exact variants agree bitwise, the
  * scale-free one to rounding. */
 int mlbp_set_sweep_variant(int32_t variant);
+
+/* Diagnostic: which kernel family the calling thread's last mlbp_sweep_f64 enqueued first (the exact
+ * kernel may follow it for flagged graphs); -1 before the first call. */
+#define MLBP_KERNEL_FIRST_GEN 0
+#define MLBP_KERNEL_SCALE_FREE 1
+#define MLBP_KERNEL_EXACT 2
+#define MLBP_KERNEL_SHARED_MFMA 3
+#define MLBP_KERNEL_WIDE 4
+#define MLBP_KERNEL_GENERIC 5
+int mlbp_last_sweep_kernel(void);
 
 /* Fills msgs[B][n_msgs][X] with 1/X: FactorGraph.initialize (LBP.py:211-216). */
 int mlbp_init_messages_f64(double* msgs, int64_t n_rows, int32_t X, void* stream);

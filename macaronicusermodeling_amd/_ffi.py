@@ -44,7 +44,12 @@ class SweepArgs(C.Structure):
     _fields_ = [('B', C.c_int32), ('X', C.c_int32), ('n_pair_tables', C.c_int32),
                 ('n_unary_tables', C.c_int32), ('pair_tables', C.c_void_p), ('pair_tab', C.c_void_p),
                 ('unary_tables', C.c_void_p), ('unary_tab', C.c_void_p), ('msgs', C.c_void_p),
-                ('normalize_messages', C.c_int32), ('init_messages', C.c_int32), ('marginals', C.c_void_p), ('gradient', C.c_void_p)]
+                ('normalize_messages', C.c_int32), ('init_messages', C.c_int32), ('marginals', C.c_void_p), ('gradient', C.c_void_p),
+                ('flags', C.c_int32)]
+
+
+SWEEP_SHARED_PAIR_TABLES = 1      # include/mlbp.h MLBP_SWEEP_*
+SWEEP_NO_MESSAGE_WRITEBACK = 2
 
 
 _i32p = C.POINTER(C.c_int32)
@@ -57,6 +62,7 @@ SIGNATURES = {
     'mlbp_arch': (C.c_char_p, []),
     'mlbp_last_error': (C.c_char_p, []),
     'mlbp_device_count': (C.c_int, []),
+    'mlbp_last_sweep_kernel': (C.c_int, []),
     'mlbp_has_loops': (C.c_int, [C.POINTER(Topology), _i32]),
     'mlbp_message_schedule': (C.c_int, [C.POINTER(Topology), _i32, _i32p, _i32]),
     'mlbp_message_slots': (C.c_int, [C.POINTER(Topology), _i32p, _i32p, _i32p, _i32p]),

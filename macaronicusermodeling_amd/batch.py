@@ -94,7 +94,11 @@ class FactorGraphBatch:
             if t.shape[0] != self.B * self.topo.P:
                 raise ValueError('need B*P tables when pair_tab is omitted')
             pair_tab = np.arange(self.B * self.topo.P).reshape(self.B, self.topo.P)
-        self.pair_tab = self._as_index(pair_tab, self.B, self.topo.P, t.shape[0], 'pair table', self.device)
+        host_tab = np.asarray(pair_tab).reshape(self.B, self.topo.P)
+        # every graph reads the same table for factor p (the reference's layout: one pot array behind all
+        # pairwise factors): eligible for the shared-table kernel, which re-checks it on the device
+        self.pair_tables_shared = bool(self.topo.P) and bool((host_tab == host_tab[:1]).all())
+        self.pair_tab = self._as_index(host_tab, self.B, self.topo.P, t.shape[0], 'pair table', self.device)
         self.pair_tables = t
 
     def set_unary_tables(self, tables, unary_tab=None):
@@ -122,13 +126,15 @@ class FactorGraphBatch:
             self._programs[key] = Program(self.topo, key, max_graphs=self.B)
         return self._programs[key]
 
-    def sweep(self, roots, init=False, marginals=None, gradient=None):
+    def sweep(self, roots, init=False, marginals=None, gradient=None, keep_messages=True):
         """Runs len(roots) sweeps, sweep s rooted at variable id roots[s], on every graph, in one
         launch.  init=True starts from uniform messages (initialize() fused into the launch);
         marginals: optional [B][n_vars][X] device tensor that receives every variable's marginal
         after the last sweep, read out of the on-chip messages in the same launch; gradient: optional
         (out_ee [B][F_ee], out_ed [B][F_ed]) device tensors that receive the per-graph gradients
-        (set_features / set_observations first), fused into the launch when the kernel allows."""
+        (set_features / set_observations first), fused into the launch when the kernel allows;
+        keep_messages=False lets a shared-table launch with a fused read-out skip the write-back of
+        self.msgs (their contents are then undefined)."""
         prog = self.program(roots)
         a = _ffi.SweepArgs()
         a.B, a.X = self.B, self.X
@@ -145,6 +151,10 @@ class FactorGraphBatch:
         a.msgs = self.msgs.data_ptr()
         a.normalize_messages = 1 if self.normalize_messages else 0
         a.init_messages = 1 if init else 0
+        if getattr(self, 'pair_tables_shared', False):
+            a.flags |= _ffi.SWEEP_SHARED_PAIR_TABLES
+            if not keep_messages and marginals is not None:
+                a.flags |= _ffi.SWEEP_NO_MESSAGE_WRITEBACK
         if marginals is not None:
             if tuple(marginals.shape) != (self.B, self.topo.n_vars, self.X) or marginals.dtype != torch.float64:
                 raise ValueError('marginals must be float64 [B][n_vars][X]')

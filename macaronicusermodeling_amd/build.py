@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libmlbp.so')
-SOURCES = ['mlbp_host.cpp', 'mlbp_sweep.hip', 'mlbp_prims.hip', 'mlbp_grad.hip']
+SOURCES = ['mlbp_host.cpp', 'mlbp_sweep.hip', 'mlbp_shared.hip', 'mlbp_prims.hip', 'mlbp_grad.hip']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fno-fast-math', '-Wall',
          '-Wno-unused-function']
 

@@ -3,11 +3,46 @@
 #ifndef MLBP_INTERNAL_H
 #define MLBP_INTERNAL_H
 
+#include <vector>
+
 #include "../../include/mlbp.h"
+
+struct mlbp_program;
 
 namespace mlbp {
 // Records a printf-style message for mlbp_last_error() and returns `code`.
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// Fused program form of the X = 64 kernels (build_fused_program in mlbp_sweep.hip): 8-word op headers.
+enum { FOP_UNARY = 0, FOP_PAIR_TM = 1, FOP_PAIR_MT = 2, FOP_VAR = 3, FOP_VAR_PAIR_TM = 4, FOP_VAR_PAIR_MT = 5,
+       FOP_BUNDLED = 0x100 /* flag: the next update touches disjoint slots and may share this one's barrier */ };
+struct FusedProgram {
+  std::vector<int32_t> fops, psrcs, fsweeps, hoist, cpw, pairseq, written;
+  int n_cprod = 0;
+  bool has_unary_fops = false;
+};
+
+// Shared-table (MFMA) form, mlbp_shared.hip: 16 graphs per workgroup, messages kept as [state][graph]
+// tiles in LDS, only the "live" slots (read or written inside the sweeps) resident.
+struct SharedProgram {
+  bool ok = false;
+  const char* why = "";               // when !ok: what rules the program out
+  int n_ops = 0, n_live = 0, n_lists = 0, n_cpw = 0, n_back = 0, n_fill = 0, off_sweeps = 0;
+  std::vector<int32_t> sweeps;         // {first op, count} per sweep of the transformed op list
+  std::vector<int32_t> image;          // ops [n_ops][8], lists [n_lists], cprod lists [n_cpw], write-back pairs [n_back][2], fill slots [n_fill]
+  std::vector<int32_t> live_of_slot;   // [n_msgs + 1 + n_cprod] LDS tile of a slot (ext slots included) or -1
+  std::vector<int32_t> hoisted;        // [n_msgs] unary factor whose constant message the slot holds, or -1
+  std::vector<char> written;           // [n_msgs] some update of the program writes the slot
+  std::vector<std::vector<int32_t>> cprods;   // hoisted message slots of constant product k
+};
+void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, SharedProgram& out);
+// Builds the device read-out image of the shared form from the per-variable incoming-slot lists;
+// false when some variable's constant part matches no constant product.
+bool build_shared_readout(const SharedProgram& sp, int n_msgs, int n_vars, const int32_t* in_off, const int32_t* in_slots,
+                          std::vector<int32_t>& image);
+// Enqueues the shared-table kernel when it applies (sets *launched); flagged graphs are left in
+// prog->d_bail for the exact kernel.
+int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched);
 }  // namespace mlbp
 
 // Device-resident, validated op list (see mlbp_program_create).
@@ -32,6 +67,11 @@ struct mlbp_program {
   int32_t* d_fsweeps;     // [n_sweeps][2]
   int32_t* d_fpairseq;    // pair slot of the k-th executed pairwise update of the fused form (-1 terminated)
   int device;
+  // shared-table form (mlbp_shared.hip)
+  mlbp::SharedProgram shared;
+  int32_t* d_simage;      // SharedProgram::image
+  int32_t* d_sreadout;    // per variable: base tile, count, live tiles (4-word aligned lists) or NULL
+  int32_t n_sreadout;
 };
 
 #endif

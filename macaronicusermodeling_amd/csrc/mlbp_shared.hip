@@ -1,0 +1,689 @@
+// Shared-table sweeps on the gfx950 matrix cores (X = 64, float64).
+//
+// When every graph of the batch reads the SAME pairwise table for factor p -- the reference's own
+// layout: one pot_en_en / pot_en_en_w1 array per FactorGraph, shared by all of its pairwise factors
+// (LBP.py:456-467, 695-710) and, at one theta, by every instance of a minibatch (train_mp.py:178-255)
+// -- the factor->variable update of G graphs is a dense contraction  OUT[64 x G] = T[64 x 64] . M[64 x G]
+// (or T^T . M), i.e. exactly the case SURVEY.md section 8(d) prices against the MFMA peak instead of HBM.
+//
+// One 256-thread workgroup owns G = 16 graphs for all sweeps of the call:
+//   * wave w holds rows 16w..16w+15 of every distinct table in BOTH orientations as
+//     v_mfma_f64_16x16x4_f64 A-fragments in registers (16 doubles per table and orientation) for the
+//     whole launch -- the tables are read once per workgroup, from L2;
+//   * messages live in LDS as [state][graph] tiles (8 KiB): a tile read 64 lanes wide IS the B operand
+//     of k-step s (lane l = state 4s + (l >> 4), graph l & 15), and the D fragment of wave w (lane l,
+//     register r = state 16w + (l >> 4) + 4r, graph l & 15) is stored straight back into that layout;
+//   * a factor->variable message is kept UNNORMALISED with its four per-wave partial column sums
+//     beside it; readers multiply by the reciprocal of the total, so an update needs ONE barrier
+//     (the scale of the variable->factor input cancels in normalise(T.m), LBP.py:509-524, 649-657);
+//   * only the slots the sweeps read or write are resident ("live" tiles): unary messages are constants
+//     (LBP.py:494-498), written back once in the prologue and folded into one product per variable.
+// Degenerate graphs (zero / non-finite totals, where Message.renormalize and nan_to_num take their
+// special branches) are flagged per graph and redone by the exact kernel, like the scale-free path.
+//
+// Flops per pairwise update per graph: 2 * 64 * 64 = 8192 (shared-table mode).
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
+
+#include "mlbp_internal.h"
+
+namespace mlbp {
+
+// ------------------------------------------------------------------------------------------------
+// host: live-tile form of the fused program
+// ------------------------------------------------------------------------------------------------
+void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, SharedProgram& out) {
+  out = SharedProgram();
+  const int n_hoist = (int)fp.hoist.size() / 2;
+  out.why = "unary messages are not all constant, or no / too many pairwise factors";
+  if (fp.has_unary_fops || n_hoist != U || P < 1 || P > 16) return;
+  const int n_all = n_msgs + 1 + fp.n_cprod;
+  out.hoisted.assign(n_msgs, -1);
+  for (int h = 0; h < n_hoist; ++h) out.hoisted[fp.hoist[2 * h + 1]] = fp.hoist[2 * h];
+  out.why = "a unary message is folded into no variable update";
+  {
+    std::vector<char> in_list(n_msgs, 0);
+    size_t at = 0;
+    for (int k = 0; k < fp.n_cprod; ++k) {
+      const int cnt = fp.cpw[at];
+      out.cprods.emplace_back(fp.cpw.begin() + at + 1, fp.cpw.begin() + at + 1 + cnt);
+      for (int c : out.cprods.back()) {
+        if (c < 0 || c >= n_msgs || out.hoisted[c] < 0) return;
+        in_list[c] = 1;
+      }
+      at += 1 + cnt;
+    }
+    for (int c = 0; c < n_msgs; ++c)
+      if (out.hoisted[c] >= 0 && !in_list[c]) return;     // a unary message no variable update folds in
+  }
+  // Sweep boundaries mean nothing to this kernel (it runs the updates in order), so the whole call is one
+  // sequence.  Two rewrites keep the variable->factor messages out of LDS:
+  //   1. a pairwise update whose input message c was produced by a variable->factor update whose own inputs
+  //      have not changed since RECOMPUTES c in registers (fused pair) instead of reading a stored tile --
+  //      the up pass of a loopy schedule (LBP.py:227-233) emits "X7->F17, X4->F14, F17->X1, F14->X1", and the
+  //      sweep that follows may read X4->F14 once more;
+  //   2. a lone variable->factor update whose output is rewritten later and not read before that is dropped.
+  // Both leave every stored value exactly what the original order computes.
+  std::vector<int32_t> fops;                                   // transformed op list, 8 words each
+  {
+    std::vector<std::vector<int32_t>> seq;
+    for (size_t sw = 0; sw + 1 < fp.fsweeps.size(); sw += 2)
+      for (int i = fp.fsweeps[sw]; i < fp.fsweeps[sw] + fp.fsweeps[sw + 1]; ++i) {
+        seq.emplace_back(fp.fops.begin() + 8 * (size_t)i, fp.fops.begin() + 8 * (size_t)i + 8);
+        seq.back()[0] &= 0xFF;
+      }
+    auto is_pair = [](const std::vector<int32_t>& w) { return w[0] == FOP_PAIR_TM || w[0] == FOP_PAIR_MT; };
+    auto writes = [&](const std::vector<int32_t>& w, int slot) {
+      if (is_pair(w) || w[0] == FOP_VAR) return w[3] == slot;
+      return w[3] == slot || w[5] == slot;
+    };
+    for (size_t j = 0; j < seq.size(); ++j) {
+      if (!is_pair(seq[j])) continue;
+      const int c = seq[j][2];
+      int i = (int)j - 1;
+      while (i >= 0 && !writes(seq[i], c)) --i;
+      if (i < 0 || is_pair(seq[i]) || seq[i][3] != c) continue;               // never written, or not by a variable update
+      const std::vector<int32_t> v = seq[i];
+      bool legal = true;
+      for (size_t k = i + 1; k < j && legal; ++k) {
+        for (int q = 0; q < v[2] && legal; ++q) if (writes(seq[k], fp.psrcs[v[1] + q])) legal = false;
+        for (int q = 0; q < v[7] && legal; ++q) if (writes(seq[k], fp.psrcs[v[6] + q])) legal = false;
+      }
+      if (!legal) continue;
+      const std::vector<int32_t> pr = seq[j];
+      seq[j] = {pr[0] == FOP_PAIR_TM ? FOP_VAR_PAIR_TM : FOP_VAR_PAIR_MT, v[1], v[2], c, pr[1], pr[3], v[6], v[7]};
+    }
+    for (size_t i = 0; i < seq.size();) {
+      if (seq[i][0] != FOP_VAR) { ++i; continue; }
+      const int c = seq[i][3];
+      bool dead = false;
+      for (size_t k = i + 1; k < seq.size(); ++k) {
+        if (is_pair(seq[k]) && seq[k][2] == c) break;                          // still read from its tile
+        if (writes(seq[k], c)) { dead = true; break; }
+      }
+      if (dead) seq.erase(seq.begin() + i);
+      else ++i;
+    }
+    out.sweeps.push_back(0);
+    out.sweeps.push_back((int)seq.size());
+    for (auto& w : seq) fops.insert(fops.end(), w.begin(), w.end());
+  }
+  const int n_ops = (int)fops.size() / 8;
+  out.why = "unsupported update kind or slot use";
+  std::vector<char> live(n_all, 0), written(n_msgs, 0);
+  for (int i = 0; i < n_ops; ++i) {
+    const int32_t* w = &fops[8 * i];
+    const int kind = w[0] & 0xFF;
+    if (kind == FOP_PAIR_TM || kind == FOP_PAIR_MT) {
+      if (written[w[2]]) live[w[2]] = 1;        // else: still the initial uniform message, no tile needed
+      else fops[8 * i + 2] = -1;
+      live[w[3]] = 1; written[w[3]] = 1;
+    } else if (kind == FOP_VAR || kind == FOP_VAR_PAIR_TM || kind == FOP_VAR_PAIR_MT) {
+      for (int q = 0; q < w[2]; ++q) live[fp.psrcs[w[1] + q]] = 1;
+      written[w[3]] = 1;
+      if (kind != FOP_VAR) { live[w[5]] = 1; written[w[5]] = 1; }
+    } else {
+      return;
+    }
+  }
+  for (int c = 0; c < n_msgs; ++c)
+    if (out.hoisted[c] >= 0 && (live[c] || written[c])) return;
+  out.written = written;
+  out.live_of_slot.assign(n_all, -1);
+  for (int s = 0; s < n_all; ++s)
+    if (live[s]) out.live_of_slot[s] = out.n_live++;
+  // ops + source lists
+  std::vector<int32_t> ops((size_t)n_ops * 8, 0), lists;
+  std::vector<int> last_var_write(n_msgs, -1);
+  for (int i = 0; i < n_ops; ++i) {
+    const int32_t* w = &fops[8 * i];
+    int32_t* so = &ops[8 * (size_t)i];
+    const int kind = w[0] & 0xFF;
+    so[0] = kind;
+    if (kind == FOP_PAIR_TM || kind == FOP_PAIR_MT) {
+      so[1] = w[2] < 0 ? -1 : out.live_of_slot[w[2]]; so[4] = w[1]; so[5] = out.live_of_slot[w[3]];
+    } else {
+      while (lists.size() % 4) lists.push_back(0);
+      so[1] = (int)lists.size(); so[2] = w[2];
+      for (int q = 0; q < w[2]; ++q) lists.push_back(out.live_of_slot[fp.psrcs[w[1] + q]]);
+      so[3] = out.live_of_slot[w[3]]; so[6] = w[3];
+      if (kind != FOP_VAR) { so[4] = w[4]; so[5] = out.live_of_slot[w[5]]; }
+      if (so[3] < 0) last_var_write[w[3]] = i;
+    }
+  }
+  for (int c = 0; c < n_msgs; ++c)
+    if (last_var_write[c] >= 0) ops[8 * (size_t)last_var_write[c]] |= 0x200;     // write this v->f message out here
+  while (lists.size() % 4) lists.push_back(0);
+  // constant products, flattened: {unary factor, message slot, tile, 1 = first | 2 = last of its product}
+  std::vector<int32_t> ent;
+  for (int k = 0; k < fp.n_cprod; ++k) {
+    const int tile = out.live_of_slot[n_msgs + 1 + k];
+    if (tile < 0 || out.cprods[k].empty()) return;
+    for (size_t q = 0; q < out.cprods[k].size(); ++q) {
+      const int c = out.cprods[k][q];
+      ent.insert(ent.end(), {out.hoisted[c], c, tile, (q == 0 ? 1 : 0) | (q + 1 == out.cprods[k].size() ? 2 : 0)});
+    }
+  }
+  std::vector<int32_t> back, fill;
+  for (int c = 0; c < n_msgs; ++c) {
+    if (out.hoisted[c] >= 0) continue;
+    if (written[c] && out.live_of_slot[c] >= 0) { back.push_back(out.live_of_slot[c]); back.push_back(c); }
+    else if (!written[c]) fill.push_back(c);
+  }
+  out.n_ops = n_ops; out.n_lists = (int)lists.size(); out.n_cpw = (int)ent.size();
+  out.n_back = (int)back.size() / 2; out.n_fill = (int)fill.size();
+  out.image = ops;
+  out.image.insert(out.image.end(), lists.begin(), lists.end());
+  out.image.insert(out.image.end(), ent.begin(), ent.end());
+  out.image.insert(out.image.end(), back.begin(), back.end());
+  out.image.insert(out.image.end(), fill.begin(), fill.end());
+  out.off_sweeps = (int)out.image.size();
+  out.image.insert(out.image.end(), out.sweeps.begin(), out.sweeps.end());
+  out.image.push_back(0);
+  out.why = "";
+  out.ok = true;
+}
+
+bool build_shared_readout(const SharedProgram& sp, int n_msgs, int n_vars, const int32_t* in_off, const int32_t* in_slots,
+                          std::vector<int32_t>& image) {
+  // layout: offset of variable v's list [n_vars], then per variable {base tile or -1, n, tiles...}
+  image.assign(n_vars, 0);
+  while (image.size() % 4) image.push_back(0);
+  for (int v = 0; v < n_vars; ++v) {
+    std::vector<int32_t> consts, tiles;
+    for (int q = in_off[v]; q < in_off[v + 1]; ++q) {
+      const int c = in_slots[q];
+      if (sp.hoisted[c] >= 0) consts.push_back(c);
+      else if (sp.live_of_slot[c] >= 0) tiles.push_back(sp.live_of_slot[c]);
+      else if (sp.written[c]) return false;            // written but not resident: not an incoming message we can read
+      // else: never read and never written inside the sweeps -> still uniform, cancels in the normalisation
+    }
+    int base = -1;
+    if (!consts.empty()) {
+      for (size_t k = 0; k < sp.cprods.size(); ++k)
+        if (sp.cprods[k] == consts) base = sp.live_of_slot[n_msgs + 1 + (int)k];
+      if (base < 0) return false;
+    }
+    image[v] = (int)image.size();
+    image.push_back(base);
+    image.push_back((int)tiles.size());
+    image.insert(image.end(), tiles.begin(), tiles.end());
+    while (image.size() % 4) image.push_back(0);
+  }
+  return true;
+}
+
+namespace {
+
+constexpr int WG = 256;
+constexpr int G = 16;                 // graphs per workgroup = the N of v_mfma_f64_16x16x4_f64
+constexpr int TILE = 64 * G;          // doubles per message tile
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double wave_sum(double v) {      // all 64 lanes, same bits everywhere
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+}
+// Sum over the four lanes l, l^16, l^32, l^48 (= the four k-rows of one graph column), the same bits in all
+// four: v_permlane16_swap / v_permlane32_swap (gfx950) exchange whole rows of 16 / halves of 32 lanes in the
+// VALU -- with both operands equal the two results are the value of the even and of the odd partner row.
+__device__ __forceinline__ double column_sum(double v) {
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  v = __hiloint2double((int)h16[0], (int)l16[0]) + __hiloint2double((int)h16[1], (int)l16[1]);
+  lo = (unsigned)__double2loint(v); hi = (unsigned)__double2hiint(v);
+  auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)h32[0], (int)l32[0]) + __hiloint2double((int)h32[1], (int)l32[1]);
+}
+// A total a reader may divide by: finite, positive and far from the ends of the exponent range.
+__device__ __forceinline__ bool total_ok(double t) { return t >= 1e-280 && t <= 1e280; }
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct SharedDev {
+  const double* pair_tables;
+  const int32_t* pair_tab;
+  const double* unary_tables;
+  const int32_t* unary_tab;
+  double* msgs;                 // [B][n_msgs][64] or NULL (no write-back)
+  double* marginals;            // [B][n_vars][64] or NULL
+  int32_t* status;
+  uint8_t* bail;
+  const int32_t* image;
+  const int32_t* fsweeps;
+  const int32_t* readout;
+  int32_t B, n_sweeps, n_msgs, P, U, n_pair_tables, n_unary_tables, n_vars;
+  int32_t n_ops, n_live, n_lists, n_cpw, n_back, n_fill, n_readout;
+};
+
+#ifdef MLBP_STAMPS
+__device__ unsigned long long* g_sh_stamp = nullptr;
+__device__ int g_sh_ablate = 0;
+#define ABL(bit) (abl_ & (1 << (bit)))
+#define ABL_DECL const int abl_ = __builtin_amdgcn_readfirstlane(g_sh_ablate);
+#define STAMP_DECL unsigned long long _t0 = 0, _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t0) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define STAMPV(i) { unsigned long long _t1; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t1) :: "memory"); __builtin_amdgcn_sched_barrier(0); _ph[i] += _t1 - _t0; _t0 = _t1; }
+#define STAMP(i) { unsigned long long _t1; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t1) :: "memory"); __builtin_amdgcn_sched_barrier(0); _ph[i] += _t1 - _t0; _t0 = _t1; }
+#define STAMP_FLUSH if (g_sh_stamp && blockIdx.x < 64 && threadIdx.x == 0) { for (int _i = 0; _i < 8; ++_i) g_sh_stamp[blockIdx.x * 8 + _i] = _ph[_i]; }
+#else
+#define STAMP_DECL
+#define STAMP_START
+#define STAMP(i)
+#define STAMPV(i)
+#define ABL(bit) 0
+#define ABL_DECL
+#define STAMP_FLUSH
+#endif
+
+#define MLBP_MFMA16(A)                                                               \
+  _Pragma("unroll") for (int s_ = 0; s_ < 16; s_ += 2) {                            \
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s_], b[s_], acc0, 0, 0, 0);       \
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s_ + 1], b[s_ + 1], acc1, 0, 0, 0); \
+  }
+
+template <int NTAB>
+__global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
+  extern __shared__ double lds[];
+  double* tiles = lds;                                           // [n_live][64 states][16 graphs]
+  double* tot = tiles + (size_t)d.n_live * TILE;                 // [n_live][4 waves][16 graphs] partial column sums
+  int32_t* img = reinterpret_cast<int32_t*>(tot + (size_t)d.n_live * 64);
+  const int32_t* lists = img + d.n_ops * 8;
+  const int32_t* ent = lists + d.n_lists;
+  const int32_t* back = ent + d.n_cpw;
+  const int32_t* fill = back + 2 * d.n_back;
+  int32_t* rd = const_cast<int32_t*>(fill) + d.n_fill;           // read-out image
+  int32_t* utab = rd + d.n_readout;                              // [16][U]
+  int32_t* ptab = utab + G * d.U;                                // [P] table of factor p
+  int32_t* preg = ptab + d.P;                                    // [P] register set of factor p
+  int32_t* dist = preg + d.P;                                    // [NTAB] distinct tables, then {count, overflow}
+  int32_t* gflag = dist + NTAB + 2;                              // [16] prologue verdict per graph
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int gl = lane & 15, cq = lane >> 4;                      // B/D operand: graph column, k-row
+  const int g0 = blockIdx.x * G;
+  const int gi = g0 + gl;
+  const bool gvalid = gi < d.B;
+  const int gc = gvalid ? gi : d.B - 1;                          // tail columns replay the last graph, outputs masked
+  const double uniform = 1.0 / 64.0;
+
+  STAMP_DECL
+  ABL_DECL
+  STAMP_START
+  // ---- phase A: indices (range-checked), program image, uniform tiles ----
+  bool ok = true, same = true;
+  for (int i = t; i < G * d.U; i += WG) {
+    const int gg = i / d.U, u = i - gg * d.U;
+    const int v = d.unary_tab[(size_t)min(g0 + gg, d.B - 1) * d.U + u];
+    ok &= (unsigned)v < (unsigned)d.n_unary_tables;
+    utab[i] = v;
+  }
+  for (int i = t; i < G * d.P; i += WG) {
+    const int gg = i / d.P, p = i - gg * d.P;
+    const int v = d.pair_tab[(size_t)min(g0 + gg, d.B - 1) * d.P + p];
+    ok &= (unsigned)v < (unsigned)d.n_pair_tables;
+    same &= v == d.pair_tab[(size_t)g0 * d.P + p];
+    if (gg == 0) ptab[p] = v;
+  }
+  {
+    const int n_img = d.n_ops * 8 + d.n_lists + d.n_cpw + 2 * d.n_back + d.n_fill;
+    for (int i = t; i < n_img; i += WG) img[i] = d.image[i];
+    if (d.marginals)
+      for (int i = t; i < d.n_readout; i += WG) rd[i] = d.readout[i];
+    double2* dst = reinterpret_cast<double2*>(tiles);
+    for (int i = t; i < d.n_live * (TILE / 2); i += WG) dst[i] = make_double2(uniform, uniform);
+    for (int i = t; i < d.n_live * 64; i += WG) tot[i] = 0.25;    // four partials of a total of 1
+    if (t < G) gflag[t] = 0;
+  }
+  if (!__syncthreads_and(ok ? 1 : 0)) {
+    if (t == 0) atomicExch(d.status, 1);
+    return;
+  }
+  if (t == 0) {
+    int nd = 0, over = 0;
+    for (int p = 0; p < d.P; ++p) {
+      int r = 0;
+      while (r < nd && dist[r] != ptab[p]) ++r;
+      if (r == nd) {
+        if (nd < NTAB) dist[nd++] = ptab[p];
+        else { over = 1; r = 0; }
+      }
+      preg[p] = r;
+    }
+    dist[NTAB] = nd; dist[NTAB + 1] = over;
+  }
+  if (!__syncthreads_and(same ? 1 : 0) || dist[NTAB + 1]) {      // not a shared-table batch: exact kernel takes all 16
+    if (t < G && g0 + t < d.B) d.bail[g0 + t] = 4;
+    return;
+  }
+
+  STAMPV(0)
+  // ---- phase B: A fragments of every distinct table, both orientations (lane: row l&15, k l>>4) ----
+  double aTM[NTAB][16], aMT[NTAB][16];
+  const int nd = __builtin_amdgcn_readfirstlane(dist[NTAB]);
+#pragma unroll
+  for (int r = 0; r < NTAB; ++r) {
+    const int ti = __builtin_amdgcn_readfirstlane(dist[r < nd ? r : 0]);
+    const double* T = d.pair_tables + (size_t)ti * 4096;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      aTM[r][s] = T[(16 * wave + gl) * 64 + 4 * s + cq];         // (T.m)[x]  : A[x][y] = T[x][y]
+      aMT[r][s] = T[(4 * s + cq) * 64 + 16 * wave + gl];         // (m^T.T)[x]: A[x][y] = T[y][x]
+    }
+  }
+
+  STAMP(1)
+  // ---- phase C: unary messages (constants) -> one product tile per variable ----
+  // wave w takes graphs 4w..4w+3 with lanes = states.  Loads only (the write-back of these constants is a
+  // separate streaming kernel): every load is unconditional (clamped index) so that the rows of the NEXT
+  // batch stay in flight while the current one is reduced -- the only HBM reads of the kernel that miss L2.
+  {
+    constexpr int HB = 12;
+    const int E = d.n_cpw / 4;
+    double cur = uniform;
+    bool bad = false;
+    double row[HB], nxt[HB];
+    auto fetch = [&](int j4, int e0, double (&r)[HB]) {
+      const int32_t* ut = utab + (4 * wave + j4) * d.U;
+#pragma unroll
+      for (int j = 0; j < HB; ++j)
+        r[j] = d.unary_tables[(size_t)ut[ent[4 * min(e0 + j, E - 1)]] * 64 + lane];
+    };
+    int j4 = 0, e0 = 0;
+    if (E > 0 && !ABL(3)) fetch(0, 0, row);
+    while (j4 < 4 && E > 0) {
+      int nj = j4, ne = e0 + HB;
+      if (ne >= E) { ne = 0; ++nj; }
+      if (!ABL(3)) fetch(min(nj, 3), ne, nxt);
+      const int gg = 4 * wave + j4;
+#pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        if (e0 + j < E) {
+          // The scale of a unary message cancels in everything downstream (only its normalised form is ever
+          // stored, by unary_writeback_kernel), so the raw columns are multiplied and the PRODUCT is
+          // normalised once.  A column Message.renormalize would replace by the uniform vector (total <= 0,
+          // LBP.py:655-657) or that is not a finite non-negative vector sends the graph to the exact kernel.
+          const int flags = __builtin_amdgcn_readfirstlane(ent[4 * (e0 + j) + 3]);
+          if (flags & 1) { cur = 1.0; bad = false; }
+          const double r = row[j];
+          bad |= !(r >= 0.0 && r <= 1e280) || !__any(r > 0.0);
+          cur *= r;
+          if (flags & 2) {
+            const double s = ABL(2) ? 64.0 : wave_sum(cur);
+            bad |= !total_ok(s);
+            if (!ABL(1)) tiles[(size_t)ent[4 * (e0 + j) + 2] * TILE + lane * G + gg] = cur * (1.0 / s);
+            if (__any(bad)) gflag[gg] = 1;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < HB; ++j) row[j] = nxt[j];
+      j4 = nj; e0 = ne;
+    }
+  }
+  if (d.msgs)                                                     // slots the sweeps never touch stay uniform
+    for (int i = t; i < d.n_fill * G * 64; i += WG) {
+      const int x = i & 63, gg = (i >> 6) & (G - 1), k = i >> 10;
+      if (g0 + gg < d.B) d.msgs[((size_t)(g0 + gg) * d.n_msgs + fill[k]) * 64 + x] = uniform;
+    }
+  __syncthreads();
+  bool bad = gflag[gl] != 0;
+  STAMPV(2)
+
+  // ---- main loop: the same in all four waves; one barrier per update ----
+  for (int sw = 0; sw < d.n_sweeps; ++sw) {
+    const int op0 = d.fsweeps[2 * sw], op1 = op0 + d.fsweeps[2 * sw + 1];
+    for (int o = op0; o < op1; ++o) {
+      const int4 h0 = reinterpret_cast<const int4*>(img)[2 * o];
+      const int4 h1 = reinterpret_cast<const int4*>(img)[2 * o + 1];
+      const int kind = __builtin_amdgcn_readfirstlane(h0.x);
+      const int k8 = kind & 0xFF;
+      const int pslot = __builtin_amdgcn_readfirstlane(h1.x), dst = __builtin_amdgcn_readfirstlane(h1.y);
+      double b[16];
+      if (k8 >= FOP_VAR) {
+        // variable -> factor (LBP.py:377-389): constant product (or uniform) times the other incoming messages
+        const int a = __builtin_amdgcn_readfirstlane(h0.y), n = __builtin_amdgcn_readfirstlane(h0.z);
+        {
+          const double* src = tiles + (size_t)lists[a] * TILE + lane;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) b[s] = src[64 * s];
+        }
+        for (int q = 1; q < n && !ABL(7); ++q) {
+          const int tl = __builtin_amdgcn_readfirstlane(lists[a + q]);
+          const double* tp = tot + tl * 64 + gl;
+          const double total = (tp[0] + tp[16]) + (tp[32] + tp[48]);
+          bad |= !total_ok(total);
+          // the scale of this product cancels downstream (every stored message is normalised by its own
+          // total), the factor only keeps the magnitudes in range: the hardware reciprocal is enough
+          const double inv = __builtin_amdgcn_rcp(total);
+          const double* src = tiles + (size_t)tl * TILE + lane;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) b[s] *= src[64 * s] * inv;
+        }
+        STAMP(3)
+        const int ct = __builtin_amdgcn_readfirstlane(h0.w);
+        const bool out_now = (kind & 0x200) && d.msgs && !ABL(4);
+        if (ct >= 0 || out_now || k8 == FOP_VAR) {               // the message itself is wanted: its total too
+          const double part = (((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]))) +
+                              (((b[8] + b[9]) + (b[10] + b[11])) + ((b[12] + b[13]) + (b[14] + b[15])));
+          const double tb = ABL(5) ? 4.0 * part : column_sum(part);
+          bad |= !total_ok(tb);
+          if (ct >= 0) {                                         // read again later: keep it as a tile
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+              if ((s >> 2) == wave) tiles[(size_t)ct * TILE + 64 * s + lane] = b[s];
+            if (cq == 0) tot[ct * 64 + wave * 16 + gl] = 0.25 * tb;
+          } else if (out_now && gvalid && !bad) {                // last value of this slot: straight to HBM
+            double* out = d.msgs + ((size_t)gc * d.n_msgs + __builtin_amdgcn_readfirstlane(h1.z)) * 64 + cq;
+            const double itb = 1.0 / tb;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+              if ((s >> 2) == wave) out[4 * s] = b[s] * itb;
+          }
+        }
+        if (k8 == FOP_VAR) {
+          __syncthreads();
+          continue;
+        }
+      } else {
+        const int tl = __builtin_amdgcn_readfirstlane(h0.y);
+        if (tl >= 0) {
+          const double* tp = tot + tl * 64 + gl;
+          const double total = (tp[0] + tp[16]) + (tp[32] + tp[48]);
+          bad |= !total_ok(total);
+          const double inv = __builtin_amdgcn_rcp(total);
+          const double* src = tiles + (size_t)tl * TILE + lane;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) b[s] = src[64 * s] * inv;
+        } else {                                                 // a message nothing has updated yet (LBP.py:211-216)
+#pragma unroll
+          for (int s = 0; s < 16; ++s) b[s] = uniform;
+        }
+      }
+      STAMP(7)
+      // factor -> variable (LBP.py:500-524): 16 x v_mfma_f64_16x16x4_f64 against the resident fragments
+      const bool mt = (k8 == FOP_PAIR_MT || k8 == FOP_VAR_PAIR_MT);
+      const int sel = __builtin_amdgcn_readfirstlane(preg[pslot]) * 2 + (mt ? 1 : 0);
+      double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      if (ABL(6)) { acc0.x = b[0]; acc0.y = b[5]; acc1.z = b[10]; acc1.w = b[15]; }
+      else if (sel == 0) { MLBP_MFMA16(aTM[0]) }
+      else if (sel == 1) { MLBP_MFMA16(aMT[0]) }
+      else if (NTAB > 1 && sel == 2) { MLBP_MFMA16(aTM[NTAB > 1 ? 1 : 0]) }
+      else if (NTAB > 1 && sel == 3) { MLBP_MFMA16(aMT[NTAB > 1 ? 1 : 0]) }
+      else if (NTAB > 2 && sel == 4) { MLBP_MFMA16(aTM[NTAB > 2 ? 2 : 0]) }
+      else if (NTAB > 2) { MLBP_MFMA16(aMT[NTAB > 2 ? 2 : 0]) }
+      const double4_t acc = acc0 + acc1;
+      double* out = tiles + (size_t)dst * TILE + (16 * wave + cq) * G + gl;     // D: state 16w + (l>>4) + 4r
+      out[0] = acc.x; out[4 * G] = acc.y; out[8 * G] = acc.z; out[12 * G] = acc.w;
+      const double part = column_sum((acc.x + acc.y) + (acc.z + acc.w));
+      if (cq == 0) tot[dst * 64 + wave * 16 + gl] = part;
+      STAMP(4)
+      __syncthreads();
+      STAMP(5)
+    }
+  }
+
+  // ---- epilogue: marginals, message write-back, verdicts ----
+  // a bad total met only here (the last update's result) must reach the verdict of every wave
+  if (d.marginals) {
+    for (int v = wave; v < d.n_vars; v += 4) {
+      const int at = rd[v];
+      const int base = rd[at], n = rd[at + 1];
+      double m[16];
+      if (base >= 0) {
+        const double* src = tiles + (size_t)base * TILE + lane;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) m[s] = src[64 * s];
+      } else {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) m[s] = uniform;
+      }
+      for (int q = 0; q < n; ++q) {
+        const int tl = rd[at + 2 + q];
+        const double* tp = tot + tl * 64 + gl;
+        const double total = (tp[0] + tp[16]) + (tp[32] + tp[48]);
+        bad |= !total_ok(total);
+        const double inv = 1.0 / total;
+        const double* src = tiles + (size_t)tl * TILE + lane;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) m[s] *= src[64 * s] * inv;
+      }
+      double part = 0.0;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) part += m[s];
+      const double tm = column_sum(part);
+      bad |= !total_ok(tm);
+      if (gvalid && !bad) {
+        double* out = d.marginals + ((size_t)gc * d.n_vars + v) * 64 + cq;
+        const double itm = 1.0 / tm;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) out[4 * s] = m[s] * itm;
+      }
+    }
+  }
+  for (int i = wave; i < d.n_back; i += 4) {
+    const int tl = back[2 * i], slot = back[2 * i + 1];
+    const double* tp = tot + tl * 64 + gl;
+    const double total = (tp[0] + tp[16]) + (tp[32] + tp[48]);
+    bad |= !total_ok(total);
+    if (d.msgs && gvalid && !bad) {
+      const double* src = tiles + (size_t)tl * TILE + lane;
+      double* out = d.msgs + ((size_t)gc * d.n_msgs + slot) * 64 + cq;
+      const double inv = 1.0 / total;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) out[4 * s] = src[64 * s] * inv;
+    }
+  }
+  STAMPV(6)
+  STAMP_FLUSH
+  if (bad && gvalid) d.bail[gi] = 2;                             // any wave that saw it says so (idempotent)
+}
+
+// Unary factor -> variable messages are constants (LBP.py:494-498): msgs[g][slot] = renormalize(column).  One
+// wave per (graph, unary factor); pure streaming, enqueued behind the sweep kernel when the caller wants the
+// message buffer filled.
+__global__ __launch_bounds__(WG) void unary_writeback_kernel(const double* unary_tables, const int32_t* unary_tab,
+                                                             const int32_t* ent, int E, int B, int U, int n_unary_tables,
+                                                             int n_msgs, double* msgs) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)B * E) return;
+  const int g = (int)(row / E), e = (int)(row % E);
+  const int ti = unary_tab[(size_t)g * U + ent[4 * e]];
+  if ((unsigned)ti >= (unsigned)n_unary_tables) return;       // the sweep kernel raises the status word for this
+  const double v = unary_tables[(size_t)ti * 64 + lane];
+  const double s = wave_sum(v);
+  msgs[((size_t)g * n_msgs + ent[4 * e + 1]) * 64 + lane] = s > 0.0 ? v * (1.0 / s) : 1.0 / 64.0;
+}
+
+std::mutex g_attr_mutex;
+
+template <int NTAB>
+int launch(const SharedDev& d, size_t lds, hipStream_t st) {
+  static size_t granted = 0;
+  {
+    std::lock_guard<std::mutex> lock(g_attr_mutex);
+    if (lds > granted) {
+      hipError_t e = hipFuncSetAttribute((const void*)sweep_x64_shared_kernel<NTAB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(MLBP_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      granted = lds;
+      int per_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sweep_x64_shared_kernel<NTAB>, WG, lds) == hipSuccess)
+        fail(MLBP_OK, "shared-table kernel <%d>: %zu bytes of LDS per workgroup, %d workgroups per CU", NTAB, lds, per_cu);
+    }
+  }
+  hipLaunchKernelGGL(sweep_x64_shared_kernel<NTAB>, dim3((d.B + G - 1) / G), dim3(WG), lds, st, d);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed: %s", hipGetErrorString(e));
+  return MLBP_OK;
+}
+
+}  // namespace
+
+int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched) {
+  *launched = false;
+  const SharedProgram& sp = prog->shared;
+  if (!(a->flags & MLBP_SWEEP_SHARED_PAIR_TABLES)) return MLBP_OK;
+  if (a->X != 64 || !a->normalize_messages || !a->init_messages)
+    return fail(MLBP_OK, "shared-table kernel not used: needs X = 64, normalize_messages and init_messages");
+  if (!sp.ok || !prog->d_simage) return fail(MLBP_OK, "shared-table kernel not used: %s", sp.why);
+  if (a->marginals && !prog->d_sreadout)
+    return fail(MLBP_OK, "shared-table kernel not used: a variable's constant messages match no folded product");
+  const int n_readout = a->marginals ? prog->n_sreadout : 0;
+  const int ntab = prog->P >= 2 ? 2 : 1;
+  const size_t words = (size_t)sp.off_sweeps + 1 + n_readout + (size_t)G * prog->U + 2 * prog->P + ntab + 2 + G + 8;
+  const size_t lds = ((size_t)sp.n_live * (TILE + 64)) * sizeof(double) + words * sizeof(int32_t);
+  if (lds > 160 * 1024)
+    return fail(MLBP_OK, "shared-table kernel not used: %d live message tiles need %zu bytes of LDS", sp.n_live, lds);
+  mlbp_program* mp = const_cast<mlbp_program*>(prog);
+  if (mp->bail_cap < a->B)
+    if (int e = mlbp_program_reserve(mp, a->B)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(mp->d_bail, 0, (size_t)a->B, st) != hipSuccess) return fail(MLBP_EHIP, "hipMemsetAsync failed");
+  SharedDev d;
+  d.pair_tables = a->pair_tables; d.pair_tab = a->pair_tab; d.unary_tables = a->unary_tables; d.unary_tab = a->unary_tab;
+  d.msgs = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && !a->gradient) ? nullptr : a->msgs;
+  d.marginals = a->marginals; d.status = prog->d_status; d.bail = mp->d_bail;
+  d.image = prog->d_simage; d.fsweeps = prog->d_simage + sp.off_sweeps; d.readout = prog->d_sreadout;
+  d.B = a->B; d.n_sweeps = (int)sp.sweeps.size() / 2; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U;
+  d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables; d.n_vars = prog->n_vars;
+  d.n_ops = sp.n_ops; d.n_live = sp.n_live; d.n_lists = sp.n_lists; d.n_cpw = sp.n_cpw; d.n_back = sp.n_back;
+  d.n_fill = sp.n_fill; d.n_readout = n_readout;
+  int e = ntab == 2 ? launch<2>(d, lds, st) : launch<1>(d, lds, st);
+  if (e) return e;
+  if (d.msgs && sp.n_cpw > 0) {
+    const int E = sp.n_cpw / 4;
+    const long long rows = (long long)a->B * E;
+    hipLaunchKernelGGL(unary_writeback_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(WG), 0, st, a->unary_tables, a->unary_tab,
+                       prog->d_simage + sp.n_ops * 8 + sp.n_lists, E, a->B, prog->U, a->n_unary_tables, prog->n_msgs, a->msgs);
+    if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "unary write-back launch failed");
+  }
+  *launched = true;
+  return MLBP_OK;
+}
+
+#ifdef MLBP_STAMPS
+extern "C" int mlbp_debug_set_shared_stamp_buffer(void* dev_ptr, int ablate_mask) {
+  unsigned long long* p = (unsigned long long*)dev_ptr;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sh_ablate), &ablate_mask, sizeof(int)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_sh_stamp), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
+}  // namespace mlbp

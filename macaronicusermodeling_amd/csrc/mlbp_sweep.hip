@@ -317,8 +317,8 @@ __device__ __forceinline__ void marginals_from_lds_x64(const SweepDev& d, const 
   }
 }
 
-enum { FOP_UNARY = 0, FOP_PAIR_TM = 1, FOP_PAIR_MT = 2, FOP_VAR = 3, FOP_VAR_PAIR_TM = 4, FOP_VAR_PAIR_MT = 5,
-       FOP_BUNDLED = 0x100 /* flag: the next update touches disjoint slots and may share this one's barrier */ };
+using mlbp::FOP_UNARY; using mlbp::FOP_PAIR_TM; using mlbp::FOP_PAIR_MT; using mlbp::FOP_VAR;
+using mlbp::FOP_VAR_PAIR_TM; using mlbp::FOP_VAR_PAIR_MT; using mlbp::FOP_BUNDLED;
 
 struct FusedDev {
   const uint8_t* only;     // when non-NULL: run only graphs with only[g] != 0 (fix-up pass)
@@ -1340,11 +1340,7 @@ __global__ void log_posterior_kernel(const double* marg, const int32_t* labels, 
 }
 
 // Fused program form (see sweep_x64_fused_kernel).  Input: the validated 4-word op list.
-struct FusedProgram {
-  std::vector<int32_t> fops, psrcs, fsweeps, hoist, cpw, pairseq, written;
-  int n_cprod = 0;
-  bool has_unary_fops = false;
-};
+using mlbp::FusedProgram;
 
 void build_fused_program(const int32_t* ops, const int32_t* srcs, const int32_t* sweeps, int n_sweeps, int n_msgs,
                          FusedProgram& out) {
@@ -1484,6 +1480,7 @@ void build_fused_program(const int32_t* ops, const int32_t* srcs, const int32_t*
 // kernel with the default table-residency rule (default), 10+N = fused kernel forcing N resident
 // tables (N = 0 streams).
 int g_sweep_variant = -1;
+thread_local int g_last_kernel = -1;       // mlbp_last_sweep_kernel()
 int sweep_variant() {
   if (g_sweep_variant < 0) {
     const char* e = getenv("MLBP_SWEEP_VARIANT");
@@ -1624,6 +1621,10 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
   p->d_readout = nullptr;
   p->n_vars = 0;
   p->n_readout = 0;
+  p->d_simage = p->d_sreadout = nullptr;
+  p->n_sreadout = 0;
+  mlbp::build_shared_program(fp, n_msgs, P, U, p->shared);
+  if (p->shared.ok && e == hipSuccess) e = up(&p->d_simage, p->shared.image.data(), p->shared.image.size());
   if (e == hipSuccess) e = up(&p->d_fops, image.data(), image.size());
   if (e == hipSuccess) e = up(&p->d_fsweeps, fp.fsweeps.data(), fp.fsweeps.size());
   if (e == hipSuccess) e = up(&p->d_fpairseq, fp.pairseq.data(), fp.pairseq.size());
@@ -1640,6 +1641,7 @@ int mlbp_program_destroy(mlbp_program* p) {
   (void)hipFree(p->d_ops); (void)hipFree(p->d_srcs); (void)hipFree(p->d_sweeps);
   (void)hipFree(p->d_pairseq); (void)hipFree(p->d_status);
   (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq); (void)hipFree(p->d_bail); (void)hipFree(p->d_readout);
+  (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout);
   delete p;
   return MLBP_OK;
 }
@@ -1707,6 +1709,11 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
           gf.grad_en_en = ga->grad_en_en; gf.grad_en_de = ga->grad_en_de; gf.Vde = ga->Vde; gf.enabled = 1;
         }
       }
+      bool shared_done = false;                // shared-table batches: 16 graphs per workgroup on the matrix cores
+      if (variant == 1 || variant == 30)
+        if (int e = mlbp::launch_shared_sweep(prog, a, stream, &shared_done)) return e;
+      if (shared_done) { want_sf = false; grad_fused = false; gf = GradFusedDev{}; }
+      g_last_kernel = shared_done ? MLBP_KERNEL_SHARED_MFMA : (want_sf ? MLBP_KERNEL_SCALE_FREE : MLBP_KERNEL_EXACT);
       if (want_sf) {
         if (mp->bail_cap < a->B)              // not reserved for this batch size: allocate now (a stream-
           if (int e = mlbp_program_reserve(mp, a->B)) return e;   // capturing caller reserves up front instead)
@@ -1729,7 +1736,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
         HIP_TRY(hipGetLastError());
       }
       FusedDev f;
-      f.only = want_sf ? mp->d_bail : nullptr;     // after the scale-free pass: flagged graphs only
+      f.only = (want_sf || shared_done) ? mp->d_bail : nullptr;     // after a fast pass: flagged graphs only
       f.image = prog->d_fops; f.fsweeps = prog->d_fsweeps;
       f.n_fops = prog->n_fops; f.n_psrcs = prog->n_psrcs; f.n_hoist = prog->n_hoist;
       f.n_cprod = prog->n_cprod; f.n_cpw = prog->n_cpw; f.n_ext = n_ext;
@@ -1766,6 +1773,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   if (a->X == 64) {
     size_t lds = ((size_t)prog->n_msgs * 64 + 8 * 64) * sizeof(double);
     if (lds <= LDS_MAX) {
+      g_last_kernel = MLBP_KERNEL_FIRST_GEN;
       auto k = norm ? sweep_x64_kernel<true> : sweep_x64_kernel<false>;
       if (int e = ensure_dynamic_lds((const void*)k, lds)) return e;
       hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, st, d);
@@ -1778,6 +1786,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     }
   }
   if ((a->X == 128 || a->X == 256 || a->X == 512) && variant != 0) {
+    g_last_kernel = MLBP_KERNEL_WIDE;
     const size_t ldsw = ((size_t)6 * a->X + 4) * sizeof(double);
     void (*kw)(SweepDev) = nullptr;
     if (a->X == 128) kw = norm ? sweep_wide_kernel<true, 1> : sweep_wide_kernel<false, 1>;
@@ -1791,6 +1800,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     if (a->gradient) return mlbp_gradient_f64(a->gradient, stream);
     return MLBP_OK;
   }
+  g_last_kernel = MLBP_KERNEL_GENERIC;
   size_t base = ((size_t)a->X + 4) * sizeof(double);
   size_t with_msgs = base + (size_t)prog->n_msgs * a->X * sizeof(double);
   if (with_msgs <= 64 * 1024) {
@@ -1830,6 +1840,7 @@ int mlbp_program_reserve(mlbp_program* p, int32_t max_graphs) {
   p->d_bail = nullptr;
   p->bail_cap = 0;
   HIP_TRY(hipMalloc(&p->d_bail, (size_t)max_graphs));
+  HIP_TRY(hipMemset(p->d_bail, 0, (size_t)max_graphs));     // mlbp_program_exact_count before any fast-path launch reads 0
   p->bail_cap = max_graphs;
   return MLBP_OK;
 }
@@ -1851,15 +1862,26 @@ int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_
   HIP_TRY(hipMemcpy(p->d_readout, img.data(), img.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   p->n_vars = n_vars;
   p->n_readout = (int)img.size();
+  (void)hipFree(p->d_sreadout);
+  p->d_sreadout = nullptr;
+  p->n_sreadout = 0;
+  std::vector<int32_t> simg;
+  if (p->shared.ok && mlbp::build_shared_readout(p->shared, p->n_msgs, n_vars, in_off, in_slots, simg)) {
+    HIP_TRY(hipMalloc(&p->d_sreadout, simg.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p->d_sreadout, simg.data(), simg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    p->n_sreadout = (int)simg.size();
+  }
   return MLBP_OK;
 }
 
 int mlbp_set_sweep_variant(int32_t variant) {
-  const bool known = variant == 0 || variant == 1 || variant == 3 || (variant >= 10 && variant <= 14) || (variant >= 21 && variant <= 24);
+  const bool known = variant == 0 || variant == 1 || variant == 3 || variant == 30 || (variant >= 10 && variant <= 14) || (variant >= 21 && variant <= 24);
   if (!known) return fail(MLBP_EINVAL, "unknown sweep variant %d", variant);
   g_sweep_variant = variant;
   return MLBP_OK;
 }
+
+int mlbp_last_sweep_kernel(void) { return g_last_kernel; }
 
 int mlbp_program_exact_count(const mlbp_program* prog, int32_t B) {
   // Synchronising: how many of the first B graphs of the last default-variant launch were handed
@@ -1871,7 +1893,7 @@ int mlbp_program_exact_count(const mlbp_program* prog, int32_t B) {
   HIP_TRY(hipMemcpy(h.data(), prog->d_bail, (size_t)B, hipMemcpyDeviceToHost));
   int n = 0, hist[4] = {0, 0, 0, 0};
   for (unsigned char c : h) { n += c ? 1 : 0; hist[c & 3]++; }
-  fail(0, "exact-kernel graphs by reason: prologue %d, main loop %d, final pass %d", hist[1], hist[2], hist[3]);
+  fail(0, "exact-kernel graphs by reason: prologue %d, main loop %d, final pass %d (shared-table kernel: 2 = degenerate total, 4 -> counted under 0 = tables not shared)", hist[1], hist[2], hist[3]);
   return n;
 }
 

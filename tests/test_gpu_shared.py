@@ -1,0 +1,147 @@
+"""GPU parity of the shared-table sweep kernel (float64 MFMA, 16 graphs per workgroup; mlbp_shared.hip)
+against the CPU oracle: the reference's own table layout -- one pot_en_en / pot_en_en_w1 array behind every
+pairwise factor (LBP.py:456-467), per-graph unary columns.  Tolerance 1e-10 relative (north star: 1e-5)."""
+import numpy as np
+import pytest
+
+import cases as C
+from helpers import oracle_msgs
+from oracle import lbp_oracle as O
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+KERNEL_SHARED_MFMA, KERNEL_SCALE_FREE = 3, 1
+
+
+def _shared_batch(spec, B, seed=7, mutate=None):
+    """B graphs of one topology: pairwise tables = the two en_en pots of graph 0 (shared by all), unary
+    tables = each graph's own pots (seeded).  Returns (batch, topo, per-graph inputs)."""
+    from macaronicusermodeling_amd.batch import FactorGraphBatch
+    from macaronicusermodeling_amd.topology import GraphTopology
+    topo = GraphTopology.from_spec(spec)
+    X = spec['X']
+    inputs = [C.make_inputs(spec, seed + 1000 * b) for b in range(B)]
+    for b in range(1, B):
+        inputs[b]['pot_en_en'] = inputs[0]['pot_en_en']
+        inputs[b]['pot_en_en_w1'] = inputs[0]['pot_en_en_w1']
+    if mutate:
+        mutate(inputs)
+    g = O.Graph(spec)
+    by_id = {f['id']: f for f in spec['factors']}
+    pair_phi = [0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1 for j in topo.pair_factors]
+    pair = np.stack([inputs[0]['pot_en_en'], inputs[0]['pot_en_en_w1']])
+    unary = np.stack([O.factor_table(g, inputs[b], g.by_id[topo.factor_ids[j]]).reshape(X)
+                      for b in range(B) for j in topo.unary_factors])
+    fb = FactorGraphBatch(topo, X, B)
+    fb.set_pair_tables(pair, np.tile(np.array(pair_phi), (B, 1)))
+    fb.set_unary_tables(unary)
+    assert fb.pair_tables_shared
+    return fb, topo, inputs
+
+
+SPECS = {
+    'user_k3_gaps_3_6': lambda: C.user_spec(10, [1, 4, 7], 64, 64, seed=1),        # one distinct table
+    'user_k3_gaps_1_2_3': lambda: C.user_spec(10, [1, 2, 4], 64, 64, seed=2),      # both en_en pots
+    'user_k2': lambda: C.user_spec(6, [0, 1], 64, 64, seed=3),
+    'user_k4': lambda: C.user_spec(9, [0, 2, 3, 7], 64, 64, seed=4),
+}
+
+
+@pytest.mark.parametrize('name', list(SPECS))
+@pytest.mark.parametrize('B', [1, 37])
+def test_shared_table_kernel_matches_oracle(name, B):
+    from macaronicusermodeling_amd import _ffi
+    spec = SPECS[name]()
+    fb, topo, inputs = _shared_batch(spec, B)
+    roots = [v for v in topo.var_ids][:3]
+    roots = (roots * 3)[:3]
+    marg = torch.full((B, topo.n_vars, 64), float('nan'), dtype=torch.float64, device=fb.device)
+    fb.msgs.fill_(float('nan'))
+    prog = fb.sweep(roots, init=True, marginals=marg)
+    if name == 'user_k4':          # 21 live tiles do not fit LDS: the launch falls back, results must not change
+        assert _ffi.lib.mlbp_last_sweep_kernel() != KERNEL_SHARED_MFMA and b'LDS' in _ffi.lib.mlbp_last_error()
+    else:
+        assert _ffi.lib.mlbp_last_sweep_kernel() == KERNEL_SHARED_MFMA, _ffi.lib.mlbp_last_error()
+    assert prog.status() == 0 and prog.exact_count(B) == 0
+    got, gm = fb.msgs.cpu().numpy(), marg.cpu().numpy()
+    for b in range(B):
+        g, msgs, want = oracle_msgs(spec, inputs[b], roots)
+        np.testing.assert_allclose(got[b], want, rtol=RTOL, atol=1e-300)
+        for k, v in enumerate(topo.var_ids):
+            np.testing.assert_allclose(gm[b, k], O.marginal(g, msgs, v).reshape(-1), rtol=RTOL, atol=1e-300)
+
+
+def test_shared_kernel_agrees_with_exact_kernel_and_skips_writeback_on_request():
+    from macaronicusermodeling_amd import _ffi
+    spec = SPECS['user_k3_gaps_1_2_3']()
+    B = 200
+    fb, topo, _ = _shared_batch(spec, B)
+    roots = [1, 2, 4]
+    m1 = torch.empty(B, topo.n_vars, 64, dtype=torch.float64, device=fb.device)
+    fb.sweep(roots, init=True, marginals=m1)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == KERNEL_SHARED_MFMA
+    msgs1 = fb.msgs.clone()
+    try:
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(3))
+        m3 = torch.empty_like(m1)
+        fb.sweep(roots, init=True, marginals=m3)
+        assert _ffi.lib.mlbp_last_sweep_kernel() == 2
+    finally:
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(1))
+    np.testing.assert_allclose(msgs1.cpu().numpy(), fb.msgs.cpu().numpy(), rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(m1.cpu().numpy(), m3.cpu().numpy(), rtol=1e-11, atol=1e-300)
+    fb.msgs.fill_(-1.0)
+    m2 = torch.empty_like(m1)
+    fb.sweep(roots, init=True, marginals=m2, keep_messages=False)
+    assert torch.equal(m2, m1)
+    assert bool((fb.msgs == -1.0).all())          # nothing was written back
+
+
+def test_degenerate_graphs_in_a_shared_batch_are_redone_exactly():
+    """Zero-sum unary columns (uniform rule, LBP.py:655-657) and inf entries make the graph leave the MFMA
+    kernel; the exact kernel recomputes exactly those graphs."""
+    spec = SPECS['user_k3_gaps_3_6']()
+
+    def mutate(inputs):
+        inputs[5]['pot_en_de'] = inputs[5]['pot_en_de'].copy(); inputs[5]['pot_en_de'][:, :] = 0.0
+        inputs[21]['pot_en_de'] = inputs[21]['pot_en_de'].copy(); inputs[21]['pot_en_de'][3, :] = np.inf
+    B = 40
+    fb, topo, inputs = _shared_batch(spec, B, mutate=mutate)
+    roots = [1, 4, 7]
+    marg = torch.empty(B, topo.n_vars, 64, dtype=torch.float64, device=fb.device)
+    prog = fb.sweep(roots, init=True, marginals=marg)
+    assert prog.exact_count(B) == 2
+    got = fb.msgs.cpu().numpy()
+    with np.errstate(all='ignore'):
+        for b in range(B):
+            _, _, want = oracle_msgs(spec, inputs[b], roots)
+            np.testing.assert_allclose(got[b], want, rtol=RTOL, atol=1e-300)
+
+
+def test_a_wrong_shared_claim_is_caught_on_the_device():
+    """pair_tab rows that differ inside a group of 16 graphs (the caller's flag was wrong) send the group to
+    the exact kernel; results are those of the tables each graph really points at."""
+    spec = SPECS['user_k3_gaps_1_2_3']()
+    B = 48
+    fb, topo, inputs = _shared_batch(spec, B)
+    tab = fb.pair_tab.cpu().numpy().copy()
+    tab[20] = 1 - tab[20]                      # graph 20 swaps the two pots
+    fb.pair_tab = torch.from_numpy(tab).to(fb.device)
+    assert fb.pair_tables_shared               # stale claim, on purpose
+    roots = [1, 2, 4]
+    prog = fb.sweep(roots, init=True)
+    assert prog.exact_count(B) == 16
+    got = fb.msgs.cpu().numpy()
+    for b in (0, 15, 32, 47):                  # graphs of the untouched groups: MFMA kernel, oracle values
+        _, _, want = oracle_msgs(spec, inputs[b], roots)
+        np.testing.assert_allclose(got[b], want, rtol=RTOL, atol=1e-300)
+    from macaronicusermodeling_amd import _ffi
+    try:                                       # every graph, graph 20 included: what the exact kernel computes
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(3))
+        fb.sweep(roots, init=True)
+    finally:
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(1))
+    np.testing.assert_allclose(got, fb.msgs.cpu().numpy(), rtol=1e-11, atol=1e-300)
+    assert not np.allclose(got[20], got[19])

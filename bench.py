@@ -47,20 +47,21 @@ def workload_spec(name):
         return C.chain_spec(8, 64), [0] * 10, 10, 1235
     if name == 'ring8':
         return C.ring_spec(8, 64), [0] * 10, 10, 1235
-    if name == 'ring8_x512':
+    if name in ('ring8_x512', 'ring8_x512_f32'):
         return C.ring_spec(8, 512), [0] * 10, 10, 1238
     raise SystemExit('unknown workload %s' % name)
 
 
-def algorithmic_bytes_per_graph(topo, roots, X, elem=8):
-    """pairwise update (X^2 + 2X) s; variable update (d+1) X s; unary 2X s."""
+def algorithmic_bytes_per_graph(topo, roots, X, elem=8, table_elem=8):
+    """pairwise update (X^2 + 2X) s; variable update (d+1) X s; unary 2X s.  In the
+    float32-table mode the table term counts 4-byte entries, the messages stay float64."""
     from macaronicusermodeling_amd import _ffi
     total = 0
     for r in roots:
         ops, _ = topo.compile_sweep(r)
         for kind, a, b, c in ops.tolist():
             if kind in (_ffi.OP_PAIR_TM, _ffi.OP_PAIR_MT):
-                total += (X * X + 2 * X) * elem
+                total += X * X * table_elem + 2 * X * elem
             elif kind == _ffi.OP_VAR:
                 total += (b + 1) * X * elem
             else:
@@ -130,7 +131,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'chain8', 'ring8', 'ring8_x512'],
+    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32'],
                     help='user_k3_shared = the same graphs with the reference\'s table layout: all graphs share the two '
                          'en_en pots (MFMA kernel, reported against the f64 matrix peak)')
     ap.add_argument('--no-writeback', action='store_true', help='shared workload: skip the message write-back (read-out only)')
@@ -191,6 +192,9 @@ def main():
         by_id = {f['id']: f for f in spec['factors']}
         which = [0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1 for j in topo.pair_factors]
         fb.set_pair_tables(pair, np.tile(np.array(which), (B, 1)))
+    elif a.workload.endswith('_f32'):   # BASELINE config 5: float32 tables (generated in float32: 2 x fewer bytes to hold, too)
+        pair = torch.rand(B * topo.P, X, X, dtype=torch.float32, device=dev, generator=gen) + 0.01
+        fb.set_pair_tables(pair, dtype=torch.float32)
     else:
         pair = torch.rand(B * topo.P, X, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
         fb.set_pair_tables(pair)
@@ -266,7 +270,8 @@ def main():
         iters_per_s = world * (B / 8192.0) * sweeps * a.steps / elapsed
         sweep_ms = sorted(s.elapsed_time(e) for s, e in ev)
         avg_ms = sum(sweep_ms) / len(sweep_ms)
-        alg_bytes = algorithmic_bytes_per_graph(topo, roots, X) * B
+        table_elem = 4 if a.workload.endswith('_f32') else 8
+        alg_bytes = algorithmic_bytes_per_graph(topo, roots, X, table_elem=table_elem) * B
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         used_mfma = shared and _ffi.lib.mlbp_last_sweep_kernel() == 3
         if used_mfma:      # shared-table mode is priced in flops, 2 X^2 per pairwise update and graph
@@ -276,10 +281,10 @@ def main():
             'metric': 'LBP sweep iters/sec (whole node), batch=8192 graphs |X|=64',
             'value': iters_per_s, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': '%s: %d graphs/GPU, |X|=%d, P=%d pairwise + U=%d unary factors, unique f64 '
+            'dtype': 'f64 (f32 tables)' if a.workload.endswith('_f32') else 'f64', 'data': 'synthetic',
+            'config': {'workload': '%s: %d graphs/GPU, |X|=%d, P=%d pairwise + U=%d unary factors, unique %s '
                                    'table per (graph,factor)%s, step = initialize + %d sweeps + posterior read-out'
-                                   % (a.workload, B, X, topo.P, topo.U, ' EXCEPT the pairwise tables: two pots shared by all graphs' if shared else '', sweeps),
+                                   % (a.workload, B, X, topo.P, topo.U, 'f32 pairwise / f64 unary' if a.workload.endswith('_f32') else 'f64', ' EXCEPT the pairwise tables: two pots shared by all graphs' if shared else '', sweeps),
                        'graphs_per_gpu': B, 'X': X, 'sweeps_per_step': sweeps, 'roots': list(roots),
                        'graph_sweeps_per_s': world * B * sweeps * a.steps / elapsed,
                        'parallelism': 'graphs sharded over %d GPU(s), no data-path collective; one all-reduce of the '

@@ -170,6 +170,9 @@ typedef struct mlbp_sweep_args {
                                  pairwise factors and the transposed feature tensors are given;
                                  otherwise by mlbp_gradient_f64 enqueued behind the sweeps            */
   int32_t flags;              /* MLBP_SWEEP_* bits, 0 = none                                        */
+  const float* pair_tables_f32;
+                              /* device [n_pair_tables][X][X] float32, read instead of pair_tables
+                                 when MLBP_SWEEP_PAIR_TABLES_F32 is set                             */
 } mlbp_sweep_args;
 
 /* flags: the caller states that pair_tab[b][p] is the same for every graph b (the reference's own
@@ -183,6 +186,10 @@ typedef struct mlbp_sweep_args {
 /* flags: with MLBP_SWEEP_SHARED_PAIR_TABLES and a fused read-out (marginals != NULL) the messages
  * need not be written back to msgs (ignored when a gradient is requested, which reads them). */
 #define MLBP_SWEEP_NO_MESSAGE_WRITEBACK 2
+/* flags: the pairwise tables are float32 (pair_tables_f32): the optional large-state mode of BASELINE
+ * config 5 -- half the HBM bytes per update.  X = 256 or 512; messages, products and sums stay float64, so
+ * results equal the float64 path run on the float32-rounded tables; no gradient in this mode. */
+#define MLBP_SWEEP_PAIR_TABLES_F32 4
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
 

@@ -45,11 +45,12 @@ class SweepArgs(C.Structure):
                 ('n_unary_tables', C.c_int32), ('pair_tables', C.c_void_p), ('pair_tab', C.c_void_p),
                 ('unary_tables', C.c_void_p), ('unary_tab', C.c_void_p), ('msgs', C.c_void_p),
                 ('normalize_messages', C.c_int32), ('init_messages', C.c_int32), ('marginals', C.c_void_p), ('gradient', C.c_void_p),
-                ('flags', C.c_int32)]
+                ('flags', C.c_int32), ('pair_tables_f32', C.c_void_p)]
 
 
 SWEEP_SHARED_PAIR_TABLES = 1      # include/mlbp.h MLBP_SWEEP_*
 SWEEP_NO_MESSAGE_WRITEBACK = 2
+SWEEP_PAIR_TABLES_F32 = 4
 
 
 _i32p = C.POINTER(C.c_int32)

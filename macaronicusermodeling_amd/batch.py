@@ -83,11 +83,16 @@ class FactorGraphBatch:
             raise IndexError('%s index out of range [0, %d)' % (what, limit))
         return torch.from_numpy(idx.astype(np.int32)).to(device)
 
-    def set_pair_tables(self, tables, pair_tab=None):
+    def set_pair_tables(self, tables, pair_tab=None, dtype=torch.float64):
         """tables: [n][X][X] float64 (numpy or torch; copied to the device if needed).
         pair_tab: [B][P] integer table index per graph and pair slot; default = unique tables
-        b*P + p."""
-        t = torch.as_tensor(tables, dtype=torch.float64).to(self.device).contiguous()
+        b*P + p.  dtype=torch.float32 keeps the tables in float32 on the device (X = 256 or 512 only:
+        the large-state mode, half the bytes per update; sweeps and marginals only)."""
+        if dtype not in (torch.float64, torch.float32):
+            raise TypeError('pair tables are float64 or float32')
+        if dtype == torch.float32 and self.X not in (256, 512):
+            raise ValueError('float32 pair tables need X = 256 or 512')
+        t = torch.as_tensor(tables).to(self.device).to(dtype).contiguous()
         if t.dim() != 3 or t.shape[1] != self.X or t.shape[2] != self.X:
             raise ValueError('pair tables must be [n][X][X]')
         if pair_tab is None:
@@ -142,7 +147,12 @@ class FactorGraphBatch:
             if self.pair_tables is None:
                 raise RuntimeError('set_pair_tables() first')
             a.n_pair_tables = self.pair_tables.shape[0]
-            a.pair_tables, a.pair_tab = self.pair_tables.data_ptr(), self.pair_tab.data_ptr()
+            a.pair_tab = self.pair_tab.data_ptr()
+            if self.pair_tables.dtype == torch.float32:
+                a.pair_tables_f32 = self.pair_tables.data_ptr()
+                a.flags |= _ffi.SWEEP_PAIR_TABLES_F32
+            else:
+                a.pair_tables = self.pair_tables.data_ptr()
         if self.topo.U:
             if self.unary_tables is None:
                 raise RuntimeError('set_unary_tables() first')
@@ -201,6 +211,10 @@ class FactorGraphBatch:
         return out
 
     # ---- beliefs / gradient (LBP.py:528-619, 301-320) ---------------------------------------------
+    def _need_f64_tables(self, what):
+        if self.pair_tables is not None and self.pair_tables.dtype != torch.float64:
+            raise NotImplementedError('%s needs float64 pairwise tables' % what)
+
     def _pair_slots(self):
         """device int32 [P] message slots of the dim-0 / dim-1 variable -> factor messages."""
         if not hasattr(self, '_c_slot'):
@@ -215,6 +229,7 @@ class FactorGraphBatch:
         return self._c_slot, self._r_slot
 
     def pair_beliefs(self):
+        self._need_f64_tables('pair_beliefs')
         """[B][P][X][X]: FactorNode.get_factor_beliefs of every pairwise factor (LBP.py:543-569)."""
         c, r = self._pair_slots()
         out = torch.empty(self.B, self.topo.P, self.X, self.X, dtype=torch.float64, device=self.device)
@@ -275,6 +290,7 @@ class FactorGraphBatch:
         self._unary_obs = torch.from_numpy(np.ascontiguousarray(obs if topo.U else np.zeros((B, 1))).astype(np.int32)).to(dev)
 
     def _gradient_args(self, out_ee, out_ed):
+        self._need_f64_tables('the gradient')
         topo = self.topo
         F_ee, F_ed = int(self.phi_en_en.shape[2]), int(self.phi_en_de.shape[2])
         if tuple(out_ee.shape) != (self.B, F_ee) or tuple(out_ed.shape) != (self.B, F_ed):

@@ -1176,9 +1176,26 @@ __global__ __launch_bounds__(WG) void sweep_generic_kernel(SweepDev d) {
 // Messages stay in global memory (L2 resident; 4 KiB against a 2 MiB table at X = 512).
 // Algorithmic bytes per pairwise update (X*X + 2X) * 8 -- HBM-bound.
 // ------------------------------------------------------------------------------------------------
-template <bool NORM, int Q>
+// Table element type TT: double (V = 2 columns per lane and piece) or float (V = 4, the optional f32
+// table mode of SURVEY.md section 8 / BASELINE config 5: half the bytes per update; products and sums stay
+// in float64, so the only difference from the f64 path is the rounding of the table entries themselves).
+template <typename TT, int V> struct WidePiece;
+template <> struct WidePiece<double, 2> {
+  __device__ static __forceinline__ void load(const double* row, int idx, double (&o)[2]) {
+    const double2 v = reinterpret_cast<const double2*>(row)[idx];
+    o[0] = v.x; o[1] = v.y;
+  }
+};
+template <> struct WidePiece<float, 4> {
+  __device__ static __forceinline__ void load(const float* row, int idx, double (&o)[4]) {
+    const float4 v = reinterpret_cast<const float4*>(row)[idx];
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+};
+
+template <bool NORM, int Q, typename TT, int V>
 __global__ __launch_bounds__(WG) void sweep_wide_kernel(SweepDev d) {
-  constexpr int X = 128 * Q;
+  constexpr int X = 64 * V * Q;
   extern __shared__ double lds[];
   double* vin = lds;             // [X] input message of the update in flight
   double* raw = lds + X;         // [X] un-normalised result
@@ -1196,27 +1213,31 @@ __global__ __launch_bounds__(WG) void sweep_wide_kernel(SweepDev d) {
     for (int o = op0; o < op0 + nop; ++o) {
       const int kind = c_ops[4 * o], a = c_ops[4 * o + 1], b = c_ops[4 * o + 2], c = c_ops[4 * o + 3];
       if (kind == MLBP_OP_PAIR_TM || kind == MLBP_OP_PAIR_MT) {
-        const double* T = d.pair_tables + (size_t)ptab[a] * X * X;
+        const TT* T = reinterpret_cast<const TT*>(d.pair_tables) + (size_t)ptab[a] * X * X;
         const double* m = gm + (size_t)b * X;
         for (int j = t; j < X; j += WG) vin[j] = m[j];
         __syncthreads();
         if (kind == MLBP_OP_PAIR_TM) {
-          double2 mj[Q];
+          double mj[Q][V];
 #pragma unroll
-          for (int q = 0; q < Q; ++q) mj[q] = reinterpret_cast<const double2*>(vin)[64 * q + lane];
+          for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int e = 0; e < V; ++e) mj[q][e] = vin[64 * V * q + V * lane + e];
           for (int i0 = wave; i0 < X; i0 += 16) {          // rows i0, i0+4, i0+8, i0+12 of this wave
-            double2 r[4][Q];
+            double r[4][Q][V];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
               for (int q = 0; q < Q; ++q)
-                r[u][q] = reinterpret_cast<const double2*>(T + (size_t)(i0 + 4 * u) * X)[64 * q + lane];
+                WidePiece<TT, V>::load(T + (size_t)(i0 + 4 * u) * X, 64 * q + lane, r[u][q]);
             double v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               double acc = 0.0;
 #pragma unroll
-              for (int q = 0; q < Q; ++q) acc += r[u][q].x * mj[q].x + r[u][q].y * mj[q].y;
+              for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc += r[u][q][e] * mj[q][e];
               v[u] = acc;
             }
             // 4 values x 64 lanes -> 4 row sums: transposing butterfly inside each 16-lane row (4 -> 2
@@ -1246,29 +1267,32 @@ __global__ __launch_bounds__(WG) void sweep_wide_kernel(SweepDev d) {
             }
           }
         } else {
-          double2 acc[Q];
+          double acc[Q][V];
 #pragma unroll
-          for (int q = 0; q < Q; ++q) acc[q] = make_double2(0.0, 0.0);
+          for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[q][e] = 0.0;
           for (int i0 = wave; i0 < X; i0 += 16) {
-            double2 r[4][Q];
+            double r[4][Q][V];
             double mi[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               mi[u] = vin[i0 + 4 * u];
 #pragma unroll
               for (int q = 0; q < Q; ++q)
-                r[u][q] = reinterpret_cast<const double2*>(T + (size_t)(i0 + 4 * u) * X)[64 * q + lane];
+                WidePiece<TT, V>::load(T + (size_t)(i0 + 4 * u) * X, 64 * q + lane, r[u][q]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-              for (int q = 0; q < Q; ++q) {
-                acc[q].x += mi[u] * r[u][q].x;
-                acc[q].y += mi[u] * r[u][q].y;
-              }
+              for (int q = 0; q < Q; ++q)
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[q][e] += mi[u] * r[u][q][e];
           }
 #pragma unroll
-          for (int q = 0; q < Q; ++q) reinterpret_cast<double2*>(part + wave * X)[64 * q + lane] = acc[q];
+          for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int e = 0; e < V; ++e) part[wave * X + 64 * V * q + V * lane + e] = acc[q][e];
           __syncthreads();
           for (int j = t; j < X; j += WG) raw[j] = (part[j] + part[X + j]) + (part[2 * X + j] + part[3 * X + j]);
         }
@@ -1650,7 +1674,8 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   if (!prog || !a) return fail(MLBP_EINVAL, "mlbp_sweep_f64: NULL program or args");
   if (a->B <= 0 || a->X <= 0) return fail(MLBP_EINVAL, "mlbp_sweep_f64: B=%d X=%d", a->B, a->X);
   if (!a->msgs) return fail(MLBP_EINVAL, "mlbp_sweep_f64: msgs is NULL");
-  if (prog->P > 0 && (!a->pair_tables || !a->pair_tab || a->n_pair_tables <= 0))
+  if (prog->P > 0 && (!((a->flags & MLBP_SWEEP_PAIR_TABLES_F32) ? (const void*)a->pair_tables_f32 : (const void*)a->pair_tables) ||
+                      !a->pair_tab || a->n_pair_tables <= 0))
     return fail(MLBP_EINVAL, "mlbp_sweep_f64: program has %d pairwise factors but no pair tables", prog->P);
   if (prog->U > 0 && (!a->unary_tables || !a->unary_tab || a->n_unary_tables <= 0))
     return fail(MLBP_EINVAL, "mlbp_sweep_f64: program has %d unary factors but no unary tables", prog->U);
@@ -1785,13 +1810,22 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       return MLBP_OK;
     }
   }
-  if ((a->X == 128 || a->X == 256 || a->X == 512) && variant != 0) {
+  const bool f32_tables = (a->flags & MLBP_SWEEP_PAIR_TABLES_F32) != 0;
+  if (f32_tables && !(a->X == 256 || a->X == 512))
+    return fail(MLBP_EUNSUPPORTED, "mlbp_sweep_f64: float32 pairwise tables need X = 256 or 512 (got %d)", a->X);
+  if (f32_tables && a->gradient)
+    return fail(MLBP_EUNSUPPORTED, "mlbp_sweep_f64: no gradient with float32 pairwise tables");
+  if ((a->X == 128 || a->X == 256 || a->X == 512) && (variant != 0 || f32_tables)) {
     g_last_kernel = MLBP_KERNEL_WIDE;
     const size_t ldsw = ((size_t)6 * a->X + 4) * sizeof(double);
     void (*kw)(SweepDev) = nullptr;
-    if (a->X == 128) kw = norm ? sweep_wide_kernel<true, 1> : sweep_wide_kernel<false, 1>;
-    else if (a->X == 256) kw = norm ? sweep_wide_kernel<true, 2> : sweep_wide_kernel<false, 2>;
-    else kw = norm ? sweep_wide_kernel<true, 4> : sweep_wide_kernel<false, 4>;
+    if (f32_tables) {
+      d.pair_tables = reinterpret_cast<const double*>(a->pair_tables_f32);
+      if (a->X == 256) kw = norm ? sweep_wide_kernel<true, 1, float, 4> : sweep_wide_kernel<false, 1, float, 4>;
+      else kw = norm ? sweep_wide_kernel<true, 2, float, 4> : sweep_wide_kernel<false, 2, float, 4>;
+    } else if (a->X == 128) kw = norm ? sweep_wide_kernel<true, 1, double, 2> : sweep_wide_kernel<false, 1, double, 2>;
+    else if (a->X == 256) kw = norm ? sweep_wide_kernel<true, 2, double, 2> : sweep_wide_kernel<false, 2, double, 2>;
+    else kw = norm ? sweep_wide_kernel<true, 4, double, 2> : sweep_wide_kernel<false, 4, double, 2>;
     hipLaunchKernelGGL(kw, dim3(a->B), dim3(WG), ldsw, st, d);
     HIP_TRY(hipGetLastError());
     if (a->marginals)

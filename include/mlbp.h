@@ -190,6 +190,8 @@ typedef struct mlbp_sweep_args {
  * config 5 -- half the HBM bytes per update.  X = 256 or 512; messages, products and sums stay float64, so
  * results equal the float64 path run on the float32-rounded tables; no gradient in this mode. */
 #define MLBP_SWEEP_PAIR_TABLES_F32 4
+/* with MLBP_SWEEP_NO_MESSAGE_WRITEBACK and a gradient request only the variable->factor messages the
+ * gradient reads are written back (shared-table kernel). */
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
 
@@ -283,8 +285,28 @@ typedef struct mlbp_gradient_args {
                                 /* plane with the same 16-byte-per-lane pattern as its table           */
   double* grad_en_en;           /* out [B][F_ee]                                                    */
   double* grad_en_de;           /* out [B][F_ed]                                                    */
+  int32_t flags;                /* MLBP_GRADIENT_* bits                                              */
+  const double* unary_expect;   /* optional [n_unary_tables][8] from mlbp_unary_expectations_f64: with
+                                   MLBP_GRADIENT_SHARED_PAIR_TABLES the unary factors then cost one
+                                   gather per factor instead of a reduction over the states           */
 } mlbp_gradient_args;
+/* flags: pair_tab[b][p] is the same for every graph b (see MLBP_SWEEP_SHARED_PAIR_TABLES).  With X = 64,
+ * F_ee = 3 and the planar feature copies given, the pairwise factors of 16 graphs at a time are then
+ * contracted on the matrix cores ((T (.) phi_k) . r, four contractions per factor).  Groups of graphs for
+ * which the claim does not hold are skipped and raise mlbp_gradient_status. */
+#define MLBP_GRADIENT_SHARED_PAIR_TABLES 1
 int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream);
+
+/* A unary factor's belief is normalize(table) (LBP.py:540) whatever the messages say, so its expected
+ * features  E[row][k] = sum_x b_x phi[x][obs][k]  depend on the table ROW only; when many factors share
+ * rows (the reference's layout: rows are columns of the shared pots) they are worth computing once per
+ * row.  row_kind / row_obs: DEVICE int32 [n_rows], the phi selector (0 / 1 / 2) and observed column every
+ * user of that row has; phi_*_t as in mlbp_gradient_args ([column][x][F]); out: [n_rows][8] (first F used).
+ * Rows with an out-of-range kind or column are skipped and raise mlbp_gradient_status. */
+int mlbp_unary_expectations_f64(const double* unary_tables, int32_t n_rows, int32_t X, const int32_t* row_kind,
+                                const int32_t* row_obs, const double* phi_en_en_t, const double* phi_en_en_w1_t,
+                                const double* phi_en_de_t, int32_t F_ee, int32_t F_ed, int32_t Vde, double* out,
+                                void* stream);
 int mlbp_gradient_status(void); /* synchronising read-and-reset: 1 = some factor was skipped        */
 
 /* Per-instance sparse feature planes (train_mp.py:178-217: 'correct', 'full_history', 'hit_history'

@@ -37,7 +37,7 @@ class GradientArgs(C.Structure):
                 ('unary_label', C.c_void_p), ('phi_en_en', C.c_void_p), ('phi_en_en_w1', C.c_void_p),
                 ('phi_en_de', C.c_void_p), ('phi_en_en_t', C.c_void_p), ('phi_en_en_w1_t', C.c_void_p),
                 ('phi_en_de_t', C.c_void_p), ('phi_en_en_p', C.c_void_p), ('phi_en_en_w1_p', C.c_void_p),
-                ('grad_en_en', C.c_void_p), ('grad_en_de', C.c_void_p)]
+                ('grad_en_en', C.c_void_p), ('grad_en_de', C.c_void_p), ('flags', C.c_int32), ('unary_expect', C.c_void_p)]
 
 
 class SweepArgs(C.Structure):
@@ -51,6 +51,7 @@ class SweepArgs(C.Structure):
 SWEEP_SHARED_PAIR_TABLES = 1      # include/mlbp.h MLBP_SWEEP_*
 SWEEP_NO_MESSAGE_WRITEBACK = 2
 SWEEP_PAIR_TABLES_F32 = 4
+GRADIENT_SHARED_PAIR_TABLES = 1
 
 
 _i32p = C.POINTER(C.c_int32)
@@ -83,6 +84,7 @@ SIGNATURES = {
     'mlbp_pair_beliefs_f64': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     'mlbp_gradient_f64': (C.c_int, [C.POINTER(GradientArgs), _vp]),
     'mlbp_gradient_status': (C.c_int, []),
+    'mlbp_unary_expectations_f64': (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     'mlbp_patch_unary_tables_f64': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     'mlbp_patch_gradient_f64': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     'mlbp_sum_rows_f64': (C.c_int, [_vp, _i64, _i32, _vp, _vp]),

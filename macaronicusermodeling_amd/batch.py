@@ -163,7 +163,7 @@ class FactorGraphBatch:
         a.init_messages = 1 if init else 0
         if getattr(self, 'pair_tables_shared', False):
             a.flags |= _ffi.SWEEP_SHARED_PAIR_TABLES
-            if not keep_messages and marginals is not None:
+            if not keep_messages and (marginals is not None or gradient is not None):
                 a.flags |= _ffi.SWEEP_NO_MESSAGE_WRITEBACK
         if marginals is not None:
             if tuple(marginals.shape) != (self.B, self.topo.n_vars, self.X) or marginals.dtype != torch.float64:
@@ -289,6 +289,35 @@ class FactorGraphBatch:
         self._unary_label = torch.from_numpy(ul).to(dev)
         self._unary_obs = torch.from_numpy(np.ascontiguousarray(obs if topo.U else np.zeros((B, 1))).astype(np.int32)).to(dev)
 
+    def set_unary_rows(self, row_kind, row_obs):
+        """States, per row of the unary table array, the phi selector (0 / 1 / 2) and observed column of every
+        factor that reads the row.  With shared pairwise tables the gradient then computes each row's expected
+        features once (mlbp_unary_expectations_f64) and gathers them per factor."""
+        n = int(self.unary_tables.shape[0])
+        rk = np.asarray(row_kind, dtype=np.int32).reshape(-1)
+        ro = np.asarray(row_obs, dtype=np.int32).reshape(-1)
+        if rk.shape[0] != n or ro.shape[0] != n:
+            raise ValueError('need one (kind, column) per unary table row')
+        self._row_kind = torch.from_numpy(rk).to(self.device)
+        self._row_obs = torch.from_numpy(ro).to(self.device)
+        self._uexp = torch.zeros(n, 8, dtype=torch.float64, device=self.device)
+
+    def _derive_unary_rows(self):
+        """set_unary_rows() from (unary_tab, unary_kind, unary_obs) when every row has ONE (kind, column)."""
+        if getattr(self, '_row_kind', None) is not None or not self.topo.U or self.X != 64:
+            return
+        tab = self.unary_tab.cpu().numpy().astype(np.int64)
+        obs = self._unary_obs.cpu().numpy().astype(np.int64)
+        kind = np.tile(np.asarray(self._unary_kind_host, dtype=np.int64), (self.B, 1))
+        n = int(self.unary_tables.shape[0])
+        rk, ro = np.full(n, -1, dtype=np.int64), np.full(n, -1, dtype=np.int64)
+        rk[tab.ravel()], ro[tab.ravel()] = kind.ravel(), obs.ravel()
+        if not ((rk[tab] == kind).all() and (ro[tab] == obs).all()):
+            self._row_kind = False                      # a row is read with two different columns: no shortcut
+            return
+        rk[rk < 0], ro[ro < 0] = 0, 0
+        self.set_unary_rows(rk, ro)
+
     def _gradient_args(self, out_ee, out_ed):
         self._need_f64_tables('the gradient')
         topo = self.topo
@@ -316,6 +345,15 @@ class FactorGraphBatch:
         if getattr(self, 'use_planar', True):
             a.phi_en_en_p, a.phi_en_en_w1_p = (p.data_ptr() for p in self._phi_p)
         a.grad_en_en, a.grad_en_de = out_ee.data_ptr(), out_ed.data_ptr()
+        if getattr(self, 'pair_tables_shared', False) and getattr(self, 'use_shared_gradient', True):
+            a.flags |= _ffi.GRADIENT_SHARED_PAIR_TABLES
+            self._derive_unary_rows()
+            if getattr(self, '_row_kind', None) is not None and self._row_kind is not False and F_ee == 3 and F_ed == 6:
+                _ffi.check(_ffi.lib.mlbp_unary_expectations_f64(
+                    self.unary_tables.data_ptr(), int(self.unary_tables.shape[0]), self.X, self._row_kind.data_ptr(),
+                    self._row_obs.data_ptr(), self._phi_t[0].data_ptr(), self._phi_t[1].data_ptr(), self._phi_t[2].data_ptr(),
+                    F_ee, F_ed, int(self.phi_en_de.shape[1]), self._uexp.data_ptr(), _stream_ptr(self.device)))
+                a.unary_expect = self._uexp.data_ptr()
         return a
 
     def gradient(self, out_ee=None, out_ed=None):

@@ -49,6 +49,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 struct GradDev {
   mlbp_gradient_args a;
   int32_t* status;
+  int32_t skip_pairs;      // the pairwise factors are handled by the shared-table (MFMA) kernel
 };
 
 // sums[0..n) over the workgroup; result valid in every thread.  scratch: [4][FMAX+1] doubles.
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(WG) void gradient_x64_kernel(GradDev d) {
   double gee[FEE];
 #pragma unroll
   for (int k = 0; k < FEE; ++k) gee[k] = 0.0;
-  for (int p = 0; p < a.P; ++p) pair_gradient_x64<FEE>(d, g, p, scratch, gee);
+  for (int p = 0; p < a.P && !d.skip_pairs; ++p) pair_gradient_x64<FEE>(d, g, p, scratch, gee);
   double uee[FEE], ued[FED];
 #pragma unroll
   for (int k = 0; k < FEE; ++k) uee[k] = 0.0;
@@ -297,6 +298,28 @@ __global__ __launch_bounds__(WG) void gradient_x64_kernel(GradDev d) {
     for (int k = 0; k < FED; ++k)
       a.grad_en_de[(size_t)g * FED + k] =
           (wave_out[0][FMAX + k] + wave_out[1][FMAX + k]) + (wave_out[2][FMAX + k] + wave_out[3][FMAX + k]);
+  }
+}
+
+// E[row][k] = sum_x normalize(row)[x] * phi_t[obs][x][k]: one wave per table row (X = 64), see mlbp.h.
+__global__ __launch_bounds__(WG) void unary_expectations_kernel(const double* tables, int n_rows, const int32_t* row_kind,
+                                                                const int32_t* row_obs, const double* t_ee, const double* t_w1,
+                                                                const double* t_ed, int F_ee, int F_ed, int Vde, double* out,
+                                                                int32_t* status) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const int kind = row_kind[row], obs = row_obs[row];
+  const int F = kind == 2 ? F_ed : F_ee;
+  if ((unsigned)kind > 2u || (unsigned)obs >= (unsigned)(kind == 2 ? Vde : 64)) {
+    if (lane == 0) atomicExch(status, 1);
+    return;
+  }
+  const double* ph = (kind == 2 ? t_ed : (kind ? t_w1 : t_ee)) + ((size_t)obs * 64 + lane) * F;
+  const double w = tables[(size_t)row * 64 + lane];
+  const double Z = wave_sum(w);
+  for (int f = 0; f < F; ++f) {
+    const double e = wave_sum(w * ph[f]);
+    if (lane == 0) out[(size_t)row * 8 + f] = Z > 0.0 ? e / Z : 0.0;          // au.normalize: zero-sum -> 0
   }
 }
 
@@ -330,21 +353,43 @@ __global__ __launch_bounds__(WG) void pair_beliefs_kernel(const double* msgs, in
   for (int e = threadIdx.x; e < X * X; e += WG) o[e] = Z > 0.0 ? o[e] / Z : 0.0;
 }
 
-// out[j] = sum_b in[b][j]; deterministic (fixed order), one workgroup.
+// out[j] = sum_b in[b][j], deterministic (fixed order): SUM_PARTS workgroups each reduce a contiguous slice of
+// the rows to one partial per column, the last one to finish (device-wide counter) adds the partials in
+// slice order.  One launch, no host round trip, the same bits on every run.
+constexpr int SUM_PARTS = 64;
+__device__ double g_sum_partials[SUM_PARTS * 64];
+__device__ unsigned g_sum_done = 0;
+
 __global__ __launch_bounds__(WG) void sum_rows_kernel(const double* in, int64_t rows, int cols, double* out) {
   __shared__ double part[WG];
+  __shared__ bool last;
+  const int64_t per = (rows + SUM_PARTS - 1) / SUM_PARTS;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
   for (int j = 0; j < cols; ++j) {
     double acc = 0.0;
-    for (int64_t b = threadIdx.x; b < rows; b += WG) acc += in[b * cols + j];
+    for (int64_t b = r0 + threadIdx.x; b < r1; b += WG) acc += in[b * cols + j];
     part[threadIdx.x] = acc;
     __syncthreads();
     for (int s = WG / 2; s > 0; s >>= 1) {
       if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
       __syncthreads();
     }
-    if (threadIdx.x == 0) out[j] = part[0];
+    if (threadIdx.x == 0) g_sum_partials[blockIdx.x * 64 + j] = part[0];
     __syncthreads();
   }
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(&g_sum_done, 1u) == SUM_PARTS - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x < cols) {
+    double acc = 0.0;
+    for (int q = 0; q < SUM_PARTS; ++q) acc += __builtin_nontemporal_load(&g_sum_partials[q * 64 + threadIdx.x]);
+    out[threadIdx.x] = acc;
+  }
+  if (threadIdx.x == 0) g_sum_done = 0;                       // ready for the next (stream-ordered) launch
 }
 
 
@@ -429,18 +474,42 @@ int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream) {
   if (int e = need_device()) return e;
   GradDev d;
   d.a = *a;
+  d.skip_pairs = 0;
   if (int e = status_word(&d.status)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (a->X == 64) {
+    // shared pairwise tables: the pairwise factors of 16 graphs at a time on the matrix cores, after the unary part
+    const bool shared = (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->F_ee == 3 && a->P > 0 && a->P <= 16 && a->phi_en_en_p && a->phi_en_en_w1_p;
+    d.skip_pairs = shared ? 1 : 0;
+    if (shared && a->unary_expect && a->F_ed == 6)               // unary part by gather inside the pair kernel
+      return mlbp::launch_shared_pair_gradient(a, d.status, stream);
     if (a->F_ee == 3) hipLaunchKernelGGL((gradient_x64_kernel<3, 6>), dim3(a->B), dim3(WG), 0, st, d);
     else if (a->F_ee == 2) hipLaunchKernelGGL((gradient_x64_kernel<2, 2>), dim3(a->B), dim3(WG), 0, st, d);
     else hipLaunchKernelGGL((gradient_x64_kernel<1, 1>), dim3(a->B), dim3(WG), 0, st, d);
     HIP_TRY(hipGetLastError());
+    if (shared) return mlbp::launch_shared_pair_gradient(a, d.status, stream);
     return MLBP_OK;
   }
   if (a->F_ee == 3) hipLaunchKernelGGL((gradient_kernel<3, 6>), dim3(a->B), dim3(WG), 0, st, d);
   else if (a->F_ee == 2) hipLaunchKernelGGL((gradient_kernel<2, 2>), dim3(a->B), dim3(WG), 0, st, d);
   else hipLaunchKernelGGL((gradient_kernel<1, 1>), dim3(a->B), dim3(WG), 0, st, d);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_unary_expectations_f64(const double* unary_tables, int32_t n_rows, int32_t X, const int32_t* row_kind,
+                                const int32_t* row_obs, const double* phi_en_en_t, const double* phi_en_en_w1_t,
+                                const double* phi_en_de_t, int32_t F_ee, int32_t F_ed, int32_t Vde, double* out,
+                                void* stream) {
+  if (!unary_tables || !row_kind || !row_obs || !phi_en_en_t || !phi_en_en_w1_t || !phi_en_de_t || !out || n_rows <= 0 ||
+      F_ee <= 0 || F_ee > 8 || F_ed <= 0 || F_ed > 8 || Vde <= 0)
+    return fail(MLBP_EINVAL, "mlbp_unary_expectations_f64: bad arguments");
+  if (X != 64) return fail(MLBP_EUNSUPPORTED, "mlbp_unary_expectations_f64: X = %d (only 64)", X);
+  if (int e = need_device()) return e;
+  int32_t* status = nullptr;
+  if (int e = status_word(&status)) return e;
+  hipLaunchKernelGGL(unary_expectations_kernel, dim3((n_rows + 3) / 4), dim3(WG), 0, (hipStream_t)stream, unary_tables, n_rows,
+                     row_kind, row_obs, phi_en_en_t, phi_en_en_w1_t, phi_en_de_t, F_ee, F_ed, Vde, out, status);
   HIP_TRY(hipGetLastError());
   return MLBP_OK;
 }
@@ -462,7 +531,9 @@ int mlbp_pair_beliefs_f64(const double* msgs, int32_t B, int32_t n_msgs, int32_t
 int mlbp_sum_rows_f64(const double* in, int64_t rows, int32_t cols, double* out, void* stream) {
   if (!in || !out || rows <= 0 || cols <= 0) return fail(MLBP_EINVAL, "mlbp_sum_rows_f64: bad arguments");
   if (int e = need_device()) return e;
-  hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(WG), 0, (hipStream_t)stream, in, rows, cols, out);
+  if (cols > 64) return fail(MLBP_EUNSUPPORTED, "mlbp_sum_rows_f64: at most 64 columns (got %d)", cols);
+  // the partials live in one device-wide scratch array: launches on DIFFERENT streams must not overlap
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(SUM_PARTS), dim3(WG), 0, (hipStream_t)stream, in, rows, cols, out);
   HIP_TRY(hipGetLastError());
   return MLBP_OK;
 }

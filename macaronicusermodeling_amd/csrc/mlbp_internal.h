@@ -43,6 +43,8 @@ bool build_shared_readout(const SharedProgram& sp, int n_msgs, int n_vars, const
 // Enqueues the shared-table kernel when it applies (sets *launched); flagged graphs are left in
 // prog->d_bail for the exact kernel.
 int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched);
+// Pairwise part of the gradient for shared tables (X = 64, F_ee = 3), ADDED to a->grad_en_en.
+int launch_shared_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void* stream);
 }  // namespace mlbp
 
 // Device-resident, validated op list (see mlbp_program_create).

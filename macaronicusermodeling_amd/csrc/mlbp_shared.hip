@@ -166,10 +166,13 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
       ent.insert(ent.end(), {out.hoisted[c], c, tile, (q == 0 ? 1 : 0) | (q + 1 == out.cprods[k].size() ? 2 : 0)});
     }
   }
+  std::vector<char> is_vf(n_msgs, 0);                          // slots some variable->factor update writes
+  for (int i = 0; i < n_ops; ++i)
+    if ((fops[8 * i] & 0xFF) >= FOP_VAR) is_vf[fops[8 * i + 3]] = 1;
   std::vector<int32_t> back, fill;
   for (int c = 0; c < n_msgs; ++c) {
     if (out.hoisted[c] >= 0) continue;
-    if (written[c] && out.live_of_slot[c] >= 0) { back.push_back(out.live_of_slot[c]); back.push_back(c); }
+    if (written[c] && out.live_of_slot[c] >= 0) { back.push_back(out.live_of_slot[c]); back.push_back(c | (is_vf[c] ? 0x40000000 : 0)); }
     else if (!written[c]) fill.push_back(c);
   }
   out.n_ops = n_ops; out.n_lists = (int)lists.size(); out.n_cpw = (int)ent.size();
@@ -271,6 +274,7 @@ struct SharedDev {
   const int32_t* readout;
   int32_t B, n_sweeps, n_msgs, P, U, n_pair_tables, n_unary_tables, n_vars;
   int32_t n_ops, n_live, n_lists, n_cpw, n_back, n_fill, n_readout;
+  int32_t vf_only;              // write back only the variable->factor messages (what the gradient reads)
 };
 
 #ifdef MLBP_STAMPS
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
       j4 = nj; e0 = ne;
     }
   }
-  if (d.msgs)                                                     // slots the sweeps never touch stay uniform
+  if (d.msgs && !d.vf_only)                                       // slots the sweeps never touch stay uniform
     for (int i = t; i < d.n_fill * G * 64; i += WG) {
       const int x = i & 63, gg = (i >> 6) & (G - 1), k = i >> 10;
       if (g0 + gg < d.B) d.msgs[((size_t)(g0 + gg) * d.n_msgs + fill[k]) * 64 + x] = uniform;
@@ -579,11 +583,12 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
     }
   }
   for (int i = wave; i < d.n_back; i += 4) {
-    const int tl = back[2 * i], slot = back[2 * i + 1];
+    const int tl = back[2 * i], slot = back[2 * i + 1] & 0x3FFFFFFF;
+    const bool is_vf = (back[2 * i + 1] & 0x40000000) != 0;
     const double* tp = tot + tl * 64 + gl;
     const double total = (tp[0] + tp[16]) + (tp[32] + tp[48]);
     bad |= !total_ok(total);
-    if (d.msgs && gvalid && !bad) {
+    if (d.msgs && (!d.vf_only || is_vf) && gvalid && !bad) {
       const double* src = tiles + (size_t)tl * TILE + lane;
       double* out = d.msgs + ((size_t)gc * d.n_msgs + slot) * 64 + cq;
       const double inv = 1.0 / total;
@@ -611,6 +616,168 @@ __global__ __launch_bounds__(WG) void unary_writeback_kernel(const double* unary
   const double v = unary_tables[(size_t)ti * 64 + lane];
   const double s = wave_sum(v);
   msgs[((size_t)g * n_msgs + ent[4 * e + 1]) * 64 + lane] = s > 0.0 ? v * (1.0 / s) : 1.0 / 64.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pairwise part of FactorGraph.get_unregularized_gradeint (LBP.py:301-320, 528-619) for shared tables:
+//   grad_k += phi[l0][l1][k] - (sum_ij c_i r_j T_ij phi_ijk) / (sum_ij c_i r_j T_ij)
+// For 16 graphs at once  sum_j T_ij phi_ijk r_j  is the contraction (T (.) phi_k)[64x64] . R[64x16]: four of
+// them per factor (k = 0..2 and the normaliser), then a dot with c along the rows.  c / r are the STORED
+// variable->factor messages (the reference reads graph.messages, not a recomputation), straight from msgs.
+// ------------------------------------------------------------------------------------------------
+struct PairGradDev {
+  const double* msgs; const double* pair_tables; const int32_t* pair_tab;
+  const int32_t* c_slot; const int32_t* r_slot; const int32_t* pair_phi; const int32_t* pair_label;
+  const double* phi[2];         // interleaved [64][64][3]: the label term
+  const double* phi_p[2];       // planar [3][64][64]
+  const double* wfrag;          // [P][4][4096] A fragments of T (.) phi_k and T (pair_weight_fragments_kernel)
+  double* grad_en_en;           // [B][3], ADDED to (assigned when the unary part is done here too)
+  int32_t* status;
+  int32_t B, n_msgs, P, n_pair_tables;
+  // unary factors by gather: phi[label][obs][:] - E[row][:]  (E from mlbp_unary_expectations_f64), or NULL
+  const double* unary_expect; const int32_t* unary_tab; const int32_t* unary_kind; const int32_t* unary_obs;
+  const int32_t* unary_label; const double* phi_ed; double* grad_en_de;
+  int32_t U, n_unary_tables, Vde;
+};
+
+constexpr int PG_MAXP = 3;      // pairwise factors per pass: their two message tiles each stay in LDS (48 KiB)
+constexpr int PG_MAXW = 16;     // pairwise factors the fragment scratch holds
+
+// W[p][k] = T_p (.) phi_k (k = 0..2) and T_p itself (k = 3), written in the order the MFMA A operand is read:
+// [p][k][wave w][k-step s][lane] = element (row 16w + (lane & 15), column 4s + (lane >> 4)).  Every fragment load
+// of the gradient kernel is then one contiguous 512-byte read (the direct form -- 16 rows x 32 bytes per
+// instruction -- kept the CU's address unit busy for longer than the MFMAs took).
+__global__ __launch_bounds__(WG) void pair_weight_fragments_kernel(const double* pair_tables, const int32_t* pair_tab,
+                                                                   const int32_t* pair_phi, const double* phi_p0,
+                                                                   const double* phi_p1, int n_pair_tables, double* wfrag) {
+  const int p = blockIdx.x >> 2, k = blockIdx.x & 3;
+  const int ti = pair_tab[p];                                   // graph 0's row; the gradient kernel checks the others
+  if ((unsigned)ti >= (unsigned)n_pair_tables) return;
+  const double* T = pair_tables + (size_t)ti * 4096;
+  const double* ph = (pair_phi[p] ? phi_p1 : phi_p0) + (size_t)k * 4096;
+  double* out = wfrag + ((size_t)p * 4 + k) * 4096;
+  for (int e = threadIdx.x; e < 4096; e += WG) {
+    const int lane = e & 63, s = (e >> 6) & 15, w = e >> 10;
+    const int idx = (16 * w + (lane & 15)) * 64 + 4 * s + (lane >> 4);
+    out[e] = k < 3 ? T[idx] * ph[idx] : T[idx];
+  }
+}
+
+__global__ __launch_bounds__(WG) void gradient_shared_pairs_kernel(PairGradDev d) {
+  __shared__ double tile[PG_MAXP][2][64 * G];                  // [factor][r | c][state][graph]
+  __shared__ double red[PG_MAXP][4][G][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int gl = lane & 15, cq = lane >> 4;
+  const int g0 = blockIdx.x * G;
+  const int gi = g0 + gl, gc = gi < d.B ? gi : d.B - 1;
+  double out[3] = {0.0, 0.0, 0.0};                             // thread t < 16: graph g0 + t
+  for (int p0 = 0; p0 < d.P; p0 += PG_MAXP) {
+    const int np = d.P - p0 < PG_MAXP ? d.P - p0 : PG_MAXP;
+    // stage the stored variable->factor messages: wave w reads whole 512-byte rows of graphs 4w..4w+3 and
+    // writes them transposed (lane = state)
+    for (int i = 0; i < np * 2 * 4; ++i) {
+      const int pp = i >> 3, rc = (i >> 2) & 1, gg = 4 * wave + (i & 3);
+      const int ggc = g0 + gg < d.B ? g0 + gg : d.B - 1;
+      const int slot = rc ? d.c_slot[p0 + pp] : d.r_slot[p0 + pp];
+      tile[pp][rc][lane * G + gg] = d.msgs[((size_t)ggc * d.n_msgs + slot) * 64 + lane];
+    }
+    __syncthreads();
+    for (int pp = 0; pp < np; ++pp) {
+      const int p = p0 + pp;
+      const int ti = d.pair_tab[p];                            // the table the fragments were built from
+      bool ok = (unsigned)ti < (unsigned)d.n_pair_tables && d.pair_tab[(size_t)gc * d.P + p] == ti;
+      const int l0 = d.pair_label[((size_t)gc * d.P + p) * 2], l1 = d.pair_label[((size_t)gc * d.P + p) * 2 + 1];
+      ok &= (unsigned)l0 < 64u && (unsigned)l1 < 64u;
+      if (!__all(ok)) {                                        // not the layout the caller claimed / a bad index
+        if (t == 0) atomicExch(d.status, 1);
+        if (cq == 0) for (int k = 0; k < 4; ++k) red[pp][wave][gl][k] = 0.0;
+        continue;
+      }
+      const double* W = d.wfrag + (size_t)p * 4 * 4096 + wave * 1024 + lane;
+      const double* rt = tile[pp][0] + lane;                   // B operand: state 4s + (l >> 4), graph l & 15
+      double4_t acc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const double b = rt[64 * s];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(W[k * 4096 + 64 * s], b, acc[k], 0, 0, 0);
+      }
+      const double* ct = tile[pp][1] + (16 * wave + cq) * G + gl;  // D rows 16w + cq + 4r
+      const double c0 = ct[0], c1 = ct[4 * G], c2 = ct[8 * G], c3 = ct[12 * G];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double part = column_sum((c0 * acc[k].x + c1 * acc[k].y) + (c2 * acc[k].z + c3 * acc[k].w));
+        if (cq == 0) red[pp][wave][gl][k] = part;
+      }
+    }
+    __syncthreads();
+    if (t < G && g0 + t < d.B) {
+      const int gg = g0 + t;
+      for (int pp = 0; pp < np; ++pp) {
+        const int p = p0 + pp;
+        const double (*rp)[G][4] = red[pp];
+        const double Z = (rp[0][t][0 + 3] + rp[1][t][3]) + (rp[2][t][3] + rp[3][t][3]);
+        const int m0 = d.pair_label[((size_t)gg * d.P + p) * 2], m1 = d.pair_label[((size_t)gg * d.P + p) * 2 + 1];
+        if ((unsigned)m0 >= 64u || (unsigned)m1 >= 64u) continue;
+        const int which = d.pair_phi[p] ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double S = (rp[0][t][k] + rp[1][t][k]) + (rp[2][t][k] + rp[3][t][k]);
+          out[k] += d.phi[which][((size_t)m0 * 64 + m1) * 3 + k] - (Z > 0.0 ? S / Z : 0.0);     // au.normalize: zero-sum -> 0
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (d.unary_expect) {
+    // unary factors: thread (graph t & 15, lane group t >> 4) takes factors u = t>>4, t>>4 + 16, ...; every term is
+    // two short gathers (phi at the label, E of the table row), so the 16 groups hide each other's latency
+    __shared__ double ured[16][G][9];
+    const int ug = t & 15, uj = t >> 4, gg = g0 + ug;
+    double acc[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (gg < d.B)
+      for (int u = uj; u < d.U; u += 16) {
+        const int kind = d.unary_kind[u];
+        const int row = d.unary_tab[(size_t)gg * d.U + u], obs = d.unary_obs[(size_t)gg * d.U + u];
+        const int lab = d.unary_label[(size_t)gg * d.U + u];
+        const int cols = kind == 2 ? d.Vde : 64;
+        if ((unsigned)row >= (unsigned)d.n_unary_tables || (unsigned)obs >= (unsigned)cols || (unsigned)lab >= 64u || (unsigned)kind > 2u) {
+          atomicExch(d.status, 1);
+          continue;
+        }
+        const double* E = d.unary_expect + (size_t)row * 8;
+        if (kind == 2) {
+          const double* pl = d.phi_ed + ((size_t)lab * cols + obs) * 6;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc[3 + k] += pl[k] - E[k];
+        } else {
+          const double* pl = d.phi[kind] + ((size_t)lab * 64 + obs) * 3;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) acc[k] += pl[k] - E[k];
+        }
+      }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ured[uj][ug][k] = acc[k];
+    __syncthreads();
+    if (t < G && g0 + t < d.B) {
+      double tot9[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        double v = 0.0;
+        for (int j = 0; j < 16; ++j) v += ured[j][t][k];
+        tot9[k] = v;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) d.grad_en_en[(size_t)(g0 + t) * 3 + k] = out[k] + tot9[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) d.grad_en_de[(size_t)(g0 + t) * 6 + k] = tot9[3 + k];
+    }
+  } else if (t < G && g0 + t < d.B) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.grad_en_en[(size_t)(g0 + t) * 3 + k] += out[k];
+  }
 }
 
 std::mutex g_attr_mutex;
@@ -660,6 +827,7 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   SharedDev d;
   d.pair_tables = a->pair_tables; d.pair_tab = a->pair_tab; d.unary_tables = a->unary_tables; d.unary_tab = a->unary_tab;
   d.msgs = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && !a->gradient) ? nullptr : a->msgs;
+  d.vf_only = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && a->gradient) ? 1 : 0;
   d.marginals = a->marginals; d.status = prog->d_status; d.bail = mp->d_bail;
   d.image = prog->d_simage; d.fsweeps = prog->d_simage + sp.off_sweeps; d.readout = prog->d_sreadout;
   d.B = a->B; d.n_sweeps = (int)sp.sweeps.size() / 2; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U;
@@ -668,7 +836,7 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   d.n_fill = sp.n_fill; d.n_readout = n_readout;
   int e = ntab == 2 ? launch<2>(d, lds, st) : launch<1>(d, lds, st);
   if (e) return e;
-  if (d.msgs && sp.n_cpw > 0) {
+  if (d.msgs && !d.vf_only && sp.n_cpw > 0) {
     const int E = sp.n_cpw / 4;
     const long long rows = (long long)a->B * E;
     hipLaunchKernelGGL(unary_writeback_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(WG), 0, st, a->unary_tables, a->unary_tab,
@@ -676,6 +844,32 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
     if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "unary write-back launch failed");
   }
   *launched = true;
+  return MLBP_OK;
+}
+
+int launch_shared_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void* stream) {
+  PairGradDev d;
+  d.msgs = a->msgs; d.pair_tables = a->pair_tables; d.pair_tab = a->pair_tab;
+  d.c_slot = a->pair_c_slot; d.r_slot = a->pair_r_slot; d.pair_phi = a->pair_phi; d.pair_label = a->pair_label;
+  d.phi[0] = a->phi_en_en; d.phi[1] = a->phi_en_en_w1; d.phi_p[0] = a->phi_en_en_p; d.phi_p[1] = a->phi_en_en_w1_p;
+  d.grad_en_en = a->grad_en_en; d.status = status;
+  d.B = a->B; d.n_msgs = a->n_msgs; d.P = a->P; d.n_pair_tables = a->n_pair_tables;
+  d.unary_expect = (a->F_ed == 6 && a->U > 0) ? a->unary_expect : nullptr;
+  d.unary_tab = a->unary_tab; d.unary_kind = a->unary_kind; d.unary_obs = a->unary_obs; d.unary_label = a->unary_label;
+  d.phi_ed = a->phi_en_de; d.grad_en_de = a->grad_en_de; d.U = a->U; d.n_unary_tables = a->n_unary_tables; d.Vde = a->Vde;
+  // fragment scratch: one device-wide buffer (launches on different streams must not overlap, like mlbp_sum_rows_f64)
+  static double* wfrag = nullptr;
+  static std::mutex wmutex;
+  {
+    std::lock_guard<std::mutex> lock(wmutex);
+    if (!wfrag && hipMalloc(&wfrag, sizeof(double) * PG_MAXW * 4 * 4096) != hipSuccess)
+      return fail(MLBP_EHIP, "shared-table pair gradient: scratch allocation failed");
+  }
+  d.wfrag = wfrag;
+  hipLaunchKernelGGL(pair_weight_fragments_kernel, dim3(a->P * 4), dim3(WG), 0, (hipStream_t)stream, a->pair_tables, a->pair_tab,
+                     a->pair_phi, a->phi_en_en_p, a->phi_en_en_w1_p, a->n_pair_tables, wfrag);
+  hipLaunchKernelGGL(gradient_shared_pairs_kernel, dim3((a->B + G - 1) / G), dim3(WG), 0, (hipStream_t)stream, d);
+  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table pair gradient launch failed");
   return MLBP_OK;
 }
 

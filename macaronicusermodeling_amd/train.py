@@ -74,6 +74,7 @@ class UserGraphTrainer:
         self.unary_tables = torch.empty(self.n_shared_rows + self.n_priv, X, dtype=torch.float64, device=dev)
         fb.pair_tables = self.pair_tables
         fb.pair_tab = torch.from_numpy(np.tile(np.array(pair_phi or [0], dtype=np.int32), (B, 1))).to(dev)
+        fb.pair_tables_shared = bool(topo.P)      # every instance reads the two pots: the MFMA kernels apply
         obs = obs_np
         base = np.array([0, X, 2 * X], dtype=np.int64)[np.array(unary_kind, dtype=np.int64)] if topo.U else np.zeros(0)
         fb.unary_tables = self.unary_tables
@@ -149,12 +150,33 @@ class UserGraphTrainer:
                                                 self.F_ed, None, ut[2 * X:].data_ptr(), st))
         self._patch_tables()
 
+    def capture(self):
+        """Records local_statistics() into a HIP graph (torch.cuda.CUDAGraph over the library's stream-ordered
+        launches): the step is a dozen short kernels, so replaying one graph instead of issuing them from Python
+        removes the launch-bound host time.  theta is read from the same device tensors at every replay.  Call
+        after one eager local_statistics() (first-use allocations and attribute calls must not be captured)."""
+        self._graph = None
+        self._local_statistics_eager()               # warm-up on the current stream
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._local_statistics_eager()
+        self._graph = g
+        return self
+
     def local_statistics(self):
         """Runs inference on this rank's shard and returns the fused statistics buffer (device):
         [sum_i grad_en_en (F_ee) | sum_i grad_en_de (F_ed) | sum_i log-posterior | instance count]."""
+        if getattr(self, '_graph', None) is not None:
+            self._graph.replay()
+            return self.stats
+        return self._local_statistics_eager()
+
+    def _local_statistics_eager(self):
         fb = self.batch
         self.build_potentials()
-        fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg, gradient=(self._g_ee, self._g_ed))
+        fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg, gradient=(self._g_ee, self._g_ed),
+                 keep_messages=False)
         self._patch_gradient()
         _ffi.check(_ffi.lib.mlbp_log_posterior_f64(self._marg.data_ptr(), fb._labels.data_ptr(), fb.B, self.topo.n_vars,
                                                    fb.X, self._lp.data_ptr(), _stream_ptr(self.device)))
@@ -181,7 +203,7 @@ class UserGraphTrainer:
         precision counts (p@0, p@25, p@50, total) of FactorGraph.get_precision_counts, LBP.py:80-106)."""
         fb, topo = self.batch, self.topo
         self.build_potentials()
-        fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg)
+        fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg, keep_messages=False)
         st = _stream_ptr(self.device)
         _ffi.check(_ffi.lib.mlbp_log_posterior_f64(self._marg.data_ptr(), fb._labels.data_ptr(), fb.B, topo.n_vars, fb.X,
                                                    self._lp.data_ptr(), st))

@@ -145,3 +145,36 @@ def test_a_wrong_shared_claim_is_caught_on_the_device():
         _ffi.check(_ffi.lib.mlbp_set_sweep_variant(1))
     np.testing.assert_allclose(got, fb.msgs.cpu().numpy(), rtol=1e-11, atol=1e-300)
     assert not np.allclose(got[20], got[19])
+
+
+def test_shared_table_gradient_matches_per_graph_kernels_and_oracle():
+    """Train step in the reference's table layout: sweeps on the MFMA kernel, pairwise part of the gradient on
+    the MFMA kernel, against (i) the per-graph gradient kernel on the same messages and (ii) the oracle."""
+    from macaronicusermodeling_amd import _ffi
+    spec = SPECS['user_k3_gaps_1_2_3']()
+    B = 37
+    fb, topo, inputs = _shared_batch(spec, B)
+    by_id = {f['id']: f for f in spec['factors']}
+    pair_phi = [0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1 for j in topo.pair_factors]
+    kinds = [2 if by_id[topo.factor_ids[j]]['factor_type'] == 'en_de' else (0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1)
+             for j in topo.unary_factors]
+    fb.set_features(inputs[0]['phi_en_en'], inputs[0]['phi_en_en_w1'], inputs[0]['phi_en_de'], pair_phi, kinds)
+    labels = np.tile(np.array([dict(zip(spec['var_ids'], spec['labels']))[v] for v in topo.var_ids]), (B, 1))
+    obs = np.tile(np.array([by_id[topo.factor_ids[j]]['observed_dim'] for j in topo.unary_factors]), (B, 1))
+    fb.set_observations(labels, obs)
+    roots = [1, 2, 4]
+    gee = torch.full((B, 3), float('nan'), dtype=torch.float64, device=fb.device)
+    ged = torch.full((B, 6), float('nan'), dtype=torch.float64, device=fb.device)
+    fb.sweep(roots, init=True, gradient=(gee, ged))
+    assert _ffi.lib.mlbp_last_sweep_kernel() == KERNEL_SHARED_MFMA and _ffi.lib.mlbp_gradient_status() == 0
+    fb.use_shared_gradient = False                      # same messages, per-graph gradient kernel
+    ee2, ed2 = fb.gradient()
+    np.testing.assert_allclose(gee.cpu().numpy(), ee2.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(ged.cpu().numpy(), ed2.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    for b in (0, 17, 36):
+        for k in ('phi_en_en', 'phi_en_en_w1', 'phi_en_de'):
+            inputs[b][k] = inputs[0][k]
+        g, msgs, _ = oracle_msgs(spec, inputs[b], roots)
+        want_ee, want_ed = O.unregularized_gradient(g, inputs[b], msgs)
+        np.testing.assert_allclose(gee[b].cpu().numpy(), np.asarray(want_ee).reshape(-1), rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(ged[b].cpu().numpy(), np.asarray(want_ed).reshape(-1), rtol=1e-8, atol=1e-10)

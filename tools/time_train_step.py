@@ -29,6 +29,11 @@ labels = rs.randint(0, X, size=(B, topo.n_vars)); obs = rs.randint(0, 64, size=(
 tr = UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],
                       inputs['theta_en_en'], inputs['theta_en_de'])
 print('shared pots:  full local_statistics %.3f ms' % timed(tr.local_statistics))
+eager = tr.local_statistics().clone()
+tr.capture()
+print('shared pots:  full local_statistics as one HIP graph replay %.3f ms' % timed(tr.local_statistics))
+assert torch.equal(eager, tr.local_statistics()), 'graph replay differs from eager'
+tr._graph = None
 print('   potentials %.3f  sweep+marginals %.3f  gradient %.3f' % (
     timed(tr.build_potentials), timed(lambda: tr.batch.sweep(tr.roots, init=True, marginals=tr._marg)),
     timed(lambda: tr.batch.gradient(tr._g_ee, tr._g_ed))))

@@ -74,6 +74,7 @@ struct mlbp_program {
   int32_t* d_simage;      // SharedProgram::image
   int32_t* d_sreadout;    // per variable: base tile, count, live tiles (4-word aligned lists) or NULL
   int32_t n_sreadout;
+  double* d_tfrag;        // [16][2][4096] table fragments in MFMA operand order (lazily allocated)
 };
 
 #endif

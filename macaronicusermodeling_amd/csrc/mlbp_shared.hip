@@ -38,7 +38,7 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
   out = SharedProgram();
   const int n_hoist = (int)fp.hoist.size() / 2;
   out.why = "unary messages are not all constant, or no / too many pairwise factors";
-  if (fp.has_unary_fops || n_hoist != U || P < 1 || P > 16) return;
+  if (fp.has_unary_fops || n_hoist != U || P < 1 || P > 16 || U > 64) return;
   const int n_all = n_msgs + 1 + fp.n_cprod;
   out.hoisted.assign(n_msgs, -1);
   for (int h = 0; h < n_hoist; ++h) out.hoisted[fp.hoist[2 * h + 1]] = fp.hoist[2 * h];
@@ -275,6 +275,7 @@ struct SharedDev {
   int32_t B, n_sweeps, n_msgs, P, U, n_pair_tables, n_unary_tables, n_vars;
   int32_t n_ops, n_live, n_lists, n_cpw, n_back, n_fill, n_readout;
   int32_t vf_only;              // write back only the variable->factor messages (what the gradient reads)
+  const double* tfrag;          // [P][2][4096] A fragments of factor p's table (graph 0's row), or NULL
 };
 
 #ifdef MLBP_STAMPS
@@ -303,6 +304,22 @@ __device__ int g_sh_ablate = 0;
     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s_ + 1], b[s_ + 1], acc1, 0, 0, 0); \
   }
 
+// out[p][0 | 1][wave w][k-step s][lane] = the A fragments of factor p's table (graph 0's pair_tab row) for T.m and
+// m^T.T: element (16w + (lane & 15), 4s + (lane >> 4)) of T resp. T^T.
+__global__ __launch_bounds__(WG) void table_fragments_kernel(const double* pair_tables, const int32_t* pair_tab,
+                                                             int n_pair_tables, double* out) {
+  const int p = blockIdx.x >> 1, mt = blockIdx.x & 1;
+  const int ti = pair_tab[p];
+  if ((unsigned)ti >= (unsigned)n_pair_tables) return;           // the sweep kernel raises the status word
+  const double* T = pair_tables + (size_t)ti * 4096;
+  double* o = out + ((size_t)p * 2 + mt) * 4096;
+  for (int e = threadIdx.x; e < 4096; e += WG) {
+    const int lane = e & 63, s = (e >> 6) & 15, w = e >> 10;
+    const int i = 16 * w + (lane & 15), k = 4 * s + (lane >> 4);
+    o[e] = mt ? T[k * 64 + i] : T[i * 64 + k];
+  }
+}
+
 template <int NTAB>
 __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
   extern __shared__ double lds[];
@@ -318,7 +335,8 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
   int32_t* ptab = utab + G * d.U;                                // [P] table of factor p
   int32_t* preg = ptab + d.P;                                    // [P] register set of factor p
   int32_t* dist = preg + d.P;                                    // [NTAB] distinct tables, then {count, overflow}
-  int32_t* gflag = dist + NTAB + 2;                              // [16] prologue verdict per graph
+  int32_t* dfac = dist + NTAB + 2;                               // [NTAB] first factor using distinct table r, then {row equals graph 0's}
+  int32_t* gflag = dfac + NTAB + 1;                              // [16] prologue verdict per graph
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int gl = lane & 15, cq = lane >> 4;                      // B/D operand: graph column, k-row
@@ -361,17 +379,18 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
     return;
   }
   if (t == 0) {
-    int nd = 0, over = 0;
+    int nd = 0, over = 0, row0 = 1;
     for (int p = 0; p < d.P; ++p) {
       int r = 0;
       while (r < nd && dist[r] != ptab[p]) ++r;
       if (r == nd) {
-        if (nd < NTAB) dist[nd++] = ptab[p];
+        if (nd < NTAB) { dist[nd] = ptab[p]; dfac[nd++] = p; }
         else { over = 1; r = 0; }
       }
       preg[p] = r;
+      row0 &= ptab[p] == d.pair_tab[p];                          // the row the fragment copies were made from
     }
-    dist[NTAB] = nd; dist[NTAB + 1] = over;
+    dist[NTAB] = nd; dist[NTAB + 1] = over; dfac[NTAB] = row0;
   }
   if (!__syncthreads_and(same ? 1 : 0) || dist[NTAB + 1]) {      // not a shared-table batch: exact kernel takes all 16
     if (t < G && g0 + t < d.B) d.bail[g0 + t] = 4;
@@ -385,11 +404,23 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
 #pragma unroll
   for (int r = 0; r < NTAB; ++r) {
     const int ti = __builtin_amdgcn_readfirstlane(dist[r < nd ? r : 0]);
-    const double* T = d.pair_tables + (size_t)ti * 4096;
+    if (d.tfrag && __builtin_amdgcn_readfirstlane(dfac[NTAB])) {
+      // copies in operand order (table_fragments_kernel): one contiguous 512-byte read per fragment; read
+      // straight from the row-major table the same fragments are 16 rows x 32 bytes per instruction and kept
+      // the CU's address unit busy for ~20 us per workgroup
+      const double* F = d.tfrag + (size_t)__builtin_amdgcn_readfirstlane(dfac[r < nd ? r : 0]) * 2 * 4096 + wave * 1024 + lane;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      aTM[r][s] = T[(16 * wave + gl) * 64 + 4 * s + cq];         // (T.m)[x]  : A[x][y] = T[x][y]
-      aMT[r][s] = T[(4 * s + cq) * 64 + 16 * wave + gl];         // (m^T.T)[x]: A[x][y] = T[y][x]
+      for (int s = 0; s < 16; ++s) {
+        aTM[r][s] = F[64 * s];
+        aMT[r][s] = F[4096 + 64 * s];
+      }
+    } else {
+      const double* T = d.pair_tables + (size_t)ti * 4096;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        aTM[r][s] = T[(16 * wave + gl) * 64 + 4 * s + cq];       // (T.m)[x]  : A[x][y] = T[x][y]
+        aMT[r][s] = T[(4 * s + cq) * 64 + 16 * wave + gl];       // (m^T.T)[x]: A[x][y] = T[y][x]
+      }
     }
   }
 
@@ -399,32 +430,38 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
   // separate streaming kernel): every load is unconditional (clamped index) so that the rows of the NEXT
   // batch stay in flight while the current one is reduced -- the only HBM reads of the kernel that miss L2.
   {
-    constexpr int HB = 12;
+    // Four rotating buffers of HB rows: three batches are always in flight behind the one being reduced (a
+    // batch costs ~0.4 us of arithmetic against ~2.5 us of load latency).  Every fetch is unconditional -- the
+    // cursor clamps at the last batch -- so the wait before a batch is a fixed vmcnt and never drains the queue.
+    constexpr int HB = 8;
     const int E = d.n_cpw / 4;
-    double cur = uniform;
+    const int cpg = (E + HB - 1) / HB, nb = 4 * cpg;             // batches per graph, batches of this wave
+    double cur = 1.0;
     bool bad = false;
-    double row[HB], nxt[HB];
-    auto fetch = [&](int j4, int e0, double (&r)[HB]) {
-      const int32_t* ut = utab + (4 * wave + j4) * d.U;
+    int fj = 0, fe = 0, pj = 0, pe = 0;                          // fetch / process cursors: graph 4w + j, first entry
+    // entry e of the list lives in lane e: the per-row scalars come from v_readlane instead of a chain of
+    // dependent LDS reads per row (three round trips per row were most of this phase)
+    const int el = min(lane, E > 0 ? E - 1 : 0);
+    const int ent_u = E > 0 ? ent[4 * el] : 0, ent_tile = E > 0 ? ent[4 * el + 2] : 0, ent_flags = E > 0 ? ent[4 * el + 3] : 0;
+    int row_of = 0;                                              // table row of entry `lane` of the graph being fetched
+    auto fetch = [&](double (&r)[HB]) {
+      if (fe == 0) row_of = utab[(4 * wave + fj) * d.U + ent_u];
 #pragma unroll
       for (int j = 0; j < HB; ++j)
-        r[j] = d.unary_tables[(size_t)ut[ent[4 * min(e0 + j, E - 1)]] * 64 + lane];
+        r[j] = d.unary_tables[(size_t)__builtin_amdgcn_readlane(row_of, min(fe + j, E - 1)) * 64 + lane];
+      if (fe + HB < E) fe += HB;
+      else if (fj < 3) { fe = 0; ++fj; }
     };
-    int j4 = 0, e0 = 0;
-    if (E > 0 && !ABL(3)) fetch(0, 0, row);
-    while (j4 < 4 && E > 0) {
-      int nj = j4, ne = e0 + HB;
-      if (ne >= E) { ne = 0; ++nj; }
-      if (!ABL(3)) fetch(min(nj, 3), ne, nxt);
-      const int gg = 4 * wave + j4;
+    auto process = [&](const double (&row)[HB]) {
+      const int gg = 4 * wave + pj;
 #pragma unroll
       for (int j = 0; j < HB; ++j) {
-        if (e0 + j < E) {
+        if (pe + j < E) {
           // The scale of a unary message cancels in everything downstream (only its normalised form is ever
           // stored, by unary_writeback_kernel), so the raw columns are multiplied and the PRODUCT is
           // normalised once.  A column Message.renormalize would replace by the uniform vector (total <= 0,
           // LBP.py:655-657) or that is not a finite non-negative vector sends the graph to the exact kernel.
-          const int flags = __builtin_amdgcn_readfirstlane(ent[4 * (e0 + j) + 3]);
+          const int flags = __builtin_amdgcn_readlane(ent_flags, pe + j);
           if (flags & 1) { cur = 1.0; bad = false; }
           const double r = row[j];
           bad |= !(r >= 0.0 && r <= 1e280) || !__any(r > 0.0);
@@ -432,14 +469,23 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
           if (flags & 2) {
             const double s = ABL(2) ? 64.0 : wave_sum(cur);
             bad |= !total_ok(s);
-            if (!ABL(1)) tiles[(size_t)ent[4 * (e0 + j) + 2] * TILE + lane * G + gg] = cur * (1.0 / s);
+            if (!ABL(1)) tiles[(size_t)__builtin_amdgcn_readlane(ent_tile, pe + j) * TILE + lane * G + gg] = cur * (1.0 / s);
             if (__any(bad)) gflag[gg] = 1;
           }
         }
       }
-#pragma unroll
-      for (int j = 0; j < HB; ++j) row[j] = nxt[j];
-      j4 = nj; e0 = ne;
+      pe += HB;
+      if (pe >= E) { pe = 0; ++pj; }
+    };
+    if (E > 0) {
+      double r0[HB], r1[HB], r2[HB], r3[HB];
+      fetch(r0); fetch(r1); fetch(r2);
+      for (int i = 0; i < nb; i += 4) {
+        fetch(r3); process(r0);
+        fetch(r0); if (i + 1 < nb) process(r1);
+        fetch(r1); if (i + 2 < nb) process(r2);
+        fetch(r2); if (i + 3 < nb) process(r3);
+      }
     }
   }
   if (d.msgs && !d.vf_only)                                       // slots the sweeps never touch stay uniform
@@ -815,7 +861,7 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
     return fail(MLBP_OK, "shared-table kernel not used: a variable's constant messages match no folded product");
   const int n_readout = a->marginals ? prog->n_sreadout : 0;
   const int ntab = prog->P >= 2 ? 2 : 1;
-  const size_t words = (size_t)sp.off_sweeps + 1 + n_readout + (size_t)G * prog->U + 2 * prog->P + ntab + 2 + G + 8;
+  const size_t words = (size_t)sp.off_sweeps + 1 + n_readout + (size_t)G * prog->U + 2 * prog->P + 2 * ntab + 3 + G + 8;
   const size_t lds = ((size_t)sp.n_live * (TILE + 64)) * sizeof(double) + words * sizeof(int32_t);
   if (lds > 160 * 1024)
     return fail(MLBP_OK, "shared-table kernel not used: %d live message tiles need %zu bytes of LDS", sp.n_live, lds);
@@ -834,6 +880,11 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables; d.n_vars = prog->n_vars;
   d.n_ops = sp.n_ops; d.n_live = sp.n_live; d.n_lists = sp.n_lists; d.n_cpw = sp.n_cpw; d.n_back = sp.n_back;
   d.n_fill = sp.n_fill; d.n_readout = n_readout;
+  if (!mp->d_tfrag) {                              // first use (a stream-capturing caller warms up or reserves first)
+    if (hipMalloc(&mp->d_tfrag, sizeof(double) * 16 * 2 * 4096) != hipSuccess) return fail(MLBP_EHIP, "fragment scratch allocation failed");
+  }
+  d.tfrag = mp->d_tfrag;
+  hipLaunchKernelGGL(table_fragments_kernel, dim3(prog->P * 2), dim3(WG), 0, st, a->pair_tables, a->pair_tab, a->n_pair_tables, mp->d_tfrag);
   int e = ntab == 2 ? launch<2>(d, lds, st) : launch<1>(d, lds, st);
   if (e) return e;
   if (d.msgs && !d.vf_only && sp.n_cpw > 0) {

@@ -1646,6 +1646,7 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
   p->n_vars = 0;
   p->n_readout = 0;
   p->d_simage = p->d_sreadout = nullptr;
+  p->d_tfrag = nullptr;
   p->n_sreadout = 0;
   mlbp::build_shared_program(fp, n_msgs, P, U, p->shared);
   if (p->shared.ok && e == hipSuccess) e = up(&p->d_simage, p->shared.image.data(), p->shared.image.size());
@@ -1665,7 +1666,7 @@ int mlbp_program_destroy(mlbp_program* p) {
   (void)hipFree(p->d_ops); (void)hipFree(p->d_srcs); (void)hipFree(p->d_sweeps);
   (void)hipFree(p->d_pairseq); (void)hipFree(p->d_status);
   (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq); (void)hipFree(p->d_bail); (void)hipFree(p->d_readout);
-  (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout);
+  (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout); (void)hipFree(p->d_tfrag);
   delete p;
   return MLBP_OK;
 }

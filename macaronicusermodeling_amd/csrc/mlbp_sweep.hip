@@ -16,6 +16,7 @@
 // Algorithmic HBM bytes per pairwise update: (X*X + 2X) * 8.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdlib>
 #include <mutex>
@@ -1366,8 +1367,43 @@ __global__ void log_posterior_kernel(const double* marg, const int32_t* labels, 
 // Fused program form (see sweep_x64_fused_kernel).  Input: the validated 4-word op list.
 using mlbp::FusedProgram;
 
-void build_fused_program(const int32_t* ops, const int32_t* srcs, const int32_t* sweeps, int n_sweeps, int n_msgs,
+void build_fused_program(const int32_t* ops_in, const int32_t* srcs, const int32_t* sweeps, int n_sweeps, int n_msgs,
                          FusedProgram& out) {
+  // 0. inside each sweep, sink every variable->factor update down to just before the pairwise update that
+  //    consumes it when nothing in between writes one of its inputs or touches its output.  The up pass of a
+  //    loopy schedule (LBP.py:227-233) emits "X7->F17, X4->F14, F17->X1, F14->X1": neither pair is adjacent, so
+  //    without this no fusion happens.  Updates keep their inputs, hence their values; only the order of
+  //    independent updates changes.
+  int n_total = 0;
+  for (int s = 0; s < n_sweeps; ++s) n_total = std::max(n_total, sweeps[2 * s] + sweeps[2 * s + 1]);
+  std::vector<int32_t> ops_v(ops_in, ops_in + 4 * (size_t)n_total);
+  if (!getenv("MLBP_NO_SINK"))
+    for (int s = 0; s < n_sweeps; ++s) {
+      const int first = sweeps[2 * s], cnt = sweeps[2 * s + 1];
+      int32_t* q = ops_v.data() + 4 * (size_t)first;
+      auto is_pair = [&](int i) { return q[4 * i] == MLBP_OP_PAIR_TM || q[4 * i] == MLBP_OP_PAIR_MT; };
+      for (int i = 0; i < cnt; ++i) {
+        if (q[4 * i] != MLBP_OP_VAR) continue;
+        const int a = q[4 * i + 1], b = q[4 * i + 2], c = q[4 * i + 3];
+        int j = i + 1;
+        bool legal = true;
+        for (; j < cnt && legal; ++j) {
+          if (is_pair(j) && q[4 * j + 2] == c) break;                                  // the consumer
+          const int w = q[4 * j + 3];
+          if (w == c) legal = false;
+          for (int k = a; k < a + b && legal; ++k) if (srcs[k] == w) legal = false;
+          if (q[4 * j] == MLBP_OP_VAR)
+            for (int k = q[4 * j + 1]; k < q[4 * j + 1] + q[4 * j + 2] && legal; ++k) if (srcs[k] == c) legal = false;
+        }
+        if (!legal || j >= cnt || j == i + 1) continue;
+        const int32_t v[4] = {q[4 * i], a, b, c};
+        for (int k = i; k < j - 1; ++k)
+          for (int e = 0; e < 4; ++e) q[4 * k + e] = q[4 * (k + 1) + e];
+        for (int e = 0; e < 4; ++e) q[4 * (j - 1) + e] = v[e];
+        --i;                                                                           // the op that slid into place i
+      }
+    }
+  const int32_t* ops = ops_v.data();
   // 1. may the unary messages be hoisted?  Every read of a unary factor's message slot must come
   //    after a UNARY op has written that slot (then the value read is always the same constant).
   std::vector<char> is_unary_dst(n_msgs, 0), written(n_msgs, 0);

@@ -911,6 +911,7 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
   const double uniform = 1.0 / 64.0;
   const const_i32p c_fsweeps = as_const(f.fsweeps);
 
+  if (t == 0) f.bail[g] = 0;      // this workgroup owns the flag: cleared here (no separate memset), raised below by the same thread
   // ---- phase A: table indices (range-checked), program image, messages ----
   bool ok = true;
   for (int i = t; i < d.P + d.U; i += WG) {
@@ -1779,7 +1780,6 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       if (want_sf) {
         if (mp->bail_cap < a->B)              // not reserved for this batch size: allocate now (a stream-
           if (int e = mlbp_program_reserve(mp, a->B)) return e;   // capturing caller reserves up front instead)
-        HIP_TRY(hipMemsetAsync(mp->d_bail, 0, (size_t)a->B, st));
         ScaleFreeDev sf;
         sf.image = prog->d_fops; sf.fsweeps = prog->d_fsweeps; sf.bail = mp->d_bail;
         sf.n_fops = prog->n_fops; sf.n_psrcs = prog->n_psrcs; sf.n_hoist = prog->n_hoist;

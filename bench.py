@@ -261,7 +261,7 @@ def main():
     if traffic is None:
         try:    # HBM bytes per launch measured with rocprofv3 --pmc for this exact workload (profiles/)
             rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get(a.workload)
-            if rec and rec['batch'] == B and rec['sweeps'] == sweeps and a.variant in (None, 1):
+            if rec and rec['batch'] == B and rec['sweeps'] == sweeps and a.variant in (None, 1) and not a.no_writeback:
                 traffic, traffic_src = rec['hbm_bytes_per_launch'], rec['source']
         except (OSError, ValueError, KeyError):
             pass

@@ -117,6 +117,14 @@ int mlbp_program_destroy(mlbp_program* p);
  * it the first launch with a larger batch allocates. */
 int mlbp_program_reserve(mlbp_program* p, int32_t max_graphs);
 
+/* HOST only (no device needed): what the program rewrites make of an op list.  out8 = { updates of the fused
+ * form, of them lone variable->factor updates, fused variable+pairwise updates, bundles (two updates under
+ * one barrier); shared-table form applicable (0/1), its resident message tiles, its updates, LDS bytes of its
+ * tiles for 16 graphs }.  Same validation and error codes as mlbp_program_create. */
+int mlbp_program_plan(const int32_t* ops, int32_t n_ops, const int32_t* srcs, int32_t n_srcs,
+                      const int32_t* sweeps, int32_t n_sweeps, int32_t n_msgs, int32_t P, int32_t U,
+                      int32_t* out8);
+
 /* Attaches the variable read-out tables to a program so that mlbp_sweep_f64 can write the
  * variable marginals straight from the on-chip messages (mlbp_sweep_args.marginals): in_off
  * [n_vars+1] / in_slots are HOST arrays, variable v multiplies the messages in slots

@@ -72,6 +72,7 @@ SIGNATURES = {
     'mlbp_program_create': (C.c_int, [_i32p, _i32, _i32p, _i32, _i32p, _i32, _i32, _i32, _i32,
                                       C.POINTER(_vp)]),
     'mlbp_program_destroy': (C.c_int, [_vp]),
+    'mlbp_program_plan': (C.c_int, [_i32p, _i32, _i32p, _i32, _i32p, _i32, _i32, _i32, _i32, _i32p]),
     'mlbp_program_reserve': (C.c_int, [_vp, _i32]),
     'mlbp_program_set_readout': (C.c_int, [_vp, _i32, _i32p, _i32p]),
     'mlbp_program_exact_count': (C.c_int, [_vp, _i32]),

@@ -1601,14 +1601,12 @@ int mlbp_device_count(void) {
   return n;
 }
 
-int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, int32_t n_srcs,
-                        const int32_t* sweeps, int32_t n_sweeps, int32_t n_msgs, int32_t P, int32_t U,
-                        mlbp_program** out) {
-  if (!out) return fail(MLBP_EINVAL, "out is NULL");
-  *out = nullptr;
+// Range checks shared by mlbp_program_create and mlbp_program_plan; every later routine indexes freely.
+static int validate_program(const int32_t* ops, int32_t n_ops, const int32_t* srcs, int32_t n_srcs, const int32_t* sweeps,
+                            int32_t n_sweeps, int32_t n_msgs, int32_t P, int32_t U, int* max_srcs_out) {
   if (!ops || !sweeps || n_ops <= 0 || n_sweeps <= 0 || n_msgs <= 0 || P < 0 || U < 0 || n_srcs < 0 ||
       (n_srcs > 0 && !srcs))
-    return fail(MLBP_EINVAL, "mlbp_program_create: bad sizes or NULL arrays");
+    return fail(MLBP_EINVAL, "program: bad sizes or NULL arrays");
   int max_srcs = 0;
   for (int o = 0; o < n_ops; ++o) {
     const int kind = ops[4 * o], a = ops[4 * o + 1], b = ops[4 * o + 2], c = ops[4 * o + 3];
@@ -1633,11 +1631,46 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
         return fail(MLBP_EINVAL, "op %d: unknown kind %d", o, kind);
     }
   }
-  std::vector<int32_t> pairseq;
   for (int s = 0; s < n_sweeps; ++s) {
     const int first = sweeps[2 * s], cnt = sweeps[2 * s + 1];
     if (first < 0 || cnt < 0 || (int64_t)first + cnt > n_ops)
       return fail(MLBP_EINVAL, "sweep %d: op range [%d,%d) out of [0,%d)", s, first, first + cnt, n_ops);
+  }
+  if (max_srcs_out) *max_srcs_out = max_srcs;
+  return MLBP_OK;
+}
+
+/* Host only: what the program rewrites make of an op list (no device needed). */
+int mlbp_program_plan(const int32_t* ops, int32_t n_ops, const int32_t* srcs, int32_t n_srcs, const int32_t* sweeps,
+                      int32_t n_sweeps, int32_t n_msgs, int32_t P, int32_t U, int32_t* out8) {
+  if (!out8) return fail(MLBP_EINVAL, "mlbp_program_plan: out8 is NULL");
+  if (int e = validate_program(ops, n_ops, srcs, n_srcs, sweeps, n_sweeps, n_msgs, P, U, nullptr)) return e;
+  FusedProgram fp;
+  build_fused_program(ops, srcs, sweeps, n_sweeps, n_msgs, fp);
+  int lone = 0, fused = 0, bundled = 0;
+  for (size_t i = 0; i < fp.fops.size(); i += 8) {
+    const int k = fp.fops[i] & 0xFF;
+    lone += k == FOP_VAR;
+    fused += k == FOP_VAR_PAIR_TM || k == FOP_VAR_PAIR_MT;
+    bundled += (fp.fops[i] & FOP_BUNDLED) != 0;
+  }
+  mlbp::SharedProgram sp;
+  mlbp::build_shared_program(fp, n_msgs, P, U, sp);
+  out8[0] = (int)fp.fops.size() / 8; out8[1] = lone; out8[2] = fused; out8[3] = bundled;
+  out8[4] = sp.ok ? 1 : 0; out8[5] = sp.n_live; out8[6] = sp.n_ops; out8[7] = sp.n_live * (64 * 16 + 64) * 8;
+  return MLBP_OK;
+}
+
+int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, int32_t n_srcs,
+                        const int32_t* sweeps, int32_t n_sweeps, int32_t n_msgs, int32_t P, int32_t U,
+                        mlbp_program** out) {
+  if (!out) return fail(MLBP_EINVAL, "out is NULL");
+  *out = nullptr;
+  int max_srcs = 0;
+  if (int e = validate_program(ops, n_ops, srcs, n_srcs, sweeps, n_sweeps, n_msgs, P, U, &max_srcs)) return e;
+  std::vector<int32_t> pairseq;
+  for (int s = 0; s < n_sweeps; ++s) {
+    const int first = sweeps[2 * s], cnt = sweeps[2 * s + 1];
     for (int o = first; o < first + cnt; ++o)
       if (ops[4 * o] == MLBP_OP_PAIR_TM || ops[4 * o] == MLBP_OP_PAIR_MT) pairseq.push_back(ops[4 * o + 1]);
   }

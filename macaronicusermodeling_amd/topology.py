@@ -152,6 +152,20 @@ class GraphTopology:
         srcs = np.concatenate(srcs_all).astype(np.int32) if n_srcs else np.zeros(0, dtype=np.int32)
         return ops, srcs, np.array(sweeps, dtype=np.int32).reshape(-1, 2)
 
+    def plan(self, roots):
+        """What the host-side program rewrites make of this root sequence (no GPU needed): dict with the update
+        counts of the fused form and the tile budget of the shared-table form (mlbp_program_plan)."""
+        ops, srcs, sweeps = self.compile_program(roots)
+        out = np.zeros(8, dtype=np.int32)
+        ops = np.ascontiguousarray(ops, dtype=np.int32)
+        srcs_p = np.ascontiguousarray(srcs if len(srcs) else np.zeros(1), dtype=np.int32)
+        sweeps = np.ascontiguousarray(sweeps, dtype=np.int32)
+        _ffi.check(_ffi.lib.mlbp_program_plan(_ffi.i32ptr(ops), len(ops), _ffi.i32ptr(srcs_p), len(srcs), _ffi.i32ptr(sweeps),
+                                              len(sweeps), self.n_msgs, self.P, self.U, _ffi.i32ptr(out)))
+        keys = ('updates', 'lone_variable_updates', 'fused_updates', 'bundles', 'shared_ok', 'shared_tiles',
+                'shared_updates', 'shared_tile_bytes')
+        return dict(zip(keys, (int(v) for v in out)))
+
     @classmethod
     def from_spec(cls, spec):
         """From the plain-data specs used by the tests and the benchmark (tests/golden/cases.py)."""

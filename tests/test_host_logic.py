@@ -118,3 +118,24 @@ def test_bad_topologies_are_rejected():
         GraphTopology([(0, [0, 0], [0, 1])])
     with pytest.raises(ValueError):
         GraphTopology([(0, [0], [0]), (0, [1], [0])])
+
+
+def test_program_rewrites_plan():
+    """Host-side program rewrites (no GPU): after sinking variable->factor updates next to their consumers every
+    update inside a K3 sweep fuses (what is left lone / standalone are the sweep's last two variable updates and
+    its first two pairwise updates, which straddle the sweep boundary); the shared-table form of the same call
+    keeps 9 message tiles resident (3 constant products + 6 factor->variable messages) = 78 336 bytes for 16
+    graphs, i.e. two workgroups per CU; K4 needs 21 tiles and so falls back at launch."""
+    from macaronicusermodeling_amd.topology import GraphTopology
+    k3 = GraphTopology.from_spec(C.user_spec(10, [1, 4, 7], 64, 64, seed=1)).plan([1, 4, 7])
+    assert (k3['updates'], k3['fused_updates'], k3['lone_variable_updates'], k3['bundles']) == (24, 12, 6, 9)
+    assert (k3['shared_ok'], k3['shared_tiles'], k3['shared_tile_bytes']) == (1, 9, 78336)
+    assert 2 * k3['shared_tile_bytes'] < 160 * 1024
+    k2 = GraphTopology.from_spec(C.user_spec(6, [0, 1], 64, 64, seed=3)).plan([0, 1, 0])
+    assert (k2['updates'], k2['fused_updates'], k2['lone_variable_updates'], k2['shared_tiles']) == (6, 6, 0, 4)
+    k4 = GraphTopology.from_spec(C.user_spec(9, [0, 2, 3, 7], 64, 64, seed=4)).plan([0, 2, 3])
+    assert k4['shared_tiles'] == 21 and k4['shared_tile_bytes'] > 160 * 1024
+    ring = GraphTopology.from_spec(C.ring_spec(8, 64)).plan([0, 0, 0])
+    assert ring['fused_updates'] == ring['updates'] == 48 and ring['bundles'] == 24
+    k1 = GraphTopology.from_spec(C.user_spec(5, [2], 64, 64, seed=5)).plan([2])      # no pairwise factor at all
+    assert k1['shared_ok'] == 0 and k1['updates'] == 0

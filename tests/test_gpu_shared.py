@@ -178,3 +178,41 @@ def test_shared_table_gradient_matches_per_graph_kernels_and_oracle():
         want_ee, want_ed = O.unregularized_gradient(g, inputs[b], msgs)
         np.testing.assert_allclose(gee[b].cpu().numpy(), np.asarray(want_ee).reshape(-1), rtol=1e-8, atol=1e-10)
         np.testing.assert_allclose(ged[b].cpu().numpy(), np.asarray(want_ed).reshape(-1), rtol=1e-8, atol=1e-10)
+
+
+def test_full_size_properties_of_the_shared_kernel():
+    """BASELINE batch size (8192 graphs): size-independent properties -- every message and marginal sums to 1,
+    graphs with identical inputs get identical bits wherever they sit in the batch (different workgroups, different
+    columns of the MFMA tile), and a sample of graphs equals the per-graph exact kernel to rounding."""
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.batch import FactorGraphBatch
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = SPECS['user_k3_gaps_1_2_3']()
+    topo = GraphTopology.from_spec(spec)
+    B, X = 8192, 64
+    dev = torch.device('cuda:0')
+    gen = torch.Generator(device=dev); gen.manual_seed(11)
+    by_id = {f['id']: f for f in spec['factors']}
+    which = [0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1 for j in topo.pair_factors]
+    pair = torch.rand(2, X, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
+    n_distinct = 517                                   # unary table sets repeat with a period coprime to 16
+    unary = torch.rand(n_distinct * topo.U, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
+    utab = (np.arange(B)[:, None] % n_distinct) * topo.U + np.arange(topo.U)[None, :]
+    fb = FactorGraphBatch(topo, X, B)
+    fb.set_pair_tables(pair, np.tile(np.array(which), (B, 1)))
+    fb.set_unary_tables(unary, utab)
+    roots = [1, 2, 4]
+    marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)
+    prog = fb.sweep(roots, init=True, marginals=marg)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == KERNEL_SHARED_MFMA and prog.exact_count(B) == 0
+    assert float((fb.msgs.sum(-1) - 1).abs().max()) < 1e-13 and float((marg.sum(-1) - 1).abs().max()) < 1e-13
+    assert torch.equal(fb.msgs[:n_distinct], fb.msgs[n_distinct:2 * n_distinct])
+    assert torch.equal(marg[:400], marg[15 * n_distinct:15 * n_distinct + 400])
+    m1, g1 = fb.msgs[:64].clone(), marg[:64].clone()
+    try:
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(3))
+        fb.sweep(roots, init=True, marginals=marg)
+    finally:
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(1))
+    np.testing.assert_allclose(m1.cpu().numpy(), fb.msgs[:64].cpu().numpy(), rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(g1.cpu().numpy(), marg[:64].cpu().numpy(), rtol=1e-11, atol=1e-300)

@@ -479,7 +479,7 @@ int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (a->X == 64) {
     // shared pairwise tables: the pairwise factors of 16 graphs at a time on the matrix cores, after the unary part
-    const bool shared = (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->F_ee == 3 && a->P > 0 && a->P <= 16 && a->phi_en_en_p && a->phi_en_en_w1_p;
+    const bool shared = (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->F_ee == 3 && a->P > 0 && a->n_pair_tables <= 32 && a->phi_en_en_p && a->phi_en_en_w1_p;
     d.skip_pairs = shared ? 1 : 0;
     if (shared && a->unary_expect && a->F_ed == 6)               // unary part by gather inside the pair kernel
       return mlbp::launch_shared_pair_gradient(a, d.status, stream);

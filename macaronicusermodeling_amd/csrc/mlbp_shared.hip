@@ -275,7 +275,7 @@ struct SharedDev {
   int32_t B, n_sweeps, n_msgs, P, U, n_pair_tables, n_unary_tables, n_vars;
   int32_t n_ops, n_live, n_lists, n_cpw, n_back, n_fill, n_readout;
   int32_t vf_only;              // write back only the variable->factor messages (what the gradient reads)
-  const double* tfrag;          // [P][2][4096] A fragments of factor p's table (graph 0's row), or NULL
+  const double* tfrag;          // [n_pair_tables][2][4096] A fragments of every table (only when there are <= FRAG_TABLES), or NULL
 };
 
 #ifdef MLBP_STAMPS
@@ -304,15 +304,13 @@ __device__ int g_sh_ablate = 0;
     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s_ + 1], b[s_ + 1], acc1, 0, 0, 0); \
   }
 
-// out[p][0 | 1][wave w][k-step s][lane] = the A fragments of factor p's table (graph 0's pair_tab row) for T.m and
-// m^T.T: element (16w + (lane & 15), 4s + (lane >> 4)) of T resp. T^T.
-__global__ __launch_bounds__(WG) void table_fragments_kernel(const double* pair_tables, const int32_t* pair_tab,
-                                                             int n_pair_tables, double* out) {
-  const int p = blockIdx.x >> 1, mt = blockIdx.x & 1;
-  const int ti = pair_tab[p];
-  if ((unsigned)ti >= (unsigned)n_pair_tables) return;           // the sweep kernel raises the status word
+// out[table][0 | 1][wave w][k-step s][lane] = the A fragments of every table for T.m and m^T.T: element
+// (16w + (lane & 15), 4s + (lane >> 4)) of T resp. T^T.
+constexpr int FRAG_TABLES = 32;                                  // shared-table batches have a handful of tables
+__global__ __launch_bounds__(WG) void table_fragments_kernel(const double* pair_tables, double* out) {
+  const int ti = blockIdx.x >> 1, mt = blockIdx.x & 1;
   const double* T = pair_tables + (size_t)ti * 4096;
-  double* o = out + ((size_t)p * 2 + mt) * 4096;
+  double* o = out + ((size_t)ti * 2 + mt) * 4096;
   for (int e = threadIdx.x; e < 4096; e += WG) {
     const int lane = e & 63, s = (e >> 6) & 15, w = e >> 10;
     const int i = 16 * w + (lane & 15), k = 4 * s + (lane >> 4);
@@ -335,8 +333,7 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
   int32_t* ptab = utab + G * d.U;                                // [P] table of factor p
   int32_t* preg = ptab + d.P;                                    // [P] register set of factor p
   int32_t* dist = preg + d.P;                                    // [NTAB] distinct tables, then {count, overflow}
-  int32_t* dfac = dist + NTAB + 2;                               // [NTAB] first factor using distinct table r, then {row equals graph 0's}
-  int32_t* gflag = dfac + NTAB + 1;                              // [16] prologue verdict per graph
+  int32_t* gflag = dist + NTAB + 2;                              // [16] prologue verdict per graph
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int gl = lane & 15, cq = lane >> 4;                      // B/D operand: graph column, k-row
@@ -379,18 +376,17 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
     return;
   }
   if (t == 0) {
-    int nd = 0, over = 0, row0 = 1;
+    int nd = 0, over = 0;
     for (int p = 0; p < d.P; ++p) {
       int r = 0;
       while (r < nd && dist[r] != ptab[p]) ++r;
       if (r == nd) {
-        if (nd < NTAB) { dist[nd] = ptab[p]; dfac[nd++] = p; }
+        if (nd < NTAB) dist[nd++] = ptab[p];
         else { over = 1; r = 0; }
       }
       preg[p] = r;
-      row0 &= ptab[p] == d.pair_tab[p];                          // the row the fragment copies were made from
     }
-    dist[NTAB] = nd; dist[NTAB + 1] = over; dfac[NTAB] = row0;
+    dist[NTAB] = nd; dist[NTAB + 1] = over;
   }
   if (!__syncthreads_and(same ? 1 : 0) || dist[NTAB + 1]) {      // not a shared-table batch: exact kernel takes all 16
     if (t < G && g0 + t < d.B) d.bail[g0 + t] = 4;
@@ -404,11 +400,11 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
 #pragma unroll
   for (int r = 0; r < NTAB; ++r) {
     const int ti = __builtin_amdgcn_readfirstlane(dist[r < nd ? r : 0]);
-    if (d.tfrag && __builtin_amdgcn_readfirstlane(dfac[NTAB])) {
+    if (d.tfrag) {
       // copies in operand order (table_fragments_kernel): one contiguous 512-byte read per fragment; read
       // straight from the row-major table the same fragments are 16 rows x 32 bytes per instruction and kept
       // the CU's address unit busy for ~20 us per workgroup
-      const double* F = d.tfrag + (size_t)__builtin_amdgcn_readfirstlane(dfac[r < nd ? r : 0]) * 2 * 4096 + wave * 1024 + lane;
+      const double* F = d.tfrag + (size_t)ti * 2 * 4096 + wave * 1024 + lane;
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         aTM[r][s] = F[64 * s];
@@ -676,7 +672,7 @@ struct PairGradDev {
   const int32_t* c_slot; const int32_t* r_slot; const int32_t* pair_phi; const int32_t* pair_label;
   const double* phi[2];         // interleaved [64][64][3]: the label term
   const double* phi_p[2];       // planar [3][64][64]
-  const double* wfrag;          // [P][4][4096] A fragments of T (.) phi_k and T (pair_weight_fragments_kernel)
+  const double* wfrag;          // [table][which][4][4096] A fragments of T (.) phi_k and T (pair_weight_fragments_kernel)
   double* grad_en_en;           // [B][3], ADDED to (assigned when the unary part is done here too)
   int32_t* status;
   int32_t B, n_msgs, P, n_pair_tables;
@@ -687,21 +683,18 @@ struct PairGradDev {
 };
 
 constexpr int PG_MAXP = 3;      // pairwise factors per pass: their two message tiles each stay in LDS (48 KiB)
-constexpr int PG_MAXW = 16;     // pairwise factors the fragment scratch holds
+constexpr int PG_MAXW = 32;     // tables the fragment scratch holds (x 2 feature tensors x 4 planes x 32 KiB = 8 MiB)
 
-// W[p][k] = T_p (.) phi_k (k = 0..2) and T_p itself (k = 3), written in the order the MFMA A operand is read:
-// [p][k][wave w][k-step s][lane] = element (row 16w + (lane & 15), column 4s + (lane >> 4)).  Every fragment load
-// of the gradient kernel is then one contiguous 512-byte read (the direct form -- 16 rows x 32 bytes per
+// W[table][which][k] = T (.) phi_which,k (k = 0..2) and T itself (k = 3), written in the order the MFMA A operand
+// is read: [...][wave w][k-step s][lane] = element (row 16w + (lane & 15), column 4s + (lane >> 4)).  Every fragment
+// load of the gradient kernel is then one contiguous 512-byte read (the direct form -- 16 rows x 32 bytes per
 // instruction -- kept the CU's address unit busy for longer than the MFMAs took).
-__global__ __launch_bounds__(WG) void pair_weight_fragments_kernel(const double* pair_tables, const int32_t* pair_tab,
-                                                                   const int32_t* pair_phi, const double* phi_p0,
-                                                                   const double* phi_p1, int n_pair_tables, double* wfrag) {
-  const int p = blockIdx.x >> 2, k = blockIdx.x & 3;
-  const int ti = pair_tab[p];                                   // graph 0's row; the gradient kernel checks the others
-  if ((unsigned)ti >= (unsigned)n_pair_tables) return;
+__global__ __launch_bounds__(WG) void pair_weight_fragments_kernel(const double* pair_tables, const double* phi_p0,
+                                                                   const double* phi_p1, double* wfrag) {
+  const int ti = blockIdx.x >> 3, which = (blockIdx.x >> 2) & 1, k = blockIdx.x & 3;
   const double* T = pair_tables + (size_t)ti * 4096;
-  const double* ph = (pair_phi[p] ? phi_p1 : phi_p0) + (size_t)k * 4096;
-  double* out = wfrag + ((size_t)p * 4 + k) * 4096;
+  const double* ph = (which ? phi_p1 : phi_p0) + (size_t)k * 4096;
+  double* out = wfrag + (((size_t)ti * 2 + which) * 4 + k) * 4096;
   for (int e = threadIdx.x; e < 4096; e += WG) {
     const int lane = e & 63, s = (e >> 6) & 15, w = e >> 10;
     const int idx = (16 * w + (lane & 15)) * 64 + 4 * s + (lane >> 4);
@@ -730,7 +723,7 @@ __global__ __launch_bounds__(WG) void gradient_shared_pairs_kernel(PairGradDev d
     __syncthreads();
     for (int pp = 0; pp < np; ++pp) {
       const int p = p0 + pp;
-      const int ti = d.pair_tab[p];                            // the table the fragments were built from
+      const int ti = d.pair_tab[(size_t)g0 * d.P + p];
       bool ok = (unsigned)ti < (unsigned)d.n_pair_tables && d.pair_tab[(size_t)gc * d.P + p] == ti;
       const int l0 = d.pair_label[((size_t)gc * d.P + p) * 2], l1 = d.pair_label[((size_t)gc * d.P + p) * 2 + 1];
       ok &= (unsigned)l0 < 64u && (unsigned)l1 < 64u;
@@ -739,7 +732,7 @@ __global__ __launch_bounds__(WG) void gradient_shared_pairs_kernel(PairGradDev d
         if (cq == 0) for (int k = 0; k < 4; ++k) red[pp][wave][gl][k] = 0.0;
         continue;
       }
-      const double* W = d.wfrag + (size_t)p * 4 * 4096 + wave * 1024 + lane;
+      const double* W = d.wfrag + ((size_t)ti * 2 + (d.pair_phi[p] ? 1 : 0)) * 4 * 4096 + wave * 1024 + lane;
       const double* rt = tile[pp][0] + lane;                   // B operand: state 4s + (l >> 4), graph l & 15
       double4_t acc[4];
 #pragma unroll
@@ -880,11 +873,15 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables; d.n_vars = prog->n_vars;
   d.n_ops = sp.n_ops; d.n_live = sp.n_live; d.n_lists = sp.n_lists; d.n_cpw = sp.n_cpw; d.n_back = sp.n_back;
   d.n_fill = sp.n_fill; d.n_readout = n_readout;
-  if (!mp->d_tfrag) {                              // first use (a stream-capturing caller warms up or reserves first)
-    if (hipMalloc(&mp->d_tfrag, sizeof(double) * 16 * 2 * 4096) != hipSuccess) return fail(MLBP_EHIP, "fragment scratch allocation failed");
+  d.tfrag = nullptr;
+  if (a->n_pair_tables <= FRAG_TABLES) {
+    if (!mp->d_tfrag) {                            // first use (a stream-capturing caller warms up or reserves first)
+      if (hipMalloc(&mp->d_tfrag, sizeof(double) * FRAG_TABLES * 2 * 4096) != hipSuccess)
+        return fail(MLBP_EHIP, "fragment scratch allocation failed");
+    }
+    d.tfrag = mp->d_tfrag;
+    hipLaunchKernelGGL(table_fragments_kernel, dim3(a->n_pair_tables * 2), dim3(WG), 0, st, a->pair_tables, mp->d_tfrag);
   }
-  d.tfrag = mp->d_tfrag;
-  hipLaunchKernelGGL(table_fragments_kernel, dim3(prog->P * 2), dim3(WG), 0, st, a->pair_tables, a->pair_tab, a->n_pair_tables, mp->d_tfrag);
   int e = ntab == 2 ? launch<2>(d, lds, st) : launch<1>(d, lds, st);
   if (e) return e;
   if (d.msgs && !d.vf_only && sp.n_cpw > 0) {
@@ -913,12 +910,12 @@ int launch_shared_pair_gradient(const mlbp_gradient_args* a, int32_t* status, vo
   static std::mutex wmutex;
   {
     std::lock_guard<std::mutex> lock(wmutex);
-    if (!wfrag && hipMalloc(&wfrag, sizeof(double) * PG_MAXW * 4 * 4096) != hipSuccess)
+    if (!wfrag && hipMalloc(&wfrag, sizeof(double) * PG_MAXW * 2 * 4 * 4096) != hipSuccess)
       return fail(MLBP_EHIP, "shared-table pair gradient: scratch allocation failed");
   }
   d.wfrag = wfrag;
-  hipLaunchKernelGGL(pair_weight_fragments_kernel, dim3(a->P * 4), dim3(WG), 0, (hipStream_t)stream, a->pair_tables, a->pair_tab,
-                     a->pair_phi, a->phi_en_en_p, a->phi_en_en_w1_p, a->n_pair_tables, wfrag);
+  hipLaunchKernelGGL(pair_weight_fragments_kernel, dim3(a->n_pair_tables * 8), dim3(WG), 0, (hipStream_t)stream, a->pair_tables,
+                     a->phi_en_en_p, a->phi_en_en_w1_p, wfrag);
   hipLaunchKernelGGL(gradient_shared_pairs_kernel, dim3((a->B + G - 1) / G), dim3(WG), 0, (hipStream_t)stream, d);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table pair gradient launch failed");
   return MLBP_OK;

@@ -300,8 +300,8 @@ typedef struct mlbp_gradient_args {
 } mlbp_gradient_args;
 /* flags: pair_tab[b][p] is the same for every graph b (see MLBP_SWEEP_SHARED_PAIR_TABLES).  With X = 64,
  * F_ee = 3 and the planar feature copies given, the pairwise factors of 16 graphs at a time are then
- * contracted on the matrix cores ((T (.) phi_k) . r, four contractions per factor).  Groups of graphs for
- * which the claim does not hold are skipped and raise mlbp_gradient_status. */
+ * contracted on the matrix cores ((T (.) phi_k) . r, four contractions per factor).  Groups of 16 graphs for
+ * which the claim does not hold are computed one graph at a time inside the same kernel (correct, slower). */
 #define MLBP_GRADIENT_SHARED_PAIR_TABLES 1
 int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream);
 
@@ -337,6 +337,11 @@ int mlbp_patch_gradient_f64(const double* priv_tables, const int32_t* item_off, 
 /* out[j] = sum over rows of in[rows][cols], fixed summation order (bitwise reproducible): the
  * device half of batch_sgd_accumulate (train_mp.py:405-424). */
 int mlbp_sum_rows_f64(const double* in, int64_t rows, int32_t cols, double* out, void* stream);
+
+/* out[s][j] = sum of in[b][j] over the rows with seg_id[b] == s (DEVICE int32 [rows], values in [0, n_seg)), fixed
+ * order: the per-domain sums of batch_sgd_accumulate under --user_adapt / --experience_adapt (train_mp.py:413-415). */
+int mlbp_segment_sum_rows_f64(const double* in, int64_t rows, int32_t cols, const int32_t* seg_id, int32_t n_seg,
+                              double* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DEVICE: array primitives (the c_array_utils surface), batched over `batch` independent items

@@ -393,6 +393,27 @@ __global__ __launch_bounds__(WG) void sum_rows_kernel(const double* in, int64_t 
 }
 
 
+// out[s][j] = sum over the rows b with seg_id[b] == s of in[b][j]: one workgroup per segment, fixed order
+// (thread-strided partial sums, then a tree) -- the per-domain half of batch_sgd_accumulate (train_mp.py:413-415).
+__global__ __launch_bounds__(WG) void segment_sum_rows_kernel(const double* in, int64_t rows, int cols, const int32_t* seg_id,
+                                                              double* out) {
+  __shared__ double part[WG];
+  const int seg = blockIdx.x;
+  for (int j = 0; j < cols; ++j) {
+    double acc = 0.0;
+    for (int64_t b = threadIdx.x; b < rows; b += WG)
+      if (seg_id[b] == seg) acc += in[b * cols + j];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = WG / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)seg * cols + j] = part[0];
+    __syncthreads();
+  }
+}
+
 // ---- per-instance sparse feature planes (train_mp.py:178-217) ---------------------------------------
 // The reference rewrites three planes of phi_en_de per instance ('correct', 'full_history',
 // 'hit_history'); they are non-zero in a handful of cells.  Only cells in the observed column of one
@@ -534,6 +555,16 @@ int mlbp_sum_rows_f64(const double* in, int64_t rows, int32_t cols, double* out,
   if (cols > 64) return fail(MLBP_EUNSUPPORTED, "mlbp_sum_rows_f64: at most 64 columns (got %d)", cols);
   // the partials live in one device-wide scratch array: launches on DIFFERENT streams must not overlap
   hipLaunchKernelGGL(sum_rows_kernel, dim3(SUM_PARTS), dim3(WG), 0, (hipStream_t)stream, in, rows, cols, out);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_segment_sum_rows_f64(const double* in, int64_t rows, int32_t cols, const int32_t* seg_id, int32_t n_seg, double* out,
+                              void* stream) {
+  if (!in || !out || !seg_id || rows <= 0 || cols <= 0 || n_seg <= 0)
+    return fail(MLBP_EINVAL, "mlbp_segment_sum_rows_f64: bad arguments");
+  if (int e = need_device()) return e;
+  hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(n_seg), dim3(WG), 0, (hipStream_t)stream, in, rows, cols, seg_id, out);
   HIP_TRY(hipGetLastError());
   return MLBP_OK;
 }

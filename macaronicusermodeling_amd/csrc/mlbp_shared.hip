@@ -724,12 +724,33 @@ __global__ __launch_bounds__(WG) void gradient_shared_pairs_kernel(PairGradDev d
     for (int pp = 0; pp < np; ++pp) {
       const int p = p0 + pp;
       const int ti = d.pair_tab[(size_t)g0 * d.P + p];
-      bool ok = (unsigned)ti < (unsigned)d.n_pair_tables && d.pair_tab[(size_t)gc * d.P + p] == ti;
+      const int tg = d.pair_tab[(size_t)gc * d.P + p];
       const int l0 = d.pair_label[((size_t)gc * d.P + p) * 2], l1 = d.pair_label[((size_t)gc * d.P + p) * 2 + 1];
-      ok &= (unsigned)l0 < 64u && (unsigned)l1 < 64u;
-      if (!__all(ok)) {                                        // not the layout the caller claimed / a bad index
+      const bool valid = (unsigned)tg < (unsigned)d.n_pair_tables && (unsigned)l0 < 64u && (unsigned)l1 < 64u;
+      if (!__all(valid)) {                                     // a bad index: skip the factor, tell the caller
         if (t == 0) atomicExch(d.status, 1);
         if (cq == 0) for (int k = 0; k < 4; ++k) red[pp][wave][gl][k] = 0.0;
+        continue;
+      }
+      if (!__all(tg == ti)) {
+        // the 16 graphs do not share this factor's table (e.g. a group straddling two domains of the trainer):
+        // one graph at a time, every thread 16 cells of its table -- slow, correct, rare
+        const double* php = d.phi_p[d.pair_phi[p] ? 1 : 0];
+        for (int gg = 0; gg < G; ++gg) {
+          const double* Tg = d.pair_tables + (size_t)d.pair_tab[(size_t)(g0 + gg < d.B ? g0 + gg : d.B - 1) * d.P + p] * 4096;
+          double a[4] = {0.0, 0.0, 0.0, 0.0};
+          for (int e = t; e < 4096; e += WG) {
+            const double w = (tile[pp][1][(e >> 6) * G + gg] * tile[pp][0][(e & 63) * G + gg]) * Tg[e];
+            a[3] += w;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a[k] += w * php[k * 4096 + e];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const double v = wave_sum(a[k]);
+            if (lane == 0) red[pp][wave][gg][k] = v;
+          }
+        }
         continue;
       }
       const double* W = d.wfrag + ((size_t)ti * 2 + (d.pair_phi[p] ? 1 : 0)) * 4 * 4096 + wave * 1024 + lane;

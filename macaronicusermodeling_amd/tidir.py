@@ -125,7 +125,8 @@ def instance_shape(ti, en2id, de2id):
         if not ig['revealed']:
             planes['hit_history'].append((en2id[ig['guess']], de2id[ig['l2_word']], -1.0))
     return (len(sent), tuple(predicted)), dict(label=label, de_obs=de_obs, planes=planes,
-                                               sent_id=sent[0]['sent_id'], user_id=ti['user_id'])
+                                               sent_id=sent[0]['sent_id'], user_id=ti['user_id'],
+                                               n_seen=len(ti['past_sentences_seen']))
 
 
 def shape_spec(sent_len, predicted, X, Vde, name=None):

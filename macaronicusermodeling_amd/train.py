@@ -29,12 +29,17 @@ from .topology import GraphTopology
 
 class UserGraphTrainer:
     def __init__(self, spec, var_labels, unary_obs, phi_en_en, phi_en_en_w1, phi_en_de, theta_en_en, theta_en_de,
-                 device='cuda:0', sweeps=3, roots=None, planes=None):
+                 device='cuda:0', sweeps=3, roots=None, planes=None, domains=None, theta_dom_en_en=None,
+                 theta_dom_en_de=None):
         """spec: a 'trainmp'-style spec (tests/golden/cases.py: factors carry factor_type / gap);
         var_labels [B][n_vars], unary_obs [B][U]: this rank's shard of instances.
         planes: optional per-instance sparse feature planes, a list (one entry per instance) of
         {(i, j, k): value} -- cell (i, j) of phi_en_de[:, :, k] for this instance only
-        (train_mp.py:178-217 writes k = 2 'correct', 3 'full_history', 4 'hit_history')."""
+        (train_mp.py:178-217 writes k = 2 'correct', 3 'full_history', 4 'hit_history').
+        domains [B] + theta_dom_en_en [D][F_ee] + theta_dom_en_de [D][F_ed]: --user_adapt / --experience_adapt
+        (train_mp.py:162-171, 226-247): instance i builds its potentials from theta_dom[domains[i]] INSTEAD of the
+        global theta; the global theta still receives every instance's step.  Instances of one domain should be
+        contiguous (groups of 16 consecutive graphs that share their tables run on the matrix cores)."""
         self.spec = spec
         self.topo = topo = GraphTopology.from_spec(spec)
         by_id = {f['id']: f for f in spec['factors']}
@@ -67,18 +72,33 @@ class UserGraphTrainer:
         self.theta_en_de = theta_en_de if isinstance(theta_en_de, torch.Tensor) else \
             torch.as_tensor(np.asarray(theta_en_de, dtype=np.float64).reshape(-1)).to(dev)
         # pots: [pot_en_en, pot_en_en_w1] as pairwise tables; their transposes + pot_en_de^T as unary rows
-        self.pair_tables = torch.empty(2, X, X, dtype=torch.float64, device=dev)
+        as_theta = lambda t: t if isinstance(t, torch.Tensor) else torch.as_tensor(np.asarray(t, dtype=np.float64)).to(dev)   # noqa: E731
+        self.n_dom = 0
+        self._dom_host = np.zeros(B, dtype=np.int64)
+        if domains is not None:
+            self.theta_dom_en_en, self.theta_dom_en_de = as_theta(theta_dom_en_en), as_theta(theta_dom_en_de)
+            self.n_dom = int(self.theta_dom_en_en.shape[0])
+            self._dom_host = np.asarray(domains, dtype=np.int64).reshape(B)
+            if self.n_dom < 1 or self._dom_host.min() < 0 or self._dom_host.max() >= self.n_dom:
+                raise IndexError('domain index out of range')
+            if tuple(self.theta_dom_en_en.shape) != (self.n_dom, self.F_ee) or tuple(self.theta_dom_en_de.shape) != (self.n_dom, self.F_ed):
+                raise ValueError('theta_dom_* must be [D][F]')
+            self._dom = torch.from_numpy(self._dom_host.astype(np.int32)).to(dev)
+        nd = max(self.n_dom, 1)
+        self.rows_per_dom = 2 * X + self.Vde
+        self.pair_tables = torch.empty(2 * nd, X, X, dtype=torch.float64, device=dev)
         obs_np = np.asarray(unary_obs, dtype=np.int64).reshape(B, topo.U)
         self._plan_patches(planes, unary_kind, obs_np, np.asarray(var_labels, dtype=np.int64).reshape(B, topo.n_vars))
-        self.n_shared_rows = 2 * X + self.Vde
+        self.n_shared_rows = self.rows_per_dom * nd
         self.unary_tables = torch.empty(self.n_shared_rows + self.n_priv, X, dtype=torch.float64, device=dev)
         fb.pair_tables = self.pair_tables
-        fb.pair_tab = torch.from_numpy(np.tile(np.array(pair_phi or [0], dtype=np.int32), (B, 1))).to(dev)
+        ptab = np.tile(np.array(pair_phi or [0], dtype=np.int64), (B, 1)) + 2 * self._dom_host[:, None]
+        fb.pair_tab = torch.from_numpy(ptab.astype(np.int32)).to(dev)
         fb.pair_tables_shared = bool(topo.P)      # every instance reads the two pots: the MFMA kernels apply
         obs = obs_np
         base = np.array([0, X, 2 * X], dtype=np.int64)[np.array(unary_kind, dtype=np.int64)] if topo.U else np.zeros(0)
         fb.unary_tables = self.unary_tables
-        utab = obs + base[None, :]
+        utab = obs + base[None, :] + self.rows_per_dom * self._dom_host[:, None]
         for r, (b_i, u) in enumerate(self._priv_rows):          # patched factors read their private row
             utab[b_i, u] = self.n_shared_rows + r
         fb.unary_tab = torch.from_numpy(utab.astype(np.int32)).to(dev)
@@ -90,8 +110,12 @@ class UserGraphTrainer:
         self._g_ed = torch.empty(B, self.F_ed, dtype=torch.float64, device=dev)
         self._marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)
         self._lp = torch.empty(B, dtype=torch.float64, device=dev)
-        self._rows = torch.empty(B, self.F_ee + self.F_ed + 2, dtype=torch.float64, device=dev)
-        self.stats = torch.zeros(self.F_ee + self.F_ed + 2, dtype=torch.float64, device=dev)
+        n_stat = self.F_ee + self.F_ed + 2
+        self._rows = torch.empty(B, n_stat, dtype=torch.float64, device=dev)
+        # one buffer for the single all-reduce of a step: [global statistics | per-domain statistics [D][n_stat]]
+        self.stats_all = torch.zeros(n_stat * (1 + self.n_dom), dtype=torch.float64, device=dev)
+        self.stats = self.stats_all[:n_stat]
+        self.stats_dom = self.stats_all[n_stat:].view(self.n_dom, n_stat) if self.n_dom else None
 
     def _plan_patches(self, planes, unary_kind, obs, labels):
         """Host-side integer work: which (instance, en_de factor) pairs see a plane cell in their
@@ -113,9 +137,18 @@ class UserGraphTrainer:
                             raise IndexError('feature-plane cell out of range')
                         ix.append(i); ik.append(k); iv.append(float(v))
                     rows.append((b_i, u)); off.append(len(ix))
-                    rgraph.append(b_i); rbase.append(2 * X + col)
+                    rgraph.append(b_i); rbase.append(2 * X + col + self.rows_per_dom * int(self._dom_host[b_i]))
                     rlabel.append(int(labels[b_i, topo.fac_var[2 * topo.unary_factors[u]]]))
         self._priv_rows, self.n_priv = rows, len(rows)
+        # private rows of one domain must be contiguous (their exponent uses that domain's theta): instances come
+        # grouped by domain, so the row list already is; record the ranges
+        row_dom = [int(self._dom_host[b_i]) for b_i, _ in rows]
+        if any(row_dom[i] > row_dom[i + 1] for i in range(len(row_dom) - 1)):
+            raise ValueError('instances with feature planes must be grouped by domain')
+        self._priv_dom_ranges = []
+        for d in sorted(set(row_dom)):
+            lo = row_dom.index(d)
+            self._priv_dom_ranges.append((d, lo, lo + row_dom.count(d)))
         if self.n_priv:
             dev = self.device
             as_i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)          # noqa: E731
@@ -126,10 +159,12 @@ class UserGraphTrainer:
     def _patch_tables(self):
         if self.n_priv:
             priv = self.unary_tables[self.n_shared_rows:]
-            _ffi.check(_ffi.lib.mlbp_patch_unary_tables_f64(
-                self.unary_tables.data_ptr(), self._p_base.data_ptr(), self._p_off.data_ptr(), self._p_x.data_ptr(),
-                self._p_k.data_ptr(), self._p_val.data_ptr(), self.theta_en_de.data_ptr(), self.n_priv, self.spec['X'],
-                priv.data_ptr(), _stream_ptr(self.device)))
+            for d, lo, hi in self._priv_dom_ranges:          # one launch per domain present (its theta in the exponent)
+                theta = self.theta_dom_en_de[d] if self.n_dom else self.theta_en_de
+                _ffi.check(_ffi.lib.mlbp_patch_unary_tables_f64(
+                    self.unary_tables.data_ptr(), self._p_base[lo:].data_ptr(), self._p_off[lo:].data_ptr(), self._p_x.data_ptr(),
+                    self._p_k.data_ptr(), self._p_val.data_ptr(), theta.data_ptr(), hi - lo, self.spec['X'],
+                    priv[lo:].data_ptr(), _stream_ptr(self.device)))
 
     def _patch_gradient(self):
         if self.n_priv:
@@ -141,13 +176,16 @@ class UserGraphTrainer:
 
     def build_potentials(self):
         fb, X, st = self.batch, self.spec['X'], _stream_ptr(self.device)
-        ut = self.unary_tables
-        _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_en.data_ptr(), self.theta_en_en.data_ptr(), X, X, self.F_ee,
-                                                self.pair_tables[0].data_ptr(), ut[0:X].data_ptr(), st))
-        _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_en_w1.data_ptr(), self.theta_en_en.data_ptr(), X, X, self.F_ee,
-                                                self.pair_tables[1].data_ptr(), ut[X:2 * X].data_ptr(), st))
-        _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_de.data_ptr(), self.theta_en_de.data_ptr(), X, self.Vde,
-                                                self.F_ed, None, ut[2 * X:].data_ptr(), st))
+        for d in range(max(self.n_dom, 1)):             # per domain: its theta REPLACES the global one (train_mp.py:226-247)
+            t_ee = self.theta_dom_en_en[d] if self.n_dom else self.theta_en_en
+            t_ed = self.theta_dom_en_de[d] if self.n_dom else self.theta_en_de
+            ut = self.unary_tables[d * self.rows_per_dom:]
+            _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_en.data_ptr(), t_ee.data_ptr(), X, X, self.F_ee,
+                                                    self.pair_tables[2 * d].data_ptr(), ut[0:X].data_ptr(), st))
+            _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_en_w1.data_ptr(), t_ee.data_ptr(), X, X, self.F_ee,
+                                                    self.pair_tables[2 * d + 1].data_ptr(), ut[X:2 * X].data_ptr(), st))
+            _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_de.data_ptr(), t_ed.data_ptr(), X, self.Vde,
+                                                    self.F_ed, None, ut[2 * X:].data_ptr(), st))
         self._patch_tables()
 
     def capture(self):
@@ -169,7 +207,7 @@ class UserGraphTrainer:
         [sum_i grad_en_en (F_ee) | sum_i grad_en_de (F_ed) | sum_i log-posterior | instance count]."""
         if getattr(self, '_graph', None) is not None:
             self._graph.replay()
-            return self.stats
+            return self.stats_all if self.n_dom else self.stats
         return self._local_statistics_eager()
 
     def _local_statistics_eager(self):
@@ -186,15 +224,24 @@ class UserGraphTrainer:
         r[:, -2] = self._lp
         r[:, -1] = 1.0
         fb.sum_rows(r, out=self.stats)
+        if self.n_dom:
+            _ffi.check(_ffi.lib.mlbp_segment_sum_rows_f64(r.data_ptr(), fb.B, r.shape[1], self._dom.data_ptr(), self.n_dom,
+                                                          self.stats_dom.data_ptr(), _stream_ptr(self.device)))
+            return self.stats_all
         return self.stats
 
-    def step(self, learning_rate, reg_param):
+    def step(self, learning_rate, reg_param, reg_param_ua_scale=1.0):
         """One synchronous optimisation step over ALL ranks' shards: returns (mean log-posterior,
         theta_en_en, theta_en_de).  reg_param is FactorGraph.regularization_param, i.e. the reference's
-        `--reg_param / N` (train_mp.py:160)."""
+        `--reg_param / N` (train_mp.py:160); with domains the per-domain thetas take their own instances' steps
+        with the regulariser scaled by reg_param_ua_scale (train_mp.py:384-396, 413-415)."""
         stats = mdist.all_reduce_sum_(self.local_statistics())
-        apply_update(self.theta_en_en, self.theta_en_de, stats, self.F_ee, self.F_ed, learning_rate, reg_param)
-        return float(stats[-2].item() / stats[-1].item()), self.theta_en_en, self.theta_en_de
+        n_stat = self.F_ee + self.F_ed + 2
+        apply_update(self.theta_en_en, self.theta_en_de, stats[:n_stat], self.F_ee, self.F_ed, learning_rate, reg_param)
+        if self.n_dom:
+            apply_domain_update(self.theta_dom_en_en, self.theta_dom_en_de, stats[n_stat:].view(self.n_dom, n_stat),
+                                self.F_ee, self.F_ed, learning_rate, reg_param * reg_param_ua_scale)
+        return float(stats[n_stat - 2].item() / stats[n_stat - 1].item()), self.theta_en_en, self.theta_en_de
 
     def predict(self, top=50):
         """batch_predictions for the shard (train_mp.py:310-343): runs inference and returns
@@ -233,6 +280,15 @@ def apply_update(theta_en_en, theta_en_de, stats, F_ee, F_ed, learning_rate, reg
     return theta_en_en, theta_en_de
 
 
+def apply_domain_update(theta_dom_en_en, theta_dom_en_de, stats_dom, F_ee, F_ed, learning_rate, reg_param):
+    """theta_d += lr (sum_{i in d} g_i - n_d reg theta_d): the per-domain half of batch_sgd_accumulate
+    (train_mp.py:384-396, 413-415; `reg_param` already carries reg_param_ua_scale).  stats_dom: [D][F_ee+F_ed+2]."""
+    n = stats_dom[:, -1:]
+    theta_dom_en_en += learning_rate * (stats_dom[:, :F_ee] - n * reg_param * theta_dom_en_en)
+    theta_dom_en_de += learning_rate * (stats_dom[:, F_ee:F_ee + F_ed] - n * reg_param * theta_dom_en_de)
+    return theta_dom_en_en, theta_dom_en_de
+
+
 class TiDirTrainer:
     """The outer loop of train_mp.py's __main__ (train_mp.py:560-690) over files in the reference's
     formats: vocabularies, feature matrices, JSON training instances -> one UserGraphTrainer per
@@ -240,8 +296,14 @@ class TiDirTrainer:
     params written in the reference's text format."""
 
     def __init__(self, ti_path, en_vocab, de_vocab, phi_pmi, phi_pmi_w1, phi_ed, phi_ped, device='cuda:0', sweeps=3,
-                 rank=0, world=1, use_planes=True):
+                 rank=0, world=1, use_planes=True, adapt=None, domains=None, reg_param_ua_scale=1.0):
+        """adapt: None, 'user' (--user_adapt: domain = ti.user_id) or 'experience' (--experience_adapt: domain =
+        len(ti.past_sentences_seen)), train_mp.py:162-171; `domains`: the domain names in file order (the
+        reference reads <ti>.users / <ti>.experience, train_mp.py:504-516) -- default: the names that occur."""
         from . import tidir
+        if adapt not in (None, 'user', 'experience'):
+            raise ValueError("adapt is None, 'user' or 'experience'")
+        self.adapt, self.reg_param_ua_scale = adapt, float(reg_param_ua_scale)
         self.en, self.de = tidir.read_vocab(en_vocab), tidir.read_vocab(de_vocab)
         phi_ee, phi_w1, phi_ed_t = tidir.load_features(phi_pmi, phi_pmi_w1, phi_ed, phi_ped)
         instances = tidir.read_instances(ti_path)
@@ -251,9 +313,26 @@ class TiDirTrainer:
         dev = torch.device(device)
         self.theta_en_en = torch.zeros(len(tidir.EE_NAMES), dtype=torch.float64, device=dev)   # train_mp.py:519-523
         self.theta_en_de = torch.zeros(len(tidir.ED_NAMES), dtype=torch.float64, device=dev)
+        dom_of = (lambda r: str(r['user_id'])) if adapt == 'user' else (lambda r: str(r['n_seen']))
+        self.domains = []
+        if adapt:       # every rank needs the same list: it comes from ALL instances, not only this rank's shard
+            if domains is None:
+                en2id, de2id = {w: i for i, w in enumerate(self.en)}, {w: i for i, w in enumerate(self.de)}
+                domains = sorted({dom_of(tidir.instance_shape(ti, en2id, de2id)[1]) for ti in instances})
+            self.domains = [str(d) for d in domains]
+            self.theta_dom_en_en = torch.zeros(len(self.domains), len(tidir.EE_NAMES), dtype=torch.float64, device=dev)  # train_mp.py:524-527
+            self.theta_dom_en_de = torch.zeros(len(self.domains), len(tidir.ED_NAMES), dtype=torch.float64, device=dev)
+        dom_index = {d: i for i, d in enumerate(self.domains)}
         self.trainers = {}
         for key, b in sorted(self.buckets.items()):
             roots = [key[1][i % len(key[1])] for i in range(sweeps)]
+            extra = {}
+            if adapt:   # group the bucket's instances by domain: groups of 16 graphs then share their tables
+                dom = np.array([dom_index[dom_of(r)] for r in b['rows']], dtype=np.int64)
+                order = np.argsort(dom, kind='stable')
+                b['rows'] = [b['rows'][i] for i in order]
+                b['var_labels'], b['unary_obs'] = b['var_labels'][order], b['unary_obs'][order]
+                extra = dict(domains=dom[order], theta_dom_en_en=self.theta_dom_en_en, theta_dom_en_de=self.theta_dom_en_de)
             planes = None
             if use_planes:
                 feat = {'correct': tidir.ED_NAMES.index('correct'), 'full_history': tidir.ED_NAMES.index('full_history'),
@@ -267,17 +346,29 @@ class TiDirTrainer:
                     planes.append(cells)
             self.trainers[key] = UserGraphTrainer(b['spec'], b['var_labels'], b['unary_obs'], phi_ee, phi_w1, phi_ed_t,
                                                   self.theta_en_en, self.theta_en_de, device=device, sweeps=sweeps, roots=roots,
-                                                  planes=planes)
-        self.stats = torch.zeros(len(tidir.EE_NAMES) + len(tidir.ED_NAMES) + 2, dtype=torch.float64, device=dev)
+                                                  planes=planes, **extra)
+        self.n_stat = len(tidir.EE_NAMES) + len(tidir.ED_NAMES) + 2
+        self.stats = torch.zeros(self.n_stat * (1 + len(self.domains)), dtype=torch.float64, device=dev)
+
+    def domain_thetas(self):
+        """{('en_en' | 'en_de', domain name): (1, F) array} as train_mp's domain2theta / the params file."""
+        d2t = {}
+        for i, d in enumerate(self.domains):
+            d2t['en_en', d] = self.theta_dom_en_en[i].cpu().numpy().reshape(1, -1)
+            d2t['en_de', d] = self.theta_dom_en_de[i].cpu().numpy().reshape(1, -1)
+        return d2t
 
     def epoch(self, learning_rate, reg_param):
         self.stats.zero_()
         for tr in self.trainers.values():
             self.stats += tr.local_statistics()
-        mdist.all_reduce_sum_(self.stats)
-        apply_update(self.theta_en_en, self.theta_en_de, self.stats, len(self.theta_en_en), len(self.theta_en_de),
-                     learning_rate, reg_param)
-        return float(self.stats[-2].item() / max(self.stats[-1].item(), 1.0))
+        mdist.all_reduce_sum_(self.stats)                   # global and per-domain statistics in ONE reduction
+        n, F_ee, F_ed = self.n_stat, len(self.theta_en_en), len(self.theta_en_de)
+        apply_update(self.theta_en_en, self.theta_en_de, self.stats[:n], F_ee, F_ed, learning_rate, reg_param)
+        if self.domains:
+            apply_domain_update(self.theta_dom_en_en, self.theta_dom_en_de, self.stats[n:].view(len(self.domains), n), F_ee, F_ed,
+                                learning_rate, reg_param * self.reg_param_ua_scale)
+        return float(self.stats[n - 2].item() / max(self.stats[n - 1].item(), 1.0))
 
     def train(self, epochs=3, reg_param=0.2, save_params=None):
         """lr = 0.1 / (1 + 0.3 epoch) (train_mp.py:627-630); regularisation reg_param / N (train_mp.py:160);
@@ -288,10 +379,10 @@ class TiDirTrainer:
             history.append(self.epoch(0.1 / (1.0 + 0.3 * epoch), float(reg_param) / float(self.n_total)))
             if save_params:
                 tidir.save_params('%s.iter%d' % (save_params, epoch), self.theta_en_en.cpu().numpy().reshape(1, -1),
-                                  self.theta_en_de.cpu().numpy().reshape(1, -1))
+                                  self.theta_en_de.cpu().numpy().reshape(1, -1), d2t=self.domain_thetas())
         if save_params:
             tidir.save_params(save_params, self.theta_en_en.cpu().numpy().reshape(1, -1),
-                              self.theta_en_de.cpu().numpy().reshape(1, -1))
+                              self.theta_en_de.cpu().numpy().reshape(1, -1), d2t=self.domain_thetas())
         return history
 
     def predict(self):

@@ -89,3 +89,27 @@ def test_shard_range_covers_everything_once():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def test_domain_update_rule():
+    """apply_domain_update == the per-domain half of batch_sgd_accumulate (train_mp.py:384-396, 413-415):
+    theta_d += sum_{i in d} lr (g_i - reg theta_d), written as lr (sum g - n_d reg theta_d); a domain with no
+    instance on any rank keeps its theta."""
+    from macaronicusermodeling_amd.train import apply_domain_update
+    rs = np.random.RandomState(0)
+    D, lr, reg = 4, 0.07, 0.03
+    th_ee, th_ed = rs.randn(D, C.F_EE), rs.randn(D, C.F_ED)
+    counts = [3, 0, 1, 5]
+    g = [[rs.randn(C.F_EE + C.F_ED) for _ in range(n)] for n in counts]
+    stats = np.zeros((D, C.F_EE + C.F_ED + 2))
+    want_ee, want_ed = th_ee.copy(), th_ed.copy()
+    for d in range(D):
+        for gi in g[d]:
+            stats[d, :C.F_EE + C.F_ED] += gi; stats[d, -1] += 1
+            want_ee[d] += lr * (gi[:C.F_EE] - reg * th_ee[d])        # apply_regularization per instance, same theta
+            want_ed[d] += lr * (gi[C.F_EE:] - reg * th_ed[d])
+    t_ee, t_ed = torch.from_numpy(th_ee.copy()), torch.from_numpy(th_ed.copy())
+    apply_domain_update(t_ee, t_ed, torch.from_numpy(stats), C.F_EE, C.F_ED, lr, reg)
+    np.testing.assert_allclose(t_ee.numpy(), want_ee, rtol=1e-12)
+    np.testing.assert_allclose(t_ed.numpy(), want_ed, rtol=1e-12)
+    np.testing.assert_array_equal(t_ee.numpy()[1], th_ee[1])

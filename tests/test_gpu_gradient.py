@@ -254,3 +254,115 @@ def test_tidir_trainer_epochs_and_predictions(tmp_path):
     tot, want_counts = oracle_pass(th_ee, th_ed, want_counts=True)
     np.testing.assert_allclose(mean_lp, tot[9] / 24, rtol=1e-9)
     assert counts == tuple(int(v) for v in want_counts)
+
+
+def _pots(inputs, th_ee, th_ed, X=64):
+    d = dict(inputs)
+    d['theta_en_en'], d['theta_en_de'] = th_ee, th_ed
+    d['pot_en_en'] = np.exp(inputs['phi_en_en'].dot(th_ee.T).reshape(X, X))
+    d['pot_en_en_w1'] = np.exp(inputs['phi_en_en_w1'].dot(th_ee.T).reshape(X, X))
+    d['pot_en_de'] = np.exp(inputs['phi_en_de'].dot(th_ed.T).reshape(X, -1))
+    return d
+
+
+def test_train_step_with_per_domain_thetas():
+    """--user_adapt / --experience_adapt (train_mp.py:162-171, 226-247, 384-396, 413-415): instance i builds its
+    potentials from theta_dom[d_i] instead of the global theta; the global theta takes every instance's step, each
+    domain theta the steps of its own instances with the regulariser scaled.  Domain sizes 17 / 5 / 18 make groups
+    of 16 graphs straddle domains: those groups leave the matrix-core kernels for the per-graph ones."""
+    import copy
+    from macaronicusermodeling_amd.train import UserGraphTrainer
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = C.user_spec(10, [1, 4, 7], 64, 48, seed=1)
+    topo = GraphTopology.from_spec(spec)
+    inputs = C.make_inputs(spec, 77)
+    rs = np.random.RandomState(3)
+    D, sizes = 3, [17, 5, 18]
+    B = sum(sizes)
+    dom = np.repeat(np.arange(D), sizes)
+    th_dom_ee, th_dom_ed = rs.randn(D, 3) * 0.3, rs.randn(D, 6) * 0.3
+    roots, lr, reg, scale = [4, 1, 7], 0.1, 0.2 / B, 0.5
+    labels, obs = _instances(spec, topo, B, 5)
+    tr = UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],
+                          inputs['theta_en_en'], inputs['theta_en_de'], roots=roots, domains=dom,
+                          theta_dom_en_en=th_dom_ee.copy(), theta_dom_en_de=th_dom_ed.copy())
+    stats = tr.local_statistics().cpu().numpy().copy()
+    assert tr.batch.program(roots).exact_count(B) > 0          # the straddling groups were redone per graph
+    want = np.zeros((1 + D, 11))
+    g0 = O.Graph(copy.deepcopy(spec))
+    unary_ids = [f['id'] for f in g0.factors if len(f['vars']) == 1]
+    for b in range(B):
+        s = copy.deepcopy(spec)
+        s['labels'] = [int(labels[b, g0.var_order.index(v)]) for v in s['var_ids']]
+        for f in s['factors']:
+            if len(f['vars']) == 1:
+                f['observed_dim'] = int(obs[b, unary_ids.index(f['id'])])
+        inp = _pots(inputs, th_dom_ee[dom[b]].reshape(1, -1), th_dom_ed[dom[b]].reshape(1, -1))
+        g = O.Graph(s); msgs = O.init_messages(g)
+        O.treelike_inference(g, inp, msgs, 3, roots, O.has_loops(g, roots[0]))
+        ee, ed = O.unregularized_gradient(g, inp, msgs)
+        row = np.concatenate([ee.reshape(-1), ed.reshape(-1), [O.log_posterior(g, msgs), 1.0]])
+        want[0] += row; want[1 + dom[b]] += row
+    np.testing.assert_allclose(stats.reshape(1 + D, 11), want, rtol=1e-8, atol=1e-10)
+    mean_lp, t_ee, t_ed = tr.step(lr, reg, reg_param_ua_scale=scale)
+    np.testing.assert_allclose(mean_lp, want[0, 9] / B, rtol=1e-10)
+    th0_ee, th0_ed = inputs['theta_en_en'].reshape(-1), inputs['theta_en_de'].reshape(-1)
+    np.testing.assert_allclose(t_ee.cpu().numpy(), th0_ee + lr * (want[0, :3] - B * reg * th0_ee), rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(t_ed.cpu().numpy(), th0_ed + lr * (want[0, 3:9] - B * reg * th0_ed), rtol=1e-8, atol=1e-11)
+    for d in range(D):
+        np.testing.assert_allclose(tr.theta_dom_en_en[d].cpu().numpy(),
+                                   th_dom_ee[d] + lr * (want[1 + d, :3] - sizes[d] * reg * scale * th_dom_ee[d]), rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(tr.theta_dom_en_de[d].cpu().numpy(),
+                                   th_dom_ed[d] + lr * (want[1 + d, 3:9] - sizes[d] * reg * scale * th_dom_ed[d]), rtol=1e-8, atol=1e-11)
+
+
+def test_tidir_trainer_user_adapt(tmp_path):
+    """TiDirTrainer(adapt='user'): domains from ti.user_id, per-domain rows in the params file (train_mp.py:80-102),
+    one epoch from zero parameters against the oracle (all thetas zero -> every pot is 1: the per-domain sums are
+    what is being checked), then a second epoch that must move the domain thetas apart."""
+    import copy
+    from macaronicusermodeling_amd import tidir
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    paths = tidir.synthesize(str(tmp_path), n_instances=30, X=64, Vde=64, sent_len=(4, 6), n_predicted=(1, 3), seed=9)
+    tt = TiDirTrainer(paths['ti'], paths['end'], paths['ded'], paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'],
+                      paths['phi_ped'], sweeps=3, adapt='user', reg_param_ua_scale=0.5)
+    assert len(tt.domains) > 1
+    phi_ee, phi_w1, phi_ed = tidir.load_features(paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'], paths['phi_ped'])
+    D = len(tt.domains)
+    tot = np.zeros((1 + D, 11))
+    feat = {'correct': 2, 'full_history': 3, 'hit_history': 4}
+    th_ee, th_ed = np.zeros((1, 3)), np.zeros((1, 6))
+    for key, b in sorted(tt.buckets.items()):
+        unary = [f for f in sorted(b['spec']['factors'], key=lambda f: f['id']) if len(f['vars']) == 1]
+        roots = [key[1][i % len(key[1])] for i in range(3)]
+        for i, r in enumerate(b['rows']):
+            s = copy.deepcopy(b['spec'])
+            s['labels'] = [int(v) for v in b['var_labels'][i]]
+            for u, f in enumerate(unary):
+                s['factors'][f['id']]['observed_dim'] = int(b['unary_obs'][i, u])
+            phi_i = phi_ed.copy()
+            for name, k in feat.items():
+                plane = np.zeros((64, 64))
+                for ci, cj, cv in r['planes'][name]:
+                    plane[ci, cj] += cv
+                phi_i[:, :, k] = plane
+            inp = _pots(dict(phi_en_en=phi_ee, phi_en_en_w1=phi_w1, phi_en_de=phi_i), th_ee, th_ed)
+            g = O.Graph(s); msgs = O.init_messages(g)
+            O.treelike_inference(g, inp, msgs, 3, roots, O.has_loops(g, roots[0]))
+            ee, ed = O.unregularized_gradient(g, inp, msgs)
+            row = np.concatenate([ee.reshape(-1), ed.reshape(-1), [O.log_posterior(g, msgs), 1.0]])
+            tot[0] += row; tot[1 + tt.domains.index(str(r['user_id']))] += row
+    save = os.path.join(str(tmp_path), 'params.user_adapt')
+    hist = tt.train(epochs=1, reg_param=0.2, save_params=save)
+    np.testing.assert_allclose(hist[0], tot[0, 9] / 30, rtol=1e-9)
+    np.testing.assert_allclose(tt.theta_en_de.cpu().numpy(), 0.1 * tot[0, 3:9], rtol=1e-8, atol=1e-11)
+    for d in range(D):
+        np.testing.assert_allclose(tt.theta_dom_en_en[d].cpu().numpy(), 0.1 * tot[1 + d, :3], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(tt.theta_dom_en_de[d].cpu().numpy(), 0.1 * tot[1 + d, 3:9], rtol=1e-8, atol=1e-11)
+    _, _, _, _, d2t = tidir.read_params(save)
+    assert set(d2t) == {(ft, d) for ft in ('en_en', 'en_de') for d in tt.domains}
+    np.testing.assert_allclose(d2t['en_de', tt.domains[0]].reshape(-1), 0.1 * tot[1, 3:9], atol=1e-6)
+    before = tt.theta_dom_en_de.clone()
+    tt.epoch(0.1, 0.2 / 30)
+    assert not torch.equal(before, tt.theta_dom_en_de)
+    assert float((tt.theta_dom_en_de[0] - tt.theta_dom_en_de[1]).abs().max()) > 0

@@ -29,14 +29,17 @@ from macaronicusermodeling_amd.batch import FactorGraphBatch  # noqa: E402
 from macaronicusermodeling_amd.topology import GraphTopology  # noqa: E402
 
 spec, roots, sweeps, seed = bench.workload_spec('user_k3_shared')
-X, B = spec['X'], int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+X, B = spec['X'], int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8192
 topo = GraphTopology.from_spec(spec)
 dev = torch.device('cuda:0')
 fb = FactorGraphBatch(topo, X, B, device=dev)
 by_id = {f['id']: f for f in spec['factors']}
 which = [0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1 for j in topo.pair_factors]
 fb.set_pair_tables(torch.rand(2, X, X, dtype=torch.float64, device=dev) + 0.01, np.tile(np.array(which), (B, 1)))
-fb.set_unary_tables(torch.rand(B * topo.U, X, dtype=torch.float64, device=dev) + 0.01)
+if '--shared-unary' in sys.argv:      # the trainer's layout: every unary table is one of 192 rows of the transposed pots (L2-resident)
+    fb.set_unary_tables(torch.rand(192, X, dtype=torch.float64, device=dev) + 0.01, np.random.RandomState(0).randint(0, 192, size=(B, topo.U)))
+else:
+    fb.set_unary_tables(torch.rand(B * topo.U, X, dtype=torch.float64, device=dev) + 0.01)
 marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)
 names = ['A: indices/image/init', 'B: table fragment loads issued', 'C: unary -> products + barrier', 'loop: tile reads + products',
          'loop: mfma + store', 'loop: barrier', 'epilogue', 'loop: column sum + v->f stores']

@@ -47,7 +47,7 @@ def workload_spec(name):
         return C.chain_spec(8, 64), [0] * 10, 10, 1235
     if name == 'ring8':
         return C.ring_spec(8, 64), [0] * 10, 10, 1235
-    if name in ('ring8_x512', 'ring8_x512_f32'):
+    if name in ('ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared'):
         return C.ring_spec(8, 512), [0] * 10, 10, 1238
     raise SystemExit('unknown workload %s' % name)
 
@@ -131,7 +131,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32'],
+    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared'],
                     help='user_k3_shared = the same graphs with the reference\'s table layout: all graphs share the two '
                          'en_en pots (MFMA kernel, reported against the f64 matrix peak)')
     ap.add_argument('--no-writeback', action='store_true', help='shared workload: skip the message write-back (read-out only)')
@@ -187,7 +187,10 @@ def main():
     fb = FactorGraphBatch(topo, X, B, device=dev)
     shared = a.workload.endswith('_shared')
     unary = torch.rand(B * topo.U, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
-    if shared:      # LBP.py:456-467: pot_en_en behind the gap > 1 factors, pot_en_en_w1 behind the gap == 1 ones
+    if shared and spec['style'] == 'explicit':      # one table per factor, the same for every graph (X = 512: batched DGEMMs)
+        pair = torch.rand(topo.P, X, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
+        fb.set_pair_tables(pair, np.tile(np.arange(topo.P), (B, 1)))
+    elif shared:    # LBP.py:456-467: pot_en_en behind the gap > 1 factors, pot_en_en_w1 behind the gap == 1 ones
         pair = torch.rand(2, X, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
         by_id = {f['id']: f for f in spec['factors']}
         which = [0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1 for j in topo.pair_factors]
@@ -273,7 +276,10 @@ def main():
         table_elem = 4 if a.workload.endswith('_f32') else 8
         alg_bytes = algorithmic_bytes_per_graph(topo, roots, X, table_elem=table_elem) * B
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        used_mfma = shared and _ffi.lib.mlbp_last_sweep_kernel() == 3
+        used_mfma = shared and _ffi.lib.mlbp_last_sweep_kernel() in (3, 6)
+        mfma_kernel = ('sweep_x64_shared_kernel (v_mfma_f64_16x16x4_f64; timed region also holds the flag memset and the fix-up pass)'
+                       if _ffi.lib.mlbp_last_sweep_kernel() == 3 else
+                       'rocBLAS DGEMM per factor->variable update over the whole batch + renormalise / variable-update kernels (mlbp_gemm.hip)')
         if used_mfma:      # shared-table mode is priced in flops, 2 X^2 per pairwise update and graph
             n_pair = sum(int(np.isin(topo.compile_sweep(r)[0][:, 0], (_ffi.OP_PAIR_TM, _ffi.OP_PAIR_MT)).sum()) for r in roots)
             alg_flops = 2.0 * X * X * n_pair * B
@@ -284,15 +290,14 @@ def main():
             'dtype': 'f64 (f32 tables)' if a.workload.endswith('_f32') else 'f64', 'data': 'synthetic',
             'config': {'workload': '%s: %d graphs/GPU, |X|=%d, P=%d pairwise + U=%d unary factors, unique %s '
                                    'table per (graph,factor)%s, step = initialize + %d sweeps + posterior read-out'
-                                   % (a.workload, B, X, topo.P, topo.U, 'f32 pairwise / f64 unary' if a.workload.endswith('_f32') else 'f64', ' EXCEPT the pairwise tables: two pots shared by all graphs' if shared else '', sweeps),
+                                   % (a.workload, B, X, topo.P, topo.U, 'f32 pairwise / f64 unary' if a.workload.endswith('_f32') else 'f64', ' EXCEPT the pairwise tables: shared by all graphs' if shared else '', sweeps),
                        'graphs_per_gpu': B, 'X': X, 'sweeps_per_step': sweeps, 'roots': list(roots),
                        'graph_sweeps_per_s': world * B * sweeps * a.steps / elapsed,
                        'parallelism': 'graphs sharded over %d GPU(s), no data-path collective; one all-reduce of the '
                                       'step statistics per step (%s)' % (world, backend if world > 1 else 'n/a')},
             'roofline': {'bound': 'mfma', 'achieved': alg_flops / (avg_ms * 1e-3) / 1e12, 'peak': F64_MFMA_PEAK_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': alg_flops / (avg_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                         'traffic_source': traffic_src, 'kernel': 'sweep_x64_shared_kernel (v_mfma_f64_16x16x4_f64; timed region also holds '
-                         'the flag memset and the fix-up pass)', 'algorithmic_flops_per_launch': alg_flops,
+                         'traffic_source': traffic_src, 'kernel': mfma_kernel, 'algorithmic_flops_per_launch': alg_flops,
                          'avg_launch_ms': avg_ms, 'min_launch_ms': sweep_ms[0], 'max_launch_ms': sweep_ms[-1],
                          'hbm_equivalent_GBps_if_tables_were_unique': achieved} if used_mfma else
                         {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

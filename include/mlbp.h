@@ -178,6 +178,12 @@ typedef struct mlbp_sweep_args {
                                  pairwise factors and the transposed feature tensors are given;
                                  otherwise by mlbp_gradient_f64 enqueued behind the sweeps            */
   int32_t flags;              /* MLBP_SWEEP_* bits, 0 = none                                        */
+  const int32_t* pair_tab_host;
+                              /* HOST int32 [P] or NULL: with MLBP_SWEEP_SHARED_PAIR_TABLES, the pair_tab row
+                                 every graph has.  Needed for X >= 128, where the sweeps then run op by op
+                                 over the whole batch with one DGEMM (rocBLAS) per factor->variable update;
+                                 the statement is checked on the device, a false one raises
+                                 mlbp_program_status to 2                                            */
   const float* pair_tables_f32;
                               /* device [n_pair_tables][X][X] float32, read instead of pair_tables
                                  when MLBP_SWEEP_PAIR_TABLES_F32 is set                             */
@@ -225,6 +231,7 @@ int mlbp_set_sweep_variant(int32_t variant);
 #define MLBP_KERNEL_SHARED_MFMA 3
 #define MLBP_KERNEL_WIDE 4
 #define MLBP_KERNEL_GENERIC 5
+#define MLBP_KERNEL_SHARED_GEMM 6
 int mlbp_last_sweep_kernel(void);
 
 /* Fills msgs[B][n_msgs][X] with 1/X: FactorGraph.initialize (LBP.py:211-216). */

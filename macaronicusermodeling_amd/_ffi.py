@@ -45,7 +45,7 @@ class SweepArgs(C.Structure):
                 ('n_unary_tables', C.c_int32), ('pair_tables', C.c_void_p), ('pair_tab', C.c_void_p),
                 ('unary_tables', C.c_void_p), ('unary_tab', C.c_void_p), ('msgs', C.c_void_p),
                 ('normalize_messages', C.c_int32), ('init_messages', C.c_int32), ('marginals', C.c_void_p), ('gradient', C.c_void_p),
-                ('flags', C.c_int32), ('pair_tables_f32', C.c_void_p)]
+                ('flags', C.c_int32), ('pair_tab_host', C.c_void_p), ('pair_tables_f32', C.c_void_p)]
 
 
 SWEEP_SHARED_PAIR_TABLES = 1      # include/mlbp.h MLBP_SWEEP_*

@@ -103,6 +103,7 @@ class FactorGraphBatch:
         # every graph reads the same table for factor p (the reference's layout: one pot array behind all
         # pairwise factors): eligible for the shared-table kernel, which re-checks it on the device
         self.pair_tables_shared = bool(self.topo.P) and bool((host_tab == host_tab[:1]).all())
+        self._pair_row_host = np.ascontiguousarray(host_tab[0], dtype=np.int32) if self.pair_tables_shared else None
         self.pair_tab = self._as_index(host_tab, self.B, self.topo.P, t.shape[0], 'pair table', self.device)
         self.pair_tables = t
 
@@ -163,6 +164,8 @@ class FactorGraphBatch:
         a.init_messages = 1 if init else 0
         if getattr(self, 'pair_tables_shared', False):
             a.flags |= _ffi.SWEEP_SHARED_PAIR_TABLES
+            if getattr(self, '_pair_row_host', None) is not None:       # X >= 128: op-by-op DGEMM path needs the row on the host
+                a.pair_tab_host = self._pair_row_host.ctypes.data
             if not keep_messages and (marginals is not None or gradient is not None):
                 a.flags |= _ffi.SWEEP_NO_MESSAGE_WRITEBACK
         if marginals is not None:

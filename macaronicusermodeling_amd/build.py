@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libmlbp.so')
-SOURCES = ['mlbp_host.cpp', 'mlbp_sweep.hip', 'mlbp_shared.hip', 'mlbp_prims.hip', 'mlbp_grad.hip']
+SOURCES = ['mlbp_host.cpp', 'mlbp_sweep.hip', 'mlbp_shared.hip', 'mlbp_gemm.hip', 'mlbp_prims.hip', 'mlbp_grad.hip']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fno-fast-math', '-Wall',
          '-Wno-unused-function']
 
@@ -37,7 +37,7 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
         objs.append(obj)
     if force or _stale(LIB, objs):
-        subprocess.check_call([hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', LIB] + objs)
+        subprocess.check_call([hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', LIB] + objs + ['-ldl'])
     return LIB
 
 

@@ -45,6 +45,8 @@ bool build_shared_readout(const SharedProgram& sp, int n_msgs, int n_vars, const
 int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched);
 // Pairwise part of the gradient for shared tables (X = 64, F_ee = 3), ADDED to a->grad_en_en.
 int launch_shared_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void* stream);
+// Shared tables at X >= 128: the sweeps op by op over the whole batch, contractions as DGEMMs (mlbp_gemm.hip).
+int launch_gemm_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
 }  // namespace mlbp
 
 // Device-resident, validated op list (see mlbp_program_create).
@@ -74,7 +76,8 @@ struct mlbp_program {
   int32_t* d_simage;      // SharedProgram::image
   int32_t* d_sreadout;    // per variable: base tile, count, live tiles (4-word aligned lists) or NULL
   int32_t n_sreadout;
-  double* d_tfrag;        // [16][2][4096] table fragments in MFMA operand order (lazily allocated)
+  double* d_tfrag;        // [32][2][4096] table fragments in MFMA operand order (lazily allocated)
+  std::vector<int32_t> h_ops, h_sweeps;   // host copies of the validated op list (the op-by-op GEMM path walks them)
 };
 
 #endif

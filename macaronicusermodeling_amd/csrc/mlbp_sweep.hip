@@ -1717,6 +1717,8 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
   p->n_readout = 0;
   p->d_simage = p->d_sreadout = nullptr;
   p->d_tfrag = nullptr;
+  p->h_ops.assign(ops, ops + 4 * (size_t)n_ops);
+  p->h_sweeps.assign(sweeps, sweeps + 2 * (size_t)n_sweeps);
   p->n_sreadout = 0;
   mlbp::build_shared_program(fp, n_msgs, P, U, p->shared);
   if (p->shared.ok && e == hipSuccess) e = up(&p->d_simage, p->shared.image.data(), p->shared.image.size());
@@ -1873,6 +1875,20 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       if (int e = ensure_dynamic_lds((const void*)k, lds)) return e;
       hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, st, d);
       HIP_TRY(hipGetLastError());
+      if (a->marginals)
+        if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
+                                       prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;
+      if (a->gradient) return mlbp_gradient_f64(a->gradient, stream);
+      return MLBP_OK;
+    }
+  }
+  if ((a->flags & MLBP_SWEEP_SHARED_PAIR_TABLES) && a->pair_tab_host && a->X >= 128 && !(a->flags & MLBP_SWEEP_PAIR_TABLES_F32) &&
+      prog->P >= 1 && prog->P <= 16 && (variant == 1 || variant == 30)) {
+    // shared tables at a large state space: every contraction is one DGEMM over the whole batch
+    const int eg = mlbp::launch_gemm_sweep(prog, a, stream);
+    if (eg != MLBP_EUNSUPPORTED) {                 // unsupported (no rocBLAS on this machine): the per-graph kernels below
+      if (eg) return eg;
+      g_last_kernel = MLBP_KERNEL_SHARED_GEMM;
       if (a->marginals)
         if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
                                        prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;

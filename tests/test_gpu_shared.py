@@ -216,3 +216,52 @@ def test_full_size_properties_of_the_shared_kernel():
         _ffi.check(_ffi.lib.mlbp_set_sweep_variant(1))
     np.testing.assert_allclose(m1.cpu().numpy(), fb.msgs[:64].cpu().numpy(), rtol=1e-11, atol=1e-300)
     np.testing.assert_allclose(g1.cpu().numpy(), marg[:64].cpu().numpy(), rtol=1e-11, atol=1e-300)
+
+
+@pytest.mark.parametrize('X', [128, 512])
+def test_large_state_shared_tables_run_as_batched_gemms(X):
+    """X >= 128 with shared pairwise tables: the sweeps run op by op over the whole batch, every factor->variable
+    update one DGEMM (mlbp_gemm.hip).  Against the oracle per graph and against the per-graph wide kernel on the
+    same inputs (same updates, only the summation order inside the contraction differs)."""
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.batch import FactorGraphBatch
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = C.ring_spec(5, X)
+    topo = GraphTopology.from_spec(spec)
+    B = 9
+    inputs = [C.make_inputs(spec, 31 + 1000 * b) for b in range(B)]
+    g = O.Graph(spec)
+    pair = np.stack([O.factor_table(g, inputs[0], g.by_id[topo.factor_ids[j]]).reshape(X, X) for j in topo.pair_factors])
+    for b in range(1, B):                       # every graph: graph 0's pairwise tables, its own unary columns
+        tabs = list(inputs[b]['tables'])
+        for f in spec['factors']:
+            if len(f['vars']) == 2:
+                tabs[f['table']] = inputs[0]['tables'][f['table']]
+        inputs[b] = dict(tables=tabs)
+    unary = np.stack([O.factor_table(g, inputs[b], g.by_id[topo.factor_ids[j]]).reshape(X) for b in range(B) for j in topo.unary_factors])
+    fb = FactorGraphBatch(topo, X, B)
+    fb.set_pair_tables(pair, np.tile(np.arange(topo.P), (B, 1)))
+    fb.set_unary_tables(unary)
+    roots = [0, 3, 0]
+    marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=fb.device)
+    fb.msgs.fill_(float('nan'))
+    prog = fb.sweep(roots, init=True, marginals=marg)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 6, _ffi.lib.mlbp_last_error()      # MLBP_KERNEL_SHARED_GEMM
+    assert prog.status() == 0
+    got, gm = fb.msgs.clone(), marg.clone()
+    try:
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(3))                             # per-graph kernels on the same inputs
+        fb.sweep(roots, init=True, marginals=marg)
+        assert _ffi.lib.mlbp_last_sweep_kernel() == 4
+    finally:
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(1))
+    np.testing.assert_allclose(got.cpu().numpy(), fb.msgs.cpu().numpy(), rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(gm.cpu().numpy(), marg.cpu().numpy(), rtol=1e-11, atol=1e-300)
+    for b in (0, B - 1):
+        _, _, want = oracle_msgs(spec, inputs[b], roots)
+        np.testing.assert_allclose(got[b].cpu().numpy(), want, rtol=RTOL, atol=1e-300)
+    # a false sharing statement is reported, not silently computed
+    tab = fb.pair_tab.cpu().numpy().copy(); tab[4, 1] = tab[4, 0]
+    fb.pair_tab = torch.from_numpy(tab).to(fb.device)
+    prog = fb.sweep(roots, init=True)
+    assert prog.status() == 2

@@ -256,6 +256,27 @@ def test_tidir_trainer_epochs_and_predictions(tmp_path):
     assert counts == tuple(int(v) for v in want_counts)
 
 
+def test_train_step_at_a_large_state_space_uses_batched_gemms():
+    """X = 128: the trainer's shared pots make every factor->variable update of the shard one DGEMM; same step as the
+    oracle's per-instance loop."""
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.train import UserGraphTrainer
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = C.user_spec(8, [1, 3, 6], 128, 40, seed=2)
+    topo = GraphTopology.from_spec(spec)
+    inputs = C.make_inputs(spec, 78)
+    B, roots, lr, reg = 5, [3, 1, 6], 0.1, 0.2 / 5
+    labels, obs = _instances(spec, topo, B, 6)
+    tr = UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],
+                          inputs['theta_en_en'], inputs['theta_en_de'], roots=roots)
+    mean_lp, t_ee, t_ed = tr.step(lr, reg)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 6 and tr.batch.program(roots).status() == 0
+    s_ee, s_ed, lp = _oracle_step(spec, inputs, labels, obs, roots, lr, reg)
+    np.testing.assert_allclose(t_ee.cpu().numpy(), (inputs['theta_en_en'] + s_ee).reshape(-1), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(t_ed.cpu().numpy(), (inputs['theta_en_de'] + s_ed).reshape(-1), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(mean_lp, lp / B, rtol=1e-10)
+
+
 def _pots(inputs, th_ee, th_ed, X=64):
     d = dict(inputs)
     d['theta_en_en'], d['theta_en_de'] = th_ee, th_ed

@@ -301,6 +301,8 @@ typedef struct mlbp_gradient_args {
   double* grad_en_en;           /* out [B][F_ee]                                                    */
   double* grad_en_de;           /* out [B][F_ed]                                                    */
   int32_t flags;                /* MLBP_GRADIENT_* bits                                              */
+  const int32_t* pair_tab_host; /* HOST int32 [P] or NULL: with MLBP_GRADIENT_SHARED_PAIR_TABLES and X >= 128 the
+                                   pairwise factors become four DGEMMs each over the whole batch         */
   const double* unary_expect;   /* optional [n_unary_tables][8] from mlbp_unary_expectations_f64: with
                                    MLBP_GRADIENT_SHARED_PAIR_TABLES the unary factors then cost one
                                    gather per factor instead of a reduction over the states           */

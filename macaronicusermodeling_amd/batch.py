@@ -350,6 +350,8 @@ class FactorGraphBatch:
         a.grad_en_en, a.grad_en_de = out_ee.data_ptr(), out_ed.data_ptr()
         if getattr(self, 'pair_tables_shared', False) and getattr(self, 'use_shared_gradient', True):
             a.flags |= _ffi.GRADIENT_SHARED_PAIR_TABLES
+            if getattr(self, '_pair_row_host', None) is not None:
+                a.pair_tab_host = self._pair_row_host.ctypes.data
             self._derive_unary_rows()
             if getattr(self, '_row_kind', None) is not None and self._row_kind is not False and F_ee == 3 and F_ed == 6:
                 _ffi.check(_ffi.lib.mlbp_unary_expectations_f64(

@@ -146,7 +146,87 @@ __global__ void check_shared_claim_kernel(const int32_t* pair_tab, int B, int P,
   if (pair_tab[i] != want || (unsigned)want >= (unsigned)n_pair_tables) atomicExch(status, 2);
 }
 
+// ---- pairwise part of the gradient (LBP.py:528-619, 301-320) as DGEMMs ----
+// W = T (.) phi_k (k = 0..2) or T (k = 3), row-major like T
+__global__ void weight_table_kernel(const double* T, const double* phi_plane, int n, double* W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) W[i] = phi_plane ? T[i] * phi_plane[i] : T[i];
+}
+// S[k][b] = sum_i c[b][i] * Y[i][b]   (Y column-major X x B: Y[b * X + i])
+__global__ __launch_bounds__(WG) void row_dot_kernel(const double* msgs, int n_msgs, int X, int c_slot, const double* Y, double* S) {
+  __shared__ double scratch[4];
+  const double* c = msgs + ((size_t)blockIdx.x * n_msgs + c_slot) * X;
+  const double* y = Y + (size_t)blockIdx.x * X;
+  double part = 0.0;
+  for (int j = threadIdx.x; j < X; j += WG) part += c[j] * y[j];
+  const double tot = block_sum(part, scratch);
+  if (threadIdx.x == 0) S[blockIdx.x] = tot;
+}
+// grad_en_en[b][k] += phi[l0][l1][k] - S_k[b] / Z[b]   (au.normalize: zero-sum -> expectation 0)
+__global__ void pair_gradient_combine_kernel(const double* S /*[4][B]*/, int B, int X, const int32_t* pair_label, int P, int p,
+                                             const double* phi, double* grad_en_en, int32_t* status) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int l0 = pair_label[((size_t)b * P + p) * 2], l1 = pair_label[((size_t)b * P + p) * 2 + 1];
+  if ((unsigned)l0 >= (unsigned)X || (unsigned)l1 >= (unsigned)X) { atomicExch(status, 1); return; }
+  const double Z = S[3 * (size_t)B + b];
+  for (int k = 0; k < 3; ++k)
+    grad_en_en[(size_t)b * 3 + k] += phi[((size_t)l0 * X + l1) * 3 + k] - (Z > 0.0 ? S[k * (size_t)B + b] / Z : 0.0);
+}
+
 }  // namespace
+
+int gemm_path_ready() { return rocblas_ready(); }
+
+int launch_gemm_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void* stream) {
+  if (int e = rocblas_ready()) return e;
+  hipStream_t st = (hipStream_t)stream;
+  const int B = a->B, X = a->X, ld = a->n_msgs * X;
+  // scratch: W [X][X], Y [B][X] (column-major X x B), S [4][B]; one device-wide buffer, grown on demand (launches on
+  // different streams must not overlap; a stream-capturing caller runs one eager step first)
+  static double* scratch = nullptr;
+  static size_t cap = 0;
+  std::lock_guard<std::mutex> lock(g_rb_mutex);
+  const size_t need = (size_t)X * X + (size_t)B * X + 4 * (size_t)B;
+  if (need > cap) {
+    if (scratch) (void)hipFree(scratch);
+    scratch = nullptr; cap = 0;
+    if (hipMalloc(&scratch, need * sizeof(double)) != hipSuccess) return fail(MLBP_EHIP, "gradient GEMM scratch allocation failed");
+    cap = need;
+  }
+  double* W = scratch; double* Y = W + (size_t)X * X; double* S = Y + (size_t)B * X;
+  if (g_rb.set_stream(g_rb.handle, st) != 0) return fail(MLBP_EHIP, "rocblas_set_stream failed");
+  const double one = 1.0, zero = 0.0;
+  // slots come from DEVICE arrays in the ABI (pair_c_slot / pair_r_slot / pair_phi): fetch the few ints once
+  int32_t h_c[16], h_r[16], h_phi[16];
+  if (hipMemcpyAsync(h_c, a->pair_c_slot, sizeof(int32_t) * a->P, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(h_r, a->pair_r_slot, sizeof(int32_t) * a->P, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(h_phi, a->pair_phi, sizeof(int32_t) * a->P, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    return fail(MLBP_EHIP, "gradient GEMM path: reading the slot tables failed");
+  for (int p = 0; p < a->P; ++p) {
+    if ((unsigned)h_c[p] >= (unsigned)a->n_msgs || (unsigned)h_r[p] >= (unsigned)a->n_msgs ||
+        (unsigned)a->pair_tab_host[p] >= (unsigned)a->n_pair_tables)
+      return fail(MLBP_EINVAL, "gradient GEMM path: slot or table index of factor %d out of range", p);
+    const double* T = a->pair_tables + (size_t)a->pair_tab_host[p] * X * X;
+    const double* planes = h_phi[p] ? a->phi_en_en_w1_p : a->phi_en_en_p;
+    for (int k = 0; k < 4; ++k) {
+      const double* A = T;
+      if (k < 3) {
+        hipLaunchKernelGGL(weight_table_kernel, dim3((X * X + 255) / 256), dim3(256), 0, st, T, planes + (size_t)k * X * X, X * X, W);
+        A = W;
+      }
+      // Y[:, b] = A . r_b  (A row-major = A^T column-major -> op transpose), r = msgs[:, r_slot, :]
+      const int rc = g_rb.dgemm(g_rb.handle, RB_OP_TRANSPOSE, RB_OP_NONE, X, B, X, &one, A, X, a->msgs + (size_t)h_r[p] * X, ld, &zero, Y, X);
+      if (rc != 0) return fail(MLBP_EHIP, "rocblas_dgemm failed with status %d", rc);
+      hipLaunchKernelGGL(row_dot_kernel, dim3(B), dim3(WG), 0, st, a->msgs, a->n_msgs, X, h_c[p], Y, S + (size_t)k * B);
+    }
+    hipLaunchKernelGGL(pair_gradient_combine_kernel, dim3((B + 255) / 256), dim3(256), 0, st, S, B, X, a->pair_label, a->P, p,
+                       h_phi[p] ? a->phi_en_en_w1 : a->phi_en_en, a->grad_en_en, status);
+  }
+  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "gradient GEMM path: a launch failed");
+  return MLBP_OK;
+}
 
 int launch_gemm_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream) {
   if (!a->pair_tab_host) return fail(MLBP_EINVAL, "shared-table GEMM path: pair_tab_host (host int32 [P]) is required");

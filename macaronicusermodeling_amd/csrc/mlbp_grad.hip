@@ -147,7 +147,7 @@ __global__ __launch_bounds__(WG) void gradient_kernel(GradDev d) {
   double gee[FEE];
 #pragma unroll
   for (int k = 0; k < FEE; ++k) gee[k] = 0.0;
-  for (int p = 0; p < a.P; ++p) pair_gradient<FEE>(d, g, p, scratch, gee);
+  for (int p = 0; p < a.P && !d.skip_pairs; ++p) pair_gradient<FEE>(d, g, p, scratch, gee);
   // unary factors: one wave each
   double uee[FEE], ued[FED];
 #pragma unroll
@@ -511,10 +511,15 @@ int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream) {
     if (shared) return mlbp::launch_shared_pair_gradient(a, d.status, stream);
     return MLBP_OK;
   }
+  // shared pairwise tables at a large state space: pairwise part as DGEMMs over the whole batch (mlbp_gemm.hip)
+  const bool gemm_pairs = (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->pair_tab_host && a->X >= 128 && a->F_ee == 3 &&
+                          a->P > 0 && a->P <= 16 && a->phi_en_en_p && a->phi_en_en_w1_p && mlbp::gemm_path_ready() == MLBP_OK;
+  d.skip_pairs = gemm_pairs ? 1 : 0;
   if (a->F_ee == 3) hipLaunchKernelGGL((gradient_kernel<3, 6>), dim3(a->B), dim3(WG), 0, st, d);
   else if (a->F_ee == 2) hipLaunchKernelGGL((gradient_kernel<2, 2>), dim3(a->B), dim3(WG), 0, st, d);
   else hipLaunchKernelGGL((gradient_kernel<1, 1>), dim3(a->B), dim3(WG), 0, st, d);
   HIP_TRY(hipGetLastError());
+  if (gemm_pairs) return mlbp::launch_gemm_pair_gradient(a, d.status, stream);
   return MLBP_OK;
 }
 

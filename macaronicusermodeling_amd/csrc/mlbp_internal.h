@@ -47,6 +47,9 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
 int launch_shared_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void* stream);
 // Shared tables at X >= 128: the sweeps op by op over the whole batch, contractions as DGEMMs (mlbp_gemm.hip).
 int launch_gemm_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
+int gemm_path_ready();      // MLBP_OK when rocBLAS could be bound
+// Pairwise part of the gradient for shared tables at X >= 128 (F_ee = 3), ADDED to a->grad_en_en.
+int launch_gemm_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void* stream);
 }  // namespace mlbp
 
 // Device-resident, validated op list (see mlbp_program_create).

@@ -275,6 +275,16 @@ def test_train_step_at_a_large_state_space_uses_batched_gemms():
     np.testing.assert_allclose(t_ee.cpu().numpy(), (inputs['theta_en_en'] + s_ee).reshape(-1), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(t_ed.cpu().numpy(), (inputs['theta_en_de'] + s_ed).reshape(-1), rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(mean_lp, lp / B, rtol=1e-10)
+    # the pairwise part of that gradient ran as DGEMMs ((T (.) phi_k) . R, then a dot with c per graph): same numbers
+    # from the per-graph kernel on the same messages
+    fb = tr.batch
+    fb.sweep(roots, init=True)
+    ee1, ed1 = fb.gradient()
+    fb.use_shared_gradient = False
+    ee2, ed2 = fb.gradient()
+    np.testing.assert_allclose(ee1.cpu().numpy(), ee2.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(ed1.cpu().numpy(), ed2.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    assert _ffi.lib.mlbp_gradient_status() == 0
 
 
 def _pots(inputs, th_ee, th_ed, X=64):

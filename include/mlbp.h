@@ -346,6 +346,11 @@ int mlbp_patch_gradient_f64(const double* priv_tables, const int32_t* item_off, 
 /* out[j] = sum over rows of in[rows][cols], fixed summation order (bitwise reproducible): the
  * device half of batch_sgd_accumulate (train_mp.py:405-424). */
 int mlbp_sum_rows_f64(const double* in, int64_t rows, int32_t cols, double* out, void* stream);
+/* The same over up to three arrays [rows][cols_i] read side by side (out has cols0 + cols1 + cols2 entries, plus one
+ * more holding `rows` when append_count is set; in1 / in2 may be NULL with cols 0): the trainer's fused statistics
+ * [sum grad_en_en | sum grad_en_de | sum log-posterior | count] without assembling a matrix. */
+int mlbp_sum_rows_cat_f64(const double* in0, int32_t cols0, const double* in1, int32_t cols1, const double* in2,
+                          int32_t cols2, int64_t rows, int32_t append_count, double* out, void* stream);
 
 /* out[s][j] = sum of in[b][j] over the rows with seg_id[b] == s (DEVICE int32 [rows], values in [0, n_seg)), fixed
  * order: the per-domain sums of batch_sgd_accumulate under --user_adapt / --experience_adapt (train_mp.py:413-415). */

@@ -360,22 +360,29 @@ constexpr int SUM_PARTS = 64;
 __device__ double g_sum_partials[SUM_PARTS * 64];
 __device__ unsigned g_sum_done = 0;
 
-__global__ __launch_bounds__(WG) void sum_rows_kernel(const double* in, int64_t rows, int cols, double* out) {
+struct SumCat { const double* in[3]; int cols[3]; };       // up to three [rows][cols_i] arrays read as one [rows][sum cols] matrix
+
+__global__ __launch_bounds__(WG) void sum_rows_kernel(SumCat cat, int64_t rows, int append_count, double* out) {
   __shared__ double part[WG];
   __shared__ bool last;
   const int64_t per = (rows + SUM_PARTS - 1) / SUM_PARTS;
   const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
-  for (int j = 0; j < cols; ++j) {
-    double acc = 0.0;
-    for (int64_t b = r0 + threadIdx.x; b < r1; b += WG) acc += in[b * cols + j];
-    part[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = WG / 2; s > 0; s >>= 1) {
-      if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+  int jout = 0;
+  for (int a = 0; a < 3; ++a) {
+    const double* in = cat.in[a];
+    const int cols = cat.cols[a];
+    for (int j = 0; j < cols; ++j, ++jout) {
+      double acc = 0.0;
+      for (int64_t b = r0 + threadIdx.x; b < r1; b += WG) acc += in[b * cols + j];
+      part[threadIdx.x] = acc;
+      __syncthreads();
+      for (int s = WG / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) g_sum_partials[blockIdx.x * 64 + jout] = part[0];
       __syncthreads();
     }
-    if (threadIdx.x == 0) g_sum_partials[blockIdx.x * 64 + j] = part[0];
-    __syncthreads();
   }
   if (threadIdx.x == 0) {
     __threadfence();
@@ -384,11 +391,12 @@ __global__ __launch_bounds__(WG) void sum_rows_kernel(const double* in, int64_t 
   __syncthreads();
   if (!last) return;
   __threadfence();
-  if (threadIdx.x < cols) {
+  if (threadIdx.x < jout) {
     double acc = 0.0;
     for (int q = 0; q < SUM_PARTS; ++q) acc += __builtin_nontemporal_load(&g_sum_partials[q * 64 + threadIdx.x]);
     out[threadIdx.x] = acc;
   }
+  if (threadIdx.x == 0 && append_count) out[jout] = (double)rows;
   if (threadIdx.x == 0) g_sum_done = 0;                       // ready for the next (stream-ordered) launch
 }
 
@@ -554,14 +562,23 @@ int mlbp_pair_beliefs_f64(const double* msgs, int32_t B, int32_t n_msgs, int32_t
   return MLBP_OK;
 }
 
-int mlbp_sum_rows_f64(const double* in, int64_t rows, int32_t cols, double* out, void* stream) {
-  if (!in || !out || rows <= 0 || cols <= 0) return fail(MLBP_EINVAL, "mlbp_sum_rows_f64: bad arguments");
+int mlbp_sum_rows_cat_f64(const double* in0, int32_t cols0, const double* in1, int32_t cols1, const double* in2, int32_t cols2,
+                          int64_t rows, int32_t append_count, double* out, void* stream) {
+  if (!in0 || !out || rows <= 0 || cols0 <= 0 || cols1 < 0 || cols2 < 0 || (cols1 > 0 && !in1) || (cols2 > 0 && !in2))
+    return fail(MLBP_EINVAL, "mlbp_sum_rows_cat_f64: bad arguments");
   if (int e = need_device()) return e;
-  if (cols > 64) return fail(MLBP_EUNSUPPORTED, "mlbp_sum_rows_f64: at most 64 columns (got %d)", cols);
+  if ((int64_t)cols0 + cols1 + cols2 > 64)
+    return fail(MLBP_EUNSUPPORTED, "mlbp_sum_rows: at most 64 columns (got %d)", cols0 + cols1 + cols2);
+  SumCat cat = {{in0, in1, in2}, {cols0, cols1, cols2}};
   // the partials live in one device-wide scratch array: launches on DIFFERENT streams must not overlap
-  hipLaunchKernelGGL(sum_rows_kernel, dim3(SUM_PARTS), dim3(WG), 0, (hipStream_t)stream, in, rows, cols, out);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(SUM_PARTS), dim3(WG), 0, (hipStream_t)stream, cat, rows, append_count ? 1 : 0, out);
   HIP_TRY(hipGetLastError());
   return MLBP_OK;
+}
+
+int mlbp_sum_rows_f64(const double* in, int64_t rows, int32_t cols, double* out, void* stream) {
+  if (!in || !out || rows <= 0 || cols <= 0) return fail(MLBP_EINVAL, "mlbp_sum_rows_f64: bad arguments");
+  return mlbp_sum_rows_cat_f64(in, cols, nullptr, 0, nullptr, 0, rows, 0, out, stream);
 }
 
 int mlbp_segment_sum_rows_f64(const double* in, int64_t rows, int32_t cols, const int32_t* seg_id, int32_t n_seg, double* out,

@@ -1488,9 +1488,43 @@ void build_fused_program(const int32_t* ops_in, const int32_t* srcs, const int32
         out.pairseq.push_back(a);
       }
     }
+    out.fsweeps.push_back(f0);
+    out.fsweeps.push_back((int)out.fops.size() / 8 - f0);
+  }
+  // 3b. drop lone variable->factor updates whose result is overwritten before anything reads it (the last two of a
+  //     sweep when the next sweep's root differs: the new schedule recomputes those messages first).  Backward
+  //     liveness over the whole call; every slot is live at the end (the messages are an output).
+  if (!getenv("MLBP_NO_SINK")) {
+    const int n = (int)out.fops.size() / 8;
+    std::vector<char> live(n_msgs + 1 + (int)cprods.size(), 1), dead(n, 0);
+    for (int i = n - 1; i >= 0; --i) {
+      const int32_t* w = &out.fops[8 * (size_t)i];
+      const int kd = w[0] & 0xFF;
+      if (kd == FOP_VAR && !live[w[3]]) { dead[i] = 1; continue; }
+      if (kd == FOP_UNARY) { live[w[3]] = 0; continue; }
+      if (kd == FOP_PAIR_TM || kd == FOP_PAIR_MT) { live[w[3]] = 0; live[w[2]] = 1; continue; }
+      live[w[3]] = 0;
+      if (kd != FOP_VAR) live[w[5]] = 0;
+      for (int q = 0; q < w[2]; ++q) live[out.psrcs[w[1] + q]] = 1;
+      for (int q = 0; q < w[7]; ++q) live[out.psrcs[w[6] + q]] = 1;
+    }
+    std::vector<int32_t> kept;
+    std::vector<int32_t> fs;
+    for (size_t sw = 0; sw + 1 < out.fsweeps.size(); sw += 2) {
+      const int f0 = (int)kept.size() / 8;
+      for (int i = out.fsweeps[sw]; i < out.fsweeps[sw] + out.fsweeps[sw + 1]; ++i)
+        if (!dead[i]) kept.insert(kept.end(), out.fops.begin() + 8 * (size_t)i, out.fops.begin() + 8 * (size_t)i + 8);
+      fs.push_back(f0); fs.push_back((int)kept.size() / 8 - f0);
+    }
+    out.fops.swap(kept);
+    out.fsweeps.swap(fs);
+  }
+  // 3c. bundles
+  for (size_t sw = 0; sw + 1 < out.fsweeps.size(); sw += 2) {
+    const int f0 = out.fsweeps[sw];
     // bundle adjacent pairwise updates that touch disjoint message slots
     {
-      const int f1 = (int)out.fops.size() / 8;
+      const int f1 = f0 + out.fsweeps[sw + 1];
       auto is_pair = [&](int i) { int kd = out.fops[8 * i] & 0xFF; return kd == FOP_PAIR_TM || kd == FOP_PAIR_MT || kd == FOP_VAR_PAIR_TM || kd == FOP_VAR_PAIR_MT; };
       auto sets = [&](int i, std::vector<int>& rd, std::vector<int>& wr) {
         const int32_t* w = &out.fops[8 * i];
@@ -1513,8 +1547,6 @@ void build_fused_program(const int32_t* ops_in, const int32_t* srcs, const int32
         ++i;                                       // bundles hold two updates
       }
     }
-    out.fsweeps.push_back(f0);
-    out.fsweeps.push_back((int)out.fops.size() / 8 - f0);
   }
   out.pairseq.push_back(-1);
   {

@@ -123,12 +123,16 @@ def test_bad_topologies_are_rejected():
 def test_program_rewrites_plan():
     """Host-side program rewrites (no GPU): after sinking variable->factor updates next to their consumers every
     update inside a K3 sweep fuses (what is left lone / standalone are the sweep's last two variable updates and
-    its first two pairwise updates, which straddle the sweep boundary); the shared-table form of the same call
+    its first two pairwise updates, which straddle the sweep boundary); with a different root per sweep the last two
+    variable updates of sweeps 1 and 2 are overwritten before anything reads them and are dropped (24 -> 20 updates),
+    with the same root every sweep they feed the next sweep and stay; the shared-table form of the same call
     keeps 9 message tiles resident (3 constant products + 6 factor->variable messages) = 78 336 bytes for 16
     graphs, i.e. two workgroups per CU; K4 needs 21 tiles and so falls back at launch."""
     from macaronicusermodeling_amd.topology import GraphTopology
     k3 = GraphTopology.from_spec(C.user_spec(10, [1, 4, 7], 64, 64, seed=1)).plan([1, 4, 7])
-    assert (k3['updates'], k3['fused_updates'], k3['lone_variable_updates'], k3['bundles']) == (24, 12, 6, 9)
+    assert (k3['updates'], k3['fused_updates'], k3['lone_variable_updates'], k3['bundles']) == (20, 12, 2, 9)
+    same = GraphTopology.from_spec(C.user_spec(10, [1, 4, 7], 64, 64, seed=1)).plan([1, 1, 1])
+    assert (same['updates'], same['lone_variable_updates']) == (24, 6)
     assert (k3['shared_ok'], k3['shared_tiles'], k3['shared_tile_bytes']) == (1, 9, 78336)
     assert 2 * k3['shared_tile_bytes'] < 160 * 1024
     k2 = GraphTopology.from_spec(C.user_spec(6, [0, 1], 64, 64, seed=3)).plan([0, 1, 0])

@@ -326,7 +326,9 @@ struct FusedDev {
   const int32_t* image;    // fused op headers, source lists, hoist list, constant-product lists (one block)
   const int32_t* fsweeps;  // [n_sweeps][2]
   int32_t n_fops, n_psrcs, n_hoist, n_cprod, n_cpw, n_ext, init;
+  int32_t n_graphs;        // B
 };
+constexpr int FIXUP_GRAPHS_PER_WG = 64;
 
 __device__ __forceinline__ void wg_barrier() {
   // LDS traffic only: wait for this wave's LDS ops, then the workgroup barrier.  Outstanding
@@ -535,7 +537,7 @@ __device__ __forceinline__ void gradient_epilogue_x64(const SweepDev& d, const G
 //   prog  int32             fused op headers [n_fops][8], source lists, hoist / constant-product
 //                           lists, the graph's table indices
 template <bool NORM, int NT, bool GRAD>
-__global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x64_fused_kernel(SweepDev d, FusedDev f, GradFusedDev gf) {
+__device__ __forceinline__ void sweep_x64_fused_body(const SweepDev& d, const FusedDev& f, const GradFusedDev& gf, const int g) {
   extern __shared__ double lds[];
   double* msg = lds;
   double* gin = lds + (size_t)(d.n_msgs + f.n_ext) * 64;
@@ -552,8 +554,6 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
   STAMP_DECL
   ABLATE_DECL
   STAMP_START
-  const int g = blockIdx.x;
-  if (f.only && !f.only[g]) return;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int rg = t >> 5, cp = t & 31;
@@ -822,8 +822,27 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   return max(max(a, b), max(c, e));
 }
 
-// High word of a double as an unsigned key: for finite non-negative doubles the key orders like the
-// value; a set sign bit or an all-ones exponent (negative, -0, inf, NaN) gives a key >= 0x7FF00000.
+
+// One workgroup per graph -- or, as the fix-up pass behind a fast kernel (f.only), one workgroup per 64 graphs that
+// walks their flags and redoes the (normally zero) flagged ones: 128 workgroups instead of 8192 that exit at once.
+template <bool NORM, int NT, bool GRAD>
+__global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x64_fused_kernel(SweepDev d, FusedDev f, GradFusedDev gf) {
+  // fix-up mode: all 64 flags in one load (lane i of every wave reads flag i; the ballot is the same in the four waves)
+  int base = blockIdx.x;
+  unsigned long long todo = 1;
+  if (f.only) {
+    base = blockIdx.x * FIXUP_GRAPHS_PER_WG;
+    const int mine = base + (threadIdx.x & 63);
+    todo = __ballot(mine < f.n_graphs && f.only[mine] != 0);
+  }
+  while (todo) {
+    const int i = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    sweep_x64_fused_body<NORM, NT, GRAD>(d, f, gf, base + i);
+    if (todo) __syncthreads();
+  }
+}
+
 __device__ __forceinline__ unsigned mag_key(double x) { return (unsigned)__double2hiint(x); }
 constexpr unsigned KEY_BAD = 0x7FF00000u;   // and above: negative or non-finite
 constexpr unsigned KEY_MIN = 0x00100000u;   // below: zero or subnormal maximum
@@ -1870,6 +1889,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       f.n_fops = prog->n_fops; f.n_psrcs = prog->n_psrcs; f.n_hoist = prog->n_hoist;
       f.n_cprod = prog->n_cprod; f.n_cpw = prog->n_cpw; f.n_ext = n_ext;
       f.init = a->init_messages;
+      f.n_graphs = a->B;
       d.pairseq = prog->d_fpairseq;
       if (want_sf && nt > 3) nt = (prog->P <= 3) ? prog->P : 0;   // exact kernel keeps its own rule
       void (*k)(SweepDev, FusedDev, GradFusedDev) = nullptr;
@@ -1885,7 +1905,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
 #undef MLBP_PICK
 #undef MLBP_PICKG
       if (int e = ensure_dynamic_lds((const void*)k, lds)) return e;
-      hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, st, d, f, gf);
+      hipLaunchKernelGGL(k, dim3(f.only ? (a->B + FIXUP_GRAPHS_PER_WG - 1) / FIXUP_GRAPHS_PER_WG : a->B), dim3(WG), lds, st, d, f, gf);
       HIP_TRY(hipGetLastError());
       if (ga && !grad_fused)
         if (int e = mlbp_gradient_f64(ga, stream)) return e;

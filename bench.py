@@ -230,13 +230,14 @@ def main():
         fb.sweep(roots, init=True, marginals=marg, keep_messages=not a.no_writeback)   # initialize + marginal read-out fused into the launch
         if i is not None:
             ev[i][1].record()
-        _ffi.check(_ffi.lib.mlbp_log_posterior_f64(marg.data_ptr(), labels_d.data_ptr(), B, topo.n_vars, X,
-                                                   lp.data_ptr(), _stream_ptr(dev)))
         k = step_no[0] & 1
         step_no[0] += 1
         if pending[k] is not None:
             pending[k].wait()               # the all-reduce issued two steps ago (long finished)
-        stats[k][0] = lp.sum()
+        # get_posterior_probs of every graph and their batch total (train_mp.py:400, 405-411) in one launch,
+        # written straight into the statistics buffer this step reduces
+        _ffi.check(_ffi.lib.mlbp_log_posterior_sum_f64(marg.data_ptr(), labels_d.data_ptr(), B, topo.n_vars, X,
+                                                       lp.data_ptr(), stats[k].data_ptr(), _stream_ptr(dev)))
         if world > 1:                       # the outer-loop reduction of train_mp.py:405-424: one per step
             pending[k] = dist.all_reduce(stats[k], async_op=True)
 

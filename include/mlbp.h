@@ -252,6 +252,10 @@ int mlbp_marginals_f64(const double* msgs, int32_t B, int32_t n_msgs, int32_t X,
  * -inf replaced by -99.99.  labels is a DEVICE int32 [B][n_vars] array. */
 int mlbp_log_posterior_f64(const double* marginals, const int32_t* labels, int32_t B, int32_t n_vars,
                            int32_t X, double* out, void* stream);
+/* The same, and *sum_out = sum_b out[b] in a fixed order (device pointer; NULL = no sum): the batch total of
+ * train_mp.py:405-411 without a second reduction launch. */
+int mlbp_log_posterior_sum_f64(const double* marginals, const int32_t* labels, int32_t B, int32_t n_vars,
+                               int32_t X, double* out, double* sum_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * DEVICE: factor beliefs and the log-linear gradient, batched over graphs

@@ -1370,18 +1370,51 @@ __global__ __launch_bounds__(WG) void marginals_kernel(const double* msgs, int n
   }
 }
 
-__global__ void log_posterior_kernel(const double* marg, const int32_t* labels, int B, int n_vars, int X,
-                                     double* out, int32_t* status) {
-  int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= B) return;
+// FactorGraph.get_posterior_probs for every graph, and (when sum_out is given) their sum over the batch in a fixed
+// order: per-block tree over 128 values, then the last block to finish adds the block partials in block order.
+constexpr int LP_MAX_BLOCKS = 4096;
+__device__ double g_lp_partials[LP_MAX_BLOCKS];
+__device__ unsigned g_lp_done = 0;
+
+__global__ __launch_bounds__(128) void log_posterior_kernel(const double* marg, const int32_t* labels, int B, int n_vars, int X,
+                                                            double* out, double* sum_out, int32_t* status) {
+  __shared__ double part[128];
+  __shared__ bool last;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
   double total = 0.0;
-  for (int v = 0; v < n_vars; ++v) {
-    int lab = labels[(size_t)g * n_vars + v];
-    if ((unsigned)lab >= (unsigned)X) { atomicExch(status, 1); continue; }
-    double lp = log(marg[((size_t)g * n_vars + v) * X + lab]);
-    total += (lp == -__builtin_huge_val()) ? -99.99 : lp;  // LBP.py:254-256
+  if (g < B) {
+    for (int v = 0; v < n_vars; ++v) {
+      int lab = labels[(size_t)g * n_vars + v];
+      if ((unsigned)lab >= (unsigned)X) { atomicExch(status, 1); continue; }
+      double lp = log(marg[((size_t)g * n_vars + v) * X + lab]);
+      total += (lp == -__builtin_huge_val()) ? -99.99 : lp;  // LBP.py:254-256
+    }
+    out[g] = total;
   }
-  out[g] = total;
+  if (!sum_out) return;
+  part[threadIdx.x] = total;
+  __syncthreads();
+  for (int s = 64; s > 0; s >>= 1) {
+    if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    g_lp_partials[blockIdx.x] = part[0];
+    __threadfence();
+    last = atomicAdd(&g_lp_done, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double acc = 0.0;                                  // 128 threads, block-strided, then a tree: fixed order
+  for (unsigned q = threadIdx.x; q < gridDim.x; q += 128) acc += __builtin_nontemporal_load(&g_lp_partials[q]);
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 64; s > 0; s >>= 1) {
+    if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { *sum_out = part[0]; g_lp_done = 0; }
 }
 
 // Fused program form (see sweep_x64_fused_kernel).  Input: the validated 4-word op list.
@@ -2101,17 +2134,26 @@ int mlbp_marginals_f64(const double* msgs, int32_t B, int32_t n_msgs, int32_t X,
   return MLBP_OK;
 }
 
-int mlbp_log_posterior_f64(const double* marginals, const int32_t* labels, int32_t B, int32_t n_vars,
-                           int32_t X, double* out, void* stream) {
+int mlbp_log_posterior_sum_f64(const double* marginals, const int32_t* labels, int32_t B, int32_t n_vars,
+                               int32_t X, double* out, double* sum_out, void* stream) {
   if (!marginals || !labels || !out || B <= 0 || n_vars <= 0 || X <= 0)
     return fail(MLBP_EINVAL, "mlbp_log_posterior_f64: bad arguments");
   if (int e = check_device()) return e;
   int32_t* status = nullptr;
   if (int e = global_status(&status)) return e;
-  hipLaunchKernelGGL(log_posterior_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, marginals,
-                     labels, B, n_vars, X, out, status);
+  const int blocks = (B + 127) / 128;
+  if (sum_out && blocks > LP_MAX_BLOCKS)
+    return fail(MLBP_EUNSUPPORTED, "mlbp_log_posterior_sum_f64: at most %d graphs with sum_out", LP_MAX_BLOCKS * 128);
+  // the block partials live in one device-wide scratch array: launches on DIFFERENT streams must not overlap
+  hipLaunchKernelGGL(log_posterior_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, marginals, labels, B, n_vars, X, out,
+                     sum_out, status);
   HIP_TRY(hipGetLastError());
   return MLBP_OK;
+}
+
+int mlbp_log_posterior_f64(const double* marginals, const int32_t* labels, int32_t B, int32_t n_vars,
+                           int32_t X, double* out, void* stream) {
+  return mlbp_log_posterior_sum_f64(marginals, labels, B, n_vars, X, out, nullptr, stream);
 }
 
 }  // extern "C"

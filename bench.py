@@ -129,6 +129,37 @@ def cpu_baseline(workload, batch, budget_s=12.0):
 
 
 # ---------------------------------------------------------------------------------------------------
+def parity_sample(spec, topo, roots, fb, marg, n_graphs=4):
+    """max relative marginal error of the GPU run against the CPU restatement in the same run, on the
+    first few graphs of the batch (their tables are copied back; the oracle is the checker here, as in the
+    cpu_baseline leg)."""
+    import numpy as np
+    from oracle import lbp_oracle as O
+    X = spec['X']
+    ex = dict(name=spec.get('name', 'bench'), style='explicit', X=X, var_ids=list(spec['var_ids']), labels=list(spec['labels']),
+              factors=[dict(id=f['id'], vars=list(f['vars']), dims=list(f['dims']), table=f['id']) for f in spec['factors']])
+    n_tab = 1 + max(f['id'] for f in spec['factors'])
+    ptab = fb.pair_tab[:n_graphs].cpu().numpy() if topo.P else None
+    utab = fb.unary_tab[:n_graphs].cpu().numpy() if topo.U else None
+    worst = 0.0
+    for b in range(min(n_graphs, fb.B)):
+        tables = [None] * n_tab
+        for p, j in enumerate(topo.pair_factors):
+            tables[topo.factor_ids[j]] = fb.pair_tables[int(ptab[b, p])].double().cpu().numpy()
+        for u, j in enumerate(topo.unary_factors):
+            tables[topo.factor_ids[j]] = fb.unary_tables[int(utab[b, u])].cpu().numpy().reshape(X, 1)
+        g = O.Graph(ex)
+        msgs = O.init_messages(g)
+        for r in roots:
+            O.sweep(g, dict(tables=tables), msgs, r)
+        got = marg[b].cpu().numpy()
+        for k, v in enumerate(topo.var_ids):
+            want = O.marginal(g, msgs, v).reshape(-1)
+            worst = max(worst, float(np.max(np.abs(got[k] - want) / np.maximum(np.abs(want), 1e-300))))
+    return {'max_rel_marginal_error': worst, 'graphs_compared': min(n_graphs, fb.B),
+            'checker': 'oracle/lbp_oracle.py on the same tables (north star: <= 1e-5)'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -320,6 +351,8 @@ def main():
                          'min_launch_ms': sweep_ms[0], 'max_launch_ms': sweep_ms[-1]},
             'cpu_baseline': cpu,
         }
+        if cpu is not None:
+            out['parity'] = parity_sample(spec, topo, roots, fb, marg)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -198,14 +198,13 @@ typedef struct mlbp_sweep_args {
  * hold, and degenerate graphs, are computed by the exact kernel instead. */
 #define MLBP_SWEEP_SHARED_PAIR_TABLES 1
 /* flags: with MLBP_SWEEP_SHARED_PAIR_TABLES and a fused read-out (marginals != NULL) the messages
- * need not be written back to msgs (ignored when a gradient is requested, which reads them). */
+ * need not be written back to msgs; when a gradient is requested too, only the variable->factor
+ * messages it reads are written back (contents of the other slots are then undefined). */
 #define MLBP_SWEEP_NO_MESSAGE_WRITEBACK 2
 /* flags: the pairwise tables are float32 (pair_tables_f32): the optional large-state mode of BASELINE
  * config 5 -- half the HBM bytes per update.  X = 256 or 512; messages, products and sums stay float64, so
  * results equal the float64 path run on the float32-rounded tables; no gradient in this mode. */
 #define MLBP_SWEEP_PAIR_TABLES_F32 4
-/* with MLBP_SWEEP_NO_MESSAGE_WRITEBACK and a gradient request only the variable->factor messages the
- * gradient reads are written back (shared-table kernel). */
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
 
@@ -219,8 +218,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
  *         (N = 0 streams);           20+N  scale-free kernel with N resident tables (N = 1..4);
  *   30    as 1 (kept distinct for A/B scripts): shared-table MFMA kernel when the launch qualifies.
  * Variants other than 1 and 30 never use the shared-table kernel.
- * All variants perform the same updates in the same order; exact variants agree bitwise, the
- * scale-free one to rounding. */
+ * All variants compute every update from the same inputs as the reference's order does (the X = 64
+ * program form may reorder independent updates and skips updates whose result is overwritten unread);
+ * exact variants agree bitwise, the scale-free and shared-table ones to rounding. */
 int mlbp_set_sweep_variant(int32_t variant);
 
 /* Diagnostic: which kernel family the calling thread's last mlbp_sweep_f64 enqueued first (the exact

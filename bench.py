@@ -46,6 +46,8 @@ def workload_spec(name):
     import cases as C
     if name in ('user_k3', 'user_k3_shared'):
         return C.user_spec(10, [1, 4, 7], 64, 64, seed=1), [1, 4, 7], 3, 1236
+    if name in ('user_k4', 'user_k4_shared'):     # four predicted words: K4 = 6 pairwise + 28 unary factors
+        return C.user_spec(10, [1, 3, 5, 8], 64, 64, seed=2), [1, 3, 5], 3, 1237
     if name == 'chain8':
         return C.chain_spec(8, 64), [0] * 10, 10, 1235
     if name == 'ring8':
@@ -165,7 +167,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared'],
+    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'user_k4', 'user_k4_shared', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared'],
                     help='user_k3_shared = the same graphs with the reference\'s table layout: all graphs share the two '
                          'en_en pots (MFMA kernel, reported against the f64 matrix peak)')
     ap.add_argument('--no-writeback', action='store_true', help='shared workload: skip the message write-back (read-out only)')

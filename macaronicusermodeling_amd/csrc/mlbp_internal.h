@@ -80,6 +80,8 @@ struct mlbp_program {
   int32_t* d_sreadout;    // per variable: base tile, count, live tiles (4-word aligned lists) or NULL
   int32_t n_sreadout;
   double* d_tfrag;        // [32][2][4096] table fragments in MFMA operand order (lazily allocated)
+  double* d_spill = nullptr;   // message tiles of the shared-table kernel that do not fit LDS (lazily allocated)
+  size_t spill_cap = 0;        // in doubles
   std::vector<int32_t> h_ops, h_sweeps;   // host copies of the validated op list (the op-by-op GEMM path walks them)
 };
 

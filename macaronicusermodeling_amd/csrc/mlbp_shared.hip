@@ -131,9 +131,18 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
   for (int c = 0; c < n_msgs; ++c)
     if (out.hoisted[c] >= 0 && (live[c] || written[c])) return;
   out.written = written;
+  // tile numbering: constant products and factor->variable messages first, stored variable->factor messages
+  // (each read once, by a later pairwise update) last -- when LDS cannot hold every tile the tail lives in
+  // global memory (launcher: n_res resident tiles)
   out.live_of_slot.assign(n_all, -1);
-  for (int s = 0; s < n_all; ++s)
-    if (live[s]) out.live_of_slot[s] = out.n_live++;
+  {
+    std::vector<char> is_vf(n_all, 0);
+    for (int i = 0; i < n_ops; ++i)
+      if ((fops[8 * i] & 0xFF) >= FOP_VAR) is_vf[fops[8 * i + 3]] = 1;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int s = 0; s < n_all; ++s)
+        if (live[s] && (is_vf[s] ? 1 : 0) == pass) out.live_of_slot[s] = out.n_live++;
+  }
   // ops + source lists
   std::vector<int32_t> ops((size_t)n_ops * 8, 0), lists;
   std::vector<int> last_var_write(n_msgs, -1);
@@ -275,6 +284,8 @@ struct SharedDev {
   int32_t B, n_sweeps, n_msgs, P, U, n_pair_tables, n_unary_tables, n_vars;
   int32_t n_ops, n_live, n_lists, n_cpw, n_back, n_fill, n_readout;
   int32_t vf_only;              // write back only the variable->factor messages (what the gradient reads)
+  int32_t n_res;                // tiles [0, n_res) live in LDS, the rest in `spill`
+  double* spill;                // [workgroups][n_live - n_res][64][16] or NULL
   const double* tfrag;          // [n_pair_tables][2][4096] A fragments of every table (only when there are <= FRAG_TABLES), or NULL
 };
 
@@ -318,11 +329,19 @@ __global__ __launch_bounds__(WG) void table_fragments_kernel(const double* pair_
   }
 }
 
-template <int NTAB>
+template <int NTAB, bool SPILL>
 __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
   extern __shared__ double lds[];
-  double* tiles = lds;                                           // [n_live][64 states][16 graphs]
-  double* tot = tiles + (size_t)d.n_live * TILE;                 // [n_live][4 waves][16 graphs] partial column sums
+  double* tiles = lds;                                           // [n_res][64 states][16 graphs]
+  double* tot = tiles + (size_t)d.n_res * TILE;                  // [n_live][4 waves][16 graphs] partial column sums
+  double* spill = SPILL ? d.spill + (size_t)blockIdx.x * (d.n_live - d.n_res) * TILE : nullptr;
+  // tile t: LDS when resident, else this workgroup's slice of the global spill area (same [state][graph] layout;
+  // __syncthreads orders the workgroup's global accesses as it does the LDS ones)
+  // (SPILL is a template parameter so that the all-resident instance keeps plain LDS instructions)
+  auto TP = [&](int tile) -> double* {
+    if (!SPILL) return tiles + (size_t)tile * TILE;
+    return tile < d.n_res ? tiles + (size_t)tile * TILE : spill + (size_t)(tile - d.n_res) * TILE;
+  };
   int32_t* img = reinterpret_cast<int32_t*>(tot + (size_t)d.n_live * 64);
   const int32_t* lists = img + d.n_ops * 8;
   const int32_t* ent = lists + d.n_lists;
@@ -367,7 +386,9 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
     if (d.marginals)
       for (int i = t; i < d.n_readout; i += WG) rd[i] = d.readout[i];
     double2* dst = reinterpret_cast<double2*>(tiles);
-    for (int i = t; i < d.n_live * (TILE / 2); i += WG) dst[i] = make_double2(uniform, uniform);
+    for (int i = t; i < d.n_res * (TILE / 2); i += WG) dst[i] = make_double2(uniform, uniform);
+    if (SPILL)
+      for (int i = t; i < (d.n_live - d.n_res) * (TILE / 2); i += WG) reinterpret_cast<double2*>(spill)[i] = make_double2(uniform, uniform);
     for (int i = t; i < d.n_live * 64; i += WG) tot[i] = 0.25;    // four partials of a total of 1
     if (t < G) gflag[t] = 0;
   }
@@ -465,7 +486,7 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
           if (flags & 2) {
             const double s = ABL(2) ? 64.0 : wave_sum(cur);
             bad |= !total_ok(s);
-            if (!ABL(1)) tiles[(size_t)__builtin_amdgcn_readlane(ent_tile, pe + j) * TILE + lane * G + gg] = cur * (1.0 / s);
+            if (!ABL(1)) TP(__builtin_amdgcn_readlane(ent_tile, pe + j))[lane * G + gg] = cur * (1.0 / s);
             if (__any(bad)) gflag[gg] = 1;
           }
         }
@@ -507,7 +528,7 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
         // variable -> factor (LBP.py:377-389): constant product (or uniform) times the other incoming messages
         const int a = __builtin_amdgcn_readfirstlane(h0.y), n = __builtin_amdgcn_readfirstlane(h0.z);
         {
-          const double* src = tiles + (size_t)lists[a] * TILE + lane;
+          const double* src = TP(__builtin_amdgcn_readfirstlane(lists[a])) + lane;
 #pragma unroll
           for (int s = 0; s < 16; ++s) b[s] = src[64 * s];
         }
@@ -519,7 +540,7 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
           // the scale of this product cancels downstream (every stored message is normalised by its own
           // total), the factor only keeps the magnitudes in range: the hardware reciprocal is enough
           const double inv = __builtin_amdgcn_rcp(total);
-          const double* src = tiles + (size_t)tl * TILE + lane;
+          const double* src = TP(tl) + lane;
 #pragma unroll
           for (int s = 0; s < 16; ++s) b[s] *= src[64 * s] * inv;
         }
@@ -534,7 +555,7 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
           if (ct >= 0) {                                         // read again later: keep it as a tile
 #pragma unroll
             for (int s = 0; s < 16; ++s)
-              if ((s >> 2) == wave) tiles[(size_t)ct * TILE + 64 * s + lane] = b[s];
+              if ((s >> 2) == wave) TP(ct)[64 * s + lane] = b[s];
             if (cq == 0) tot[ct * 64 + wave * 16 + gl] = 0.25 * tb;
           } else if (out_now && gvalid && !bad) {                // last value of this slot: straight to HBM
             double* out = d.msgs + ((size_t)gc * d.n_msgs + __builtin_amdgcn_readfirstlane(h1.z)) * 64 + cq;
@@ -555,7 +576,7 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
           const double total = (tp[0] + tp[16]) + (tp[32] + tp[48]);
           bad |= !total_ok(total);
           const double inv = __builtin_amdgcn_rcp(total);
-          const double* src = tiles + (size_t)tl * TILE + lane;
+          const double* src = TP(tl) + lane;
 #pragma unroll
           for (int s = 0; s < 16; ++s) b[s] = src[64 * s] * inv;
         } else {                                                 // a message nothing has updated yet (LBP.py:211-216)
@@ -576,7 +597,7 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
       else if (NTAB > 2 && sel == 4) { MLBP_MFMA16(aTM[NTAB > 2 ? 2 : 0]) }
       else if (NTAB > 2) { MLBP_MFMA16(aMT[NTAB > 2 ? 2 : 0]) }
       const double4_t acc = acc0 + acc1;
-      double* out = tiles + (size_t)dst * TILE + (16 * wave + cq) * G + gl;     // D: state 16w + (l>>4) + 4r
+      double* out = TP(dst) + (16 * wave + cq) * G + gl;             // D: state 16w + (l>>4) + 4r
       out[0] = acc.x; out[4 * G] = acc.y; out[8 * G] = acc.z; out[12 * G] = acc.w;
       const double part = column_sum((acc.x + acc.y) + (acc.z + acc.w));
       if (cq == 0) tot[dst * 64 + wave * 16 + gl] = part;
@@ -594,7 +615,7 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
       const int base = rd[at], n = rd[at + 1];
       double m[16];
       if (base >= 0) {
-        const double* src = tiles + (size_t)base * TILE + lane;
+        const double* src = TP(base) + lane;
 #pragma unroll
         for (int s = 0; s < 16; ++s) m[s] = src[64 * s];
       } else {
@@ -607,7 +628,7 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
         const double total = (tp[0] + tp[16]) + (tp[32] + tp[48]);
         bad |= !total_ok(total);
         const double inv = 1.0 / total;
-        const double* src = tiles + (size_t)tl * TILE + lane;
+        const double* src = TP(tl) + lane;
 #pragma unroll
         for (int s = 0; s < 16; ++s) m[s] *= src[64 * s] * inv;
       }
@@ -631,7 +652,7 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
     const double total = (tp[0] + tp[16]) + (tp[32] + tp[48]);
     bad |= !total_ok(total);
     if (d.msgs && (!d.vf_only || is_vf) && gvalid && !bad) {
-      const double* src = tiles + (size_t)tl * TILE + lane;
+      const double* src = TP(tl) + lane;
       double* out = d.msgs + ((size_t)gc * d.n_msgs + slot) * 64 + cq;
       const double inv = 1.0 / total;
 #pragma unroll
@@ -842,21 +863,21 @@ __global__ __launch_bounds__(WG) void gradient_shared_pairs_kernel(PairGradDev d
 
 std::mutex g_attr_mutex;
 
-template <int NTAB>
+template <int NTAB, bool SPILL>
 int launch(const SharedDev& d, size_t lds, hipStream_t st) {
   static size_t granted = 0;
   {
     std::lock_guard<std::mutex> lock(g_attr_mutex);
     if (lds > granted) {
-      hipError_t e = hipFuncSetAttribute((const void*)sweep_x64_shared_kernel<NTAB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute((const void*)sweep_x64_shared_kernel<NTAB, SPILL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return fail(MLBP_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       granted = lds;
       int per_cu = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sweep_x64_shared_kernel<NTAB>, WG, lds) == hipSuccess)
-        fail(MLBP_OK, "shared-table kernel <%d>: %zu bytes of LDS per workgroup, %d workgroups per CU", NTAB, lds, per_cu);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sweep_x64_shared_kernel<NTAB, SPILL>, WG, lds) == hipSuccess)
+        fail(MLBP_OK, "shared-table kernel <%d%s>: %zu bytes of LDS per workgroup, %d workgroups per CU", NTAB, SPILL ? ", spilling" : "", lds, per_cu);
     }
   }
-  hipLaunchKernelGGL(sweep_x64_shared_kernel<NTAB>, dim3((d.B + G - 1) / G), dim3(WG), lds, st, d);
+  hipLaunchKernelGGL((sweep_x64_shared_kernel<NTAB, SPILL>), dim3((d.B + G - 1) / G), dim3(WG), lds, st, d);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed: %s", hipGetErrorString(e));
   return MLBP_OK;
@@ -876,10 +897,22 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   const int n_readout = a->marginals ? prog->n_sreadout : 0;
   const int ntab = prog->P >= 2 ? 2 : 1;
   const size_t words = (size_t)sp.off_sweeps + 1 + n_readout + (size_t)G * prog->U + 2 * prog->P + 2 * ntab + 3 + G + 8;
-  const size_t lds = ((size_t)sp.n_live * (TILE + 64)) * sizeof(double) + words * sizeof(int32_t);
-  if (lds > 160 * 1024)
-    return fail(MLBP_OK, "shared-table kernel not used: %d live message tiles need %zu bytes of LDS", sp.n_live, lds);
+  // resident tiles: all of them when they fit the 160 KiB of a CU, else as many as fit (constant products and
+  // factor->variable messages come first in the numbering); the rest spill to global memory
+  const size_t fixed = (size_t)sp.n_live * 64 * sizeof(double) + words * sizeof(int32_t);
+  int n_res = sp.n_live;
+  while (n_res > 0 && fixed + (size_t)n_res * TILE * sizeof(double) > 160 * 1024) --n_res;
+  const size_t lds = fixed + (size_t)n_res * TILE * sizeof(double);
+  if (n_res < sp.n_live - 8 || n_res < 1)          // more than 8 spilled tiles: the per-graph kernels do better
+    return fail(MLBP_OK, "shared-table kernel not used: %d live message tiles, %d fit LDS", sp.n_live, n_res);
   mlbp_program* mp = const_cast<mlbp_program*>(prog);
+  const size_t spill_doubles = (size_t)((a->B + G - 1) / G) * (sp.n_live - n_res) * TILE;
+  if (spill_doubles > mp->spill_cap) {             // first use at this size (a stream-capturing caller warms up first)
+    (void)hipFree(mp->d_spill);
+    mp->d_spill = nullptr; mp->spill_cap = 0;
+    if (hipMalloc(&mp->d_spill, spill_doubles * sizeof(double)) != hipSuccess) return fail(MLBP_EHIP, "tile spill allocation failed");
+    mp->spill_cap = spill_doubles;
+  }
   if (mp->bail_cap < a->B)
     if (int e = mlbp_program_reserve(mp, a->B)) return e;
   hipStream_t st = (hipStream_t)stream;
@@ -894,6 +927,7 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables; d.n_vars = prog->n_vars;
   d.n_ops = sp.n_ops; d.n_live = sp.n_live; d.n_lists = sp.n_lists; d.n_cpw = sp.n_cpw; d.n_back = sp.n_back;
   d.n_fill = sp.n_fill; d.n_readout = n_readout;
+  d.n_res = n_res; d.spill = n_res < sp.n_live ? mp->d_spill : nullptr;
   d.tfrag = nullptr;
   if (a->n_pair_tables <= FRAG_TABLES) {
     if (!mp->d_tfrag) {                            // first use (a stream-capturing caller warms up or reserves first)
@@ -903,7 +937,8 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
     d.tfrag = mp->d_tfrag;
     hipLaunchKernelGGL(table_fragments_kernel, dim3(a->n_pair_tables * 2), dim3(WG), 0, st, a->pair_tables, mp->d_tfrag);
   }
-  int e = ntab == 2 ? launch<2>(d, lds, st) : launch<1>(d, lds, st);
+  int e = d.spill ? (ntab == 2 ? launch<2, true>(d, lds, st) : launch<1, true>(d, lds, st))
+                  : (ntab == 2 ? launch<2, false>(d, lds, st) : launch<1, false>(d, lds, st));
   if (e) return e;
   if (d.msgs && !d.vf_only && sp.n_cpw > 0) {
     const int E = sp.n_cpw / 4;

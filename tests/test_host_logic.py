@@ -127,7 +127,8 @@ def test_program_rewrites_plan():
     variable updates of sweeps 1 and 2 are overwritten before anything reads them and are dropped (24 -> 20 updates),
     with the same root every sweep they feed the next sweep and stay; the shared-table form of the same call
     keeps 9 message tiles resident (3 constant products + 6 factor->variable messages) = 78 336 bytes for 16
-    graphs, i.e. two workgroups per CU; K4 needs 21 tiles and so falls back at launch."""
+    graphs, i.e. two workgroups per CU; K4 needs 21 tiles (the launcher keeps 16 in LDS and spills the 5 stored
+    variable->factor messages to global memory)."""
     from macaronicusermodeling_amd.topology import GraphTopology
     k3 = GraphTopology.from_spec(C.user_spec(10, [1, 4, 7], 64, 64, seed=1)).plan([1, 4, 7])
     assert (k3['updates'], k3['fused_updates'], k3['lone_variable_updates'], k3['bundles']) == (20, 12, 2, 9)

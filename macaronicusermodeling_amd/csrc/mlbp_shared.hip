@@ -24,6 +24,7 @@
 // Flops per pairwise update per graph: 2 * 64 * 64 = 8192 (shared-table mode).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -897,13 +898,16 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   const int n_readout = a->marginals ? prog->n_sreadout : 0;
   const int ntab = prog->P >= 2 ? 2 : 1;
   const size_t words = (size_t)sp.off_sweeps + 1 + n_readout + (size_t)G * prog->U + 2 * prog->P + 2 * ntab + 3 + G + 8;
-  // resident tiles: all of them when they fit the 160 KiB of a CU, else as many as fit (constant products and
-  // factor->variable messages come first in the numbering); the rest spill to global memory
+  // resident tiles: as many as fit HALF the CU's LDS, so that two workgroups share a CU (constant products and
+  // factor->variable messages come first in the numbering); the rest spill to global memory.  Measured on K4 user
+  // graphs (21 tiles): 8 resident + 13 spilled with two workgroups per CU 0.216 ms, 16 resident + 5 spilled with
+  // one 0.266 ms.
   const size_t fixed = (size_t)sp.n_live * 64 * sizeof(double) + words * sizeof(int32_t);
   int n_res = sp.n_live;
-  while (n_res > 0 && fixed + (size_t)n_res * TILE * sizeof(double) > 160 * 1024) --n_res;
+  while (n_res > 0 && fixed + (size_t)n_res * TILE * sizeof(double) > 80 * 1024) --n_res;
+  if (const char* e = getenv("MLBP_SHARED_NRES")) { const int v = atoi(e); if (v >= 1 && v <= sp.n_live) n_res = v; }   // experiments
   const size_t lds = fixed + (size_t)n_res * TILE * sizeof(double);
-  if (n_res < sp.n_live - 8 || n_res < 1)          // more than 8 spilled tiles: the per-graph kernels do better
+  if (n_res < 1 || sp.n_live - n_res > 16 || lds > 160 * 1024)   // too much would spill: the per-graph kernels do better
     return fail(MLBP_OK, "shared-table kernel not used: %d live message tiles, %d fit LDS", sp.n_live, n_res);
   mlbp_program* mp = const_cast<mlbp_program*>(prog);
   const size_t spill_doubles = (size_t)((a->B + G - 1) / G) * (sp.n_live - n_res) * TILE;

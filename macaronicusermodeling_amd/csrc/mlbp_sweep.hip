@@ -1861,7 +1861,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     int nt = (prog->P <= 3) ? prog->P : 0;
     bool want_sf = norm && prog->sf_ok && prog->P >= 1 && prog->P <= 4 && variant != 3;
     if (variant >= 10 && variant < 20) { nt = (prog->P <= variant - 10) ? variant - 10 : 0; want_sf = false; }
-    if (variant >= 20) { want_sf = want_sf && prog->P <= variant - 20; nt = variant - 20; }
+    if (variant >= 20 && variant < 30) { want_sf = want_sf && prog->P <= variant - 20; nt = variant - 20; }
     else if (want_sf) nt = prog->P;
     if (prog->P == 0 || (!want_sf && nt < prog->P)) nt = 0;
     if (nt > 4) nt = 0;

@@ -263,3 +263,40 @@ def test_large_state_shared_tables_run_as_batched_gemms(X):
     fb.pair_tab = torch.from_numpy(tab).to(fb.device)
     prog = fb.sweep(roots, init=True)
     assert prog.status() == 2
+
+
+@pytest.mark.parametrize('which', ['ring8', 'chain8'])
+def test_shared_kernel_with_most_tiles_spilled(which):
+    """Rings / chains of 8 variables need 22-24 message tiles; 8-9 stay in LDS, the rest live in the global spill area
+    (two distinct tables alternate along the factors).  Against the oracle per graph."""
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.batch import FactorGraphBatch
+    from macaronicusermodeling_amd.topology import GraphTopology
+    X, B = 64, 21
+    spec = C.ring_spec(8, X) if which == 'ring8' else C.chain_spec(8, X)
+    topo = GraphTopology.from_spec(spec)
+    inputs = [C.make_inputs(spec, 51 + 1000 * b) for b in range(B)]
+    g = O.Graph(spec)
+    two = [O.factor_table(g, inputs[0], g.by_id[topo.factor_ids[j]]).reshape(X, X) for j in topo.pair_factors[:2]]
+    pick = [p % 2 for p in range(topo.P)]
+    for b in range(B):                          # every graph: the two shared tables alternating, its own unary columns
+        tabs = list(inputs[b]['tables'])
+        for p, j in enumerate(topo.pair_factors):
+            tabs[g.by_id[topo.factor_ids[j]]['table']] = two[pick[p]]
+        inputs[b] = dict(tables=tabs)
+    unary = np.stack([O.factor_table(g, inputs[b], g.by_id[topo.factor_ids[j]]).reshape(X) for b in range(B) for j in topo.unary_factors])
+    fb = FactorGraphBatch(topo, X, B)
+    fb.set_pair_tables(np.stack(two), np.tile(np.array(pick), (B, 1)))
+    fb.set_unary_tables(unary)
+    roots = [0, 5, 2]
+    marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=fb.device)
+    fb.msgs.fill_(float('nan'))
+    prog = fb.sweep(roots, init=True, marginals=marg)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == KERNEL_SHARED_MFMA, _ffi.lib.mlbp_last_error()
+    assert prog.status() == 0 and prog.exact_count(B) == 0
+    got, gm = fb.msgs.cpu().numpy(), marg.cpu().numpy()
+    for b in range(B):
+        gg, msgs, want = oracle_msgs(spec, inputs[b], roots)
+        np.testing.assert_allclose(got[b], want, rtol=RTOL, atol=1e-300)
+        for k, v in enumerate(topo.var_ids):
+            np.testing.assert_allclose(gm[b, k], O.marginal(gg, msgs, v).reshape(-1), rtol=RTOL, atol=1e-300)

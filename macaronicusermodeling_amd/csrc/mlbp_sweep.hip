@@ -921,6 +921,8 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
   int32_t* upos = umsg + d.U;                             // [U] 1 when that factor's table total was positive
 
   ABLATE_DECL
+  STAMP_DECL
+  STAMP_START
   const int g = blockIdx.x;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -970,6 +972,7 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
     return;
   }
 
+  STAMP(0)
   // ---- phase B: tables + hoisted unary messages, all loads in flight together ----
   double2 tab[NT][8];
 #pragma unroll
@@ -1022,6 +1025,7 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
     return;
   }
 
+  STAMP(1)
   // ---- main loop: identical in all four waves; one barrier per BUNDLE of pairwise updates ----
   // The host marks an update "bundled with the next" when the two touch disjoint message slots
   // (e.g. the two directions of a loop-closing factor, or the two branches below a root): both
@@ -1056,7 +1060,9 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
         sf_partials<NT>(tab, pslotA, mtA, gin_w, redA, rg, cp, lane);
         if (two != 0) sf_partials<NT>(tab, pslotB, mtB, gin_w + 64, redB, rg, cp, lane);
       }
+      STAMP(2)
       if (!ABLATED(4)) wg_barrier();
+      STAMP(3)
       // exact power-of-two rescale (largest element -> [1,2)); anything the rescale cannot represent
       // faithfully sends the graph to the exact kernel.  Same decision in every wave: r is identical.
       double rA = 1.5, rB = 1.5;
@@ -1077,6 +1083,7 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
       work[dstA * 64 + lane] = __builtin_ldexp(rA, 1023 - (int)(keyA >> 20));
       if (two != 0) work[dstB * 64 + lane] = __builtin_ldexp(rB, 1023 - (int)(keyB >> 20));
       o += 1 + two;
+      STAMP(4)
     }
   }
   wg_barrier();
@@ -1089,6 +1096,7 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
     work[slot * 64 + lane] = v / wave_sum(v);
   }
   wg_barrier();
+  STAMP(5)
   if (lflag[0]) {                                 // messages of a bailed graph are not written back
     if (t == 0) f.bail[g] = 3;
     return;
@@ -1105,6 +1113,8 @@ __global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(Swe
       d.marginals[((size_t)g * d.n_vars + v) * 64 + lane] = renorm(acc, wave_sum(acc), uniform, true);
     }
   }
+  STAMP(6)
+  STAMP_FLUSH
   if (GRAD) gradient_epilogue_x64<NT>(d, gf, tab, work, umsg, upos, red0, g);
 }
 

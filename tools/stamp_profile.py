@@ -45,8 +45,9 @@ torch.cuda.synchronize()
 raw = buf.cpu().numpy().reshape(64, 8)
 print('debug bits of phase 2 (wg0): slow=%d neg=%d inf=%d allzero=%d' % ((raw[0,2]>>40)&15, (raw[0,2]>>44)&15, (raw[0,2]>>48)&15, (raw[0,2]>>52)&15))
 t = (raw & ((1<<40)-1)).astype(float)
-names = ['prologue', 'op header', 'var product', 'var normalise', 'pair partials', 'barrier', 'gather partials',
-         'pair normalise']
+names = (['A: indices, image, messages', 'B: tables + unary + products (incl. load latency)', 'loop: inputs + partials', 'loop: barrier',
+          'loop: gather + rescale', 'final normalisation', 'write-back + marginals', '-'] if variant == 1 else
+         ['prologue', 'op header', 'var product', 'var normalise', 'pair partials', 'barrier', 'gather partials', 'pair normalise'])
 tot = t.sum(1).mean()
 print('workload %s variant %d: mean cycles per workgroup %.0f' % (workload, variant, tot))
 for i, n in enumerate(names):

@@ -2,6 +2,7 @@
 """Benchmark of the batched LBP sweep (BASELINE.json metric) on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...          (WORLD_SIZE unset: starts its own N rank processes, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -19,10 +20,19 @@ batch, so a step contributes `sweeps` iters.
 value = whole-job iters/s x (graphs per GPU / 8192) aggregated over GPUs -- i.e. sweeps of an
 8192-graph batch per second; with N GPUs the job holds N batches (weak scaling).
 
-Extra objects on the JSON line: `roofline` (dominant kernel = the fused sweep launch; achieved =
-algorithmic bytes / HIP-event time of that launch) and `cpu_baseline` (the CPU oracle -- a port of
-the reference's per-graph, per-message NumPy cost model -- timed on this box's host cores on a
-bounded sample; rank 0, N=1 only).
+Extra objects on the JSON line: `roofline` (dominant kernel = the fused sweep launch) and `cpu_baseline`
+(the CPU oracle -- a port of the reference's per-graph, per-message NumPy cost model -- timed on this
+box's host cores on a bounded sample; rank 0, N=1 only).
+
+roofline, HBM-bound workloads: `achieved` = COMPULSORY HBM bytes of one launch / HIP-event time of that
+launch, where compulsory = every distinct table and unary row the batch references read once + the index
+arrays + the message write-back + the marginals (`compulsory_bytes` breaks it down so that it can be
+recomputed by hand); `frac` = achieved / 8 TB/s and is <= 1 by construction.  The resident-table kernels
+read each table once per launch however many sweeps reuse it, so SURVEY.md 8(d)'s per-update "algorithmic"
+figure (a table counted once per UPDATE) exceeds the bytes that move; it is reported beside the fraction as
+`algorithmic_GBps` with `table_reuse_factor` = algorithmic / compulsory bytes.  `traffic` = HBM bytes per
+launch measured with rocprofv3 --pmc (tools/pmc_passes.sh -> profiles/pmc_traffic.json); it is reported only
+when that measurement was made on the kernel sources of this run (sha of csrc/), else null with the reason.
 
 Before the W warmup steps the same step runs 300 more times untimed (MLBP_BENCH_SPINUP_STEPS) so that the GPU, idle
 since process start, is at its steady clocks when the timed region begins.
@@ -37,6 +47,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
+KERNEL_NAMES = {0: 'sweep_x64_kernel (first generation)',
+                1: 'scale-free X=64 kernel (include/mlbp.h MLBP_KERNEL_SCALE_FREE) + the ~5 us fix-up pass of sweep_x64_fused_kernel, timed together',
+                2: 'sweep_x64_fused_kernel (exact)',
+                3: 'sweep_x64_shared_kernel (v_mfma_f64_16x16x4_f64; timed region also holds the flag memset and the fix-up pass)',
+                4: 'sweep_wide_kernel', 5: 'sweep_generic_kernel',
+                6: 'shared-table contraction over the whole batch + renormalise / variable-update kernels (mlbp_gemm.hip)'}
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix spec (= FP64 vector; 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz); the guide's
                                 # MFMA table has no f64 row
@@ -72,6 +88,62 @@ def algorithmic_bytes_per_graph(topo, roots, X, elem=8, table_elem=8):
             else:
                 total += 2 * X * elem
     return total
+
+
+def compulsory_bytes(topo, X, B, n_pair_tables_used, n_unary_rows_used, table_elem, keep_messages, init, marginals):
+    """HBM bytes one sweep launch cannot avoid: every distinct table / unary row the batch references once, the
+    int32 index arrays, the messages (read unless the launch initialises them, written back unless told not to)
+    and the marginal read-out."""
+    parts = {
+        'pair_tables': n_pair_tables_used * X * X * table_elem,
+        'unary_rows': n_unary_rows_used * X * 8,
+        'index_arrays': B * (topo.P + topo.U) * 4,
+        'message_read': 0 if init else B * topo.n_msgs * X * 8,
+        'message_writeback': B * topo.n_msgs * X * 8 if keep_messages else 0,
+        'marginals': B * topo.n_vars * X * 8 if marginals else 0,
+    }
+    parts['total'] = sum(parts.values())
+    return parts
+
+
+def kernel_sources_sha():
+    """sha256 over the HIP/C++ sources the library is built from: ties a PMC traffic measurement to the kernels it
+    was made on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'macaronicusermodeling_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.hip', '.cpp', '.h')):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(a, argv):
+    """`python bench.py --gpus N` with no launcher around it: this process (which has not imported torch and never
+    touches the GPU) starts N fresh rank processes through torch.distributed.run -- one per GPU, RCCL rendezvous on
+    127.0.0.1 -- waits for them and relays rank 0's JSON line.  Nothing is re-exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    if proc.returncode != 0 or line is None:
+        raise SystemExit(proc.returncode or 1)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -179,12 +251,12 @@ def main():
                     help='HBM bytes per sweep launch from a rocprofv3 --pmc pass (profiles/), if known')
     a = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        return self_launch(a, sys.argv[1:])
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (a.gpus, a.gpus))
         raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, a.gpus))
 
     cpu = None
@@ -278,6 +350,13 @@ def main():
     # ~100 launches to reach its steady clocks (measured: 0.32 ms per launch over the first 20, 0.29 ms after 300).
     # The same step runs untimed MLBP_BENCH_SPINUP_STEPS times (default 300, about 0.1 s; the same count on every
     # rank, the steps include the all-reduce) before the W warmup steps; set it to 0 to time from cold.
+    step()                                  # lazy allocations / first-use module loads
+    torch.cuda.synchronize()
+    tc = time.perf_counter()
+    for _ in range(a.steps):                # the same K steps from a cold (idle-clock) device: reported as cold_ms_per_step
+        step()
+    torch.cuda.synchronize()
+    cold_ms = (time.perf_counter() - tc) / a.steps * 1e3
     for _ in range(int(os.environ.get('MLBP_BENCH_SPINUP_STEPS', '300'))):
         step()
     torch.cuda.synchronize()
@@ -304,14 +383,6 @@ def main():
         elapsed = float(t.item())
     assert fb.program(roots).status() == 0
 
-    traffic, traffic_src = a.traffic_bytes, 'command line' if a.traffic_bytes else None
-    if traffic is None:
-        try:    # HBM bytes per launch measured with rocprofv3 --pmc for this exact workload (profiles/)
-            rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get(a.workload)
-            if rec and rec['batch'] == B and rec['sweeps'] == sweeps and a.variant in (None, 1) and not a.no_writeback:
-                traffic, traffic_src = rec['hbm_bytes_per_launch'], rec['source']
-        except (OSError, ValueError, KeyError):
-            pass
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         iters_per_s = world * (B / 8192.0) * sweeps * a.steps / elapsed
@@ -319,18 +390,52 @@ def main():
         avg_ms = sum(sweep_ms) / len(sweep_ms)
         table_elem = 4 if a.workload.endswith('_f32') else 8
         alg_bytes = algorithmic_bytes_per_graph(topo, roots, X, table_elem=table_elem) * B
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        used_mfma = shared and _ffi.lib.mlbp_last_sweep_kernel() in (3, 6)
-        mfma_kernel = ('sweep_x64_shared_kernel (v_mfma_f64_16x16x4_f64; timed region also holds the flag memset and the fix-up pass)'
-                       if _ffi.lib.mlbp_last_sweep_kernel() == 3 else
-                       'rocBLAS DGEMM per factor->variable update over the whole batch + renormalise / variable-update kernels (mlbp_gemm.hip)')
+        n_pt = int(torch.unique(fb.pair_tab).numel()) if topo.P else 0
+        n_ur = int(torch.unique(fb.unary_tab).numel()) if topo.U else 0
+        comp = compulsory_bytes(topo, X, B, n_pt, n_ur, table_elem, keep_messages=not a.no_writeback, init=True, marginals=True)
+        achieved = comp['total'] / (avg_ms * 1e-3) / 1e9
+        # measured HBM traffic: only a rocprofv3 --pmc measurement of THIS workload made on THESE kernel sources counts
+        sha = kernel_sources_sha()
+        traffic, traffic_src = a.traffic_bytes, 'command line' if a.traffic_bytes else None
+        if traffic is None:
+            try:
+                key = a.workload + ('_nowriteback' if a.no_writeback else '')
+                rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get(key)
+                if not rec:
+                    traffic_src = 'no rocprofv3 --pmc measurement of this workload in profiles/pmc_traffic.json'
+                elif rec['batch'] != B or rec['sweeps'] != sweeps or a.variant not in (None, 1):
+                    traffic_src = 'profiles/pmc_traffic.json holds this workload at another size or variant'
+                elif rec.get('kernel_sources_sha') != sha:
+                    traffic_src = 'stale: %s was measured on kernel sources %s, this run is %s' % (rec['source'], rec.get('kernel_sources_sha'), sha)
+                else:
+                    traffic, traffic_src = rec['hbm_bytes_per_launch'], rec['source']
+            except (OSError, ValueError, KeyError) as e:
+                traffic_src = 'profiles/pmc_traffic.json unreadable: %s' % e
+        last = _ffi.lib.mlbp_last_sweep_kernel()
+        used_mfma = shared and last in (3, 6)
         if used_mfma:      # shared-table mode is priced in flops, 2 X^2 per pairwise update and graph
             n_pair = sum(int(np.isin(topo.compile_sweep(r)[0][:, 0], (_ffi.OP_PAIR_TM, _ffi.OP_PAIR_MT)).sum()) for r in roots)
             alg_flops = 2.0 * X * X * n_pair * B
+            tfl = alg_flops / (avg_ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'achieved': tfl, 'peak': F64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': tfl / F64_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                    'kernel': KERNEL_NAMES.get(last, str(last)), 'algorithmic_flops_per_launch': alg_flops,
+                    'hbm_GBps_on_compulsory_bytes': achieved, 'compulsory_bytes': comp}
+        else:
+            roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                    'kernel': KERNEL_NAMES.get(last, str(last)), 'compulsory_bytes': comp,
+                    'algorithmic_bytes_per_launch': alg_bytes, 'algorithmic_GBps': alg_bytes / (avg_ms * 1e-3) / 1e9,
+                    'table_reuse_factor': alg_bytes / comp['total']}
+            if traffic:
+                roof['frac_on_measured_traffic'] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            assert roof['frac'] <= 1.0, 'a roofline fraction above 1 means the byte count is wrong'
+        roof.update({'avg_launch_ms': avg_ms, 'min_launch_ms': sweep_ms[0], 'max_launch_ms': sweep_ms[-1],
+                     'kernel_sources_sha': sha})
         out = {
             'metric': 'LBP sweep iters/sec (whole node), batch=8192 graphs |X|=64',
             'value': iters_per_s, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': ms_per_step, 'cold_ms_per_step': cold_ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64 (f32 tables)' if a.workload.endswith('_f32') else 'f64', 'data': 'synthetic',
             'config': {'workload': '%s: %d graphs/GPU, |X|=%d, P=%d pairwise + U=%d unary factors, unique %s '
                                    'table per (graph,factor)%s, step = initialize + %d sweeps + posterior read-out'
@@ -339,18 +444,7 @@ def main():
                        'graph_sweeps_per_s': world * B * sweeps * a.steps / elapsed,
                        'parallelism': 'graphs sharded over %d GPU(s), no data-path collective; one all-reduce of the '
                                       'step statistics per step (%s)' % (world, backend if world > 1 else 'n/a')},
-            'roofline': {'bound': 'mfma', 'achieved': alg_flops / (avg_ms * 1e-3) / 1e12, 'peak': F64_MFMA_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': alg_flops / (avg_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                         'traffic_source': traffic_src, 'kernel': mfma_kernel, 'algorithmic_flops_per_launch': alg_flops,
-                         'avg_launch_ms': avg_ms, 'min_launch_ms': sweep_ms[0], 'max_launch_ms': sweep_ms[-1],
-                         'hbm_equivalent_GBps_if_tables_were_unique': achieved} if used_mfma else
-                        {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                         'kernel': ('sweep_x64_sf_kernel (timed region = this kernel + the ~5 us fix-up pass of sweep_x64_fused_kernel)') if X == 64 and a.variant in (None, 1) and 1 <= topo.P <= 4 else
-                                   ('sweep_x64_fused_kernel' if X == 64 else
-                                    ('sweep_wide_kernel' if X in (128, 256, 512) else 'sweep_generic_kernel')),
-                         'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': avg_ms,
-                         'min_launch_ms': sweep_ms[0], 'max_launch_ms': sweep_ms[-1]},
+            'roofline': roof,
             'cpu_baseline': cpu,
         }
         if cpu is not None:

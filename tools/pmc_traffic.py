@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
 """Summarises two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md's HBM
 section prescribes) into HBM bytes per launch for the sweep kernels of one bench.py workload.
-usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <workload> <batch> <sweeps> <out.json>
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <workload> <batch> <sweeps> <out.json> [key]
+(also merges the total into profiles/pmc_traffic.json under `key`, with the sha of the kernel sources)
 Rule (gfx950): FETCH_SIZE counts KiB and reads exactly half of a 16-byte-per-lane coalesced stream -> doubled;
 WRITE_SIZE (KiB) is taken as is."""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
 
 
-KERNELS = ['sweep_x64_sf_kernel', 'sweep_x64_fused_kernel', 'sweep_x64_shared_kernel', 'sweep_wide_kernel', 'sweep_generic_kernel',
+KERNELS = ['sweep_x64_lean_kernel', 'sweep_x64_sf_kernel', 'sweep_x64_fused_kernel', 'sweep_x64_shared_kernel', 'sweep_wide_kernel', 'sweep_generic_kernel',
            'sweep_x64_kernel', 'unary_writeback_kernel', 'table_fragments_kernel']
 
 
@@ -46,3 +48,15 @@ res['_derived'] = {'workload': '%s B=%d, %d sweeps + fused marginal read-out' % 
                    'rule': 'separate --pmc passes; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 summed over the kernels of one sweep call'}
 json.dump(res, open(out_path, 'w'), indent=1, sort_keys=True)
 print(json.dumps(res['_derived']))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_sources_sha          # noqa: E402
+key = sys.argv[7] if len(sys.argv) > 7 else workload
+reg_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+try:
+    reg = json.load(open(reg_path))
+except (OSError, ValueError):
+    reg = {}
+reg[key] = {'hbm_bytes_per_launch': total, 'source': os.path.relpath(out_path, ROOT), 'batch': batch, 'sweeps': sweeps,
+            'kernel_sources_sha': kernel_sources_sha()}
+json.dump(reg, open(reg_path, 'w'), indent=1, sort_keys=True)

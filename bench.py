@@ -52,6 +52,7 @@ KERNEL_NAMES = {0: 'sweep_x64_kernel (first generation)',
                 2: 'sweep_x64_fused_kernel (exact)',
                 3: 'sweep_x64_shared_kernel (v_mfma_f64_16x16x4_f64; timed region also holds the flag memset and the fix-up pass)',
                 4: 'sweep_wide_kernel', 5: 'sweep_generic_kernel',
+                7: 'sweep_x64_lean_kernel (scale-free, micro-op form) + the ~5 us fix-up pass of sweep_x64_fused_kernel, timed together',
                 6: 'shared-table contraction over the whole batch + renormalise / variable-update kernels (mlbp_gemm.hip)'}
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix spec (= FP64 vector; 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz); the guide's

@@ -205,14 +205,22 @@ typedef struct mlbp_sweep_args {
  * config 5 -- half the HBM bytes per update.  X = 256 or 512; messages, products and sums stay float64, so
  * results equal the float64 path run on the float32-rounded tables; no gradient in this mode. */
 #define MLBP_SWEEP_PAIR_TABLES_F32 4
+/* flags: the caller states that the index arrays are the identity, pair_tab[b][p] == b*P + p and unary_tab[b][u] ==
+ * b*U + u (one private table per (graph, factor), stored in graph order -- FactorGraphBatch's default layout).  The
+ * fast X = 64 kernel then addresses the tables directly instead of waiting for an index load before it can issue
+ * the table loads.  The arrays must still be valid: the statement is checked on the device off the critical path,
+ * and a graph for which it does not hold is computed by the exact kernel through the arrays. */
+#define MLBP_SWEEP_DENSE_TABLES 8
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
 
 /* Kernel-variant selector for A/B measurement (not needed in normal use; also settable through the
  * MLBP_SWEEP_VARIANT environment variable):
  *   1     default: for X = 64 the scale-free kernel (messages carried with an exact power-of-two
- *         scale, true normalisation deferred to the end of the call, one barrier per update)
- *         followed by the exact fused kernel on the graphs it flagged as degenerate;
+ *         scale, true normalisation deferred to the end of the call, one barrier per update) in its
+ *         micro-op form (mlbp_lean.hip) followed by the exact fused kernel on the graphs it flagged as
+ *         degenerate;
+ *   2     as 1 with the first form of the scale-free kernel (sweep_x64_sf_kernel);
  *   3     exact fused kernel only (normalises after every update like the reference);
  *   0     first-generation kernel;   10+N  exact fused kernel with N register-resident tables
  *         (N = 0 streams);           20+N  scale-free kernel with N resident tables (N = 1..4);
@@ -232,6 +240,7 @@ int mlbp_set_sweep_variant(int32_t variant);
 #define MLBP_KERNEL_WIDE 4
 #define MLBP_KERNEL_GENERIC 5
 #define MLBP_KERNEL_SHARED_GEMM 6
+#define MLBP_KERNEL_LEAN 7            /* scale-free X = 64 kernel, micro-op form (mlbp_lean.hip): the default */
 int mlbp_last_sweep_kernel(void);
 
 /* Fills msgs[B][n_msgs][X] with 1/X: FactorGraph.initialize (LBP.py:211-216). */

@@ -51,6 +51,7 @@ class SweepArgs(C.Structure):
 SWEEP_SHARED_PAIR_TABLES = 1      # include/mlbp.h MLBP_SWEEP_*
 SWEEP_NO_MESSAGE_WRITEBACK = 2
 SWEEP_PAIR_TABLES_F32 = 4
+SWEEP_DENSE_TABLES = 8
 GRADIENT_SHARED_PAIR_TABLES = 1
 
 

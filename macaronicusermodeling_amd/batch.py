@@ -95,6 +95,7 @@ class FactorGraphBatch:
         t = torch.as_tensor(tables).to(self.device).to(dtype).contiguous()
         if t.dim() != 3 or t.shape[1] != self.X or t.shape[2] != self.X:
             raise ValueError('pair tables must be [n][X][X]')
+        self._pair_dense = pair_tab is None          # identity index: stated to the kernel (MLBP_SWEEP_DENSE_TABLES)
         if pair_tab is None:
             if t.shape[0] != self.B * self.topo.P:
                 raise ValueError('need B*P tables when pair_tab is omitted')
@@ -111,6 +112,7 @@ class FactorGraphBatch:
         t = torch.as_tensor(tables, dtype=torch.float64).to(self.device).contiguous()
         if t.dim() != 2 or t.shape[1] != self.X:
             raise ValueError('unary tables must be [n][X]')
+        self._unary_dense = unary_tab is None
         if unary_tab is None:
             if t.shape[0] != self.B * self.topo.U:
                 raise ValueError('need B*U tables when unary_tab is omitted')
@@ -162,6 +164,8 @@ class FactorGraphBatch:
         a.msgs = self.msgs.data_ptr()
         a.normalize_messages = 1 if self.normalize_messages else 0
         a.init_messages = 1 if init else 0
+        if (getattr(self, '_pair_dense', False) or not self.topo.P) and (getattr(self, '_unary_dense', False) or not self.topo.U):
+            a.flags |= _ffi.SWEEP_DENSE_TABLES
         if getattr(self, 'pair_tables_shared', False):
             a.flags |= _ffi.SWEEP_SHARED_PAIR_TABLES
             if getattr(self, '_pair_row_host', None) is not None:       # X >= 128: op-by-op DGEMM path needs the row on the host

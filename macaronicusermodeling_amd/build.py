@@ -10,7 +10,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libmlbp.so')
-SOURCES = ['mlbp_host.cpp', 'mlbp_sweep.hip', 'mlbp_shared.hip', 'mlbp_gemm.hip', 'mlbp_prims.hip', 'mlbp_grad.hip']
+SOURCES = ['mlbp_host.cpp', 'mlbp_sweep.hip', 'mlbp_lean.hip', 'mlbp_shared.hip', 'mlbp_gemm.hip', 'mlbp_prims.hip', 'mlbp_grad.hip']
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fno-fast-math', '-Wall',
          '-Wno-unused-function']
 
@@ -24,7 +24,7 @@ def _stale(obj, deps):
 
 def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    headers = [os.path.join(CSRC, 'mlbp_internal.h'), os.path.join(PKG, '..', 'include', 'mlbp.h')]
+    headers = [os.path.join(CSRC, 'mlbp_internal.h'), os.path.join(CSRC, 'mlbp_device.h'), os.path.join(PKG, '..', 'include', 'mlbp.h')]
     objs = []
     for src in SOURCES:
         path = os.path.join(CSRC, src)

@@ -22,6 +22,21 @@ struct FusedProgram {
   bool has_unary_fops = false;
 };
 
+// Micro-op form of the lean X = 64 kernel (mlbp_lean.hip): operands are LDS byte offsets.
+struct LeanProgram {
+  bool ok = false;
+  const char* why = "";
+  int n_bundles = 0, HL = 0, n_cprod = 0, WL = 0;
+  std::vector<int32_t> image;          // bundles [n_bundles][16] | hoist [4][HL][2] | cprod lists [n_cprod][16] | written [4][WL] | padding
+  std::vector<char> hoisted;           // [n_msgs] the slot holds a hoisted (constant) unary message
+  std::vector<std::vector<int32_t>> cprods;   // hoisted message slots of constant product k
+};
+void build_lean_program(const FusedProgram& fp, int n_msgs, LeanProgram& out);
+bool build_lean_readout(const LeanProgram& lp, int n_msgs, int n_vars, const int32_t* in_off, const int32_t* in_slots,
+                        std::vector<int32_t>& image);
+// Enqueues the lean scale-free kernel when it applies (sets *launched); flagged graphs are left in prog->d_bail.
+int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched);
+
 // Shared-table (MFMA) form, mlbp_shared.hip: 16 graphs per workgroup, messages kept as [state][graph]
 // tiles in LDS, only the "live" slots (read or written inside the sweeps) resident.
 struct SharedProgram {
@@ -74,6 +89,9 @@ struct mlbp_program {
   int32_t* d_fsweeps;     // [n_sweeps][2]
   int32_t* d_fpairseq;    // pair slot of the k-th executed pairwise update of the fused form (-1 terminated)
   int device;
+  mlbp::LeanProgram lean;
+  int32_t* d_limage = nullptr;   // LeanProgram::image
+  int32_t* d_lreadout = nullptr; // build_lean_readout
   // shared-table form (mlbp_shared.hip)
   mlbp::SharedProgram shared;
   int32_t* d_simage;      // SharedProgram::image

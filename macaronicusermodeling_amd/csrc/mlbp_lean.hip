@@ -1,0 +1,686 @@
+// X = 64, float64, per-graph tables: the "lean" scale-free sweep kernel (default path of BASELINE configs 2-4).
+//
+// Same algorithm and the same scale-free representation as sweep_x64_sf_kernel (mlbp_sweep.hip): one 256-thread
+// workgroup owns one graph for all sweeps of a call, messages live in LDS carried with an exact power-of-two
+// scale, the pairwise tables stay in registers, true normalisations (LBP.py:649-657) happen once after the last
+// sweep, graphs the representation cannot hold are flagged for the exact kernel.  What differs is the cost of one
+// update -- the old kernel spent ~275 wave instructions and ~10 dependent LDS round trips around 16 useful FMAs:
+//
+//   * the program is compiled on the host into 8-word micro-ops whose operands are LDS byte offsets, so an
+//     update reads one descriptor and issues its message loads at once (no source lists, no slot arithmetic);
+//   * a thread owns a 4 x 4 block of each table (rows 4R..4R+3, column pairs {2c,2c+1} and {32+2c,33+2c}), so BOTH
+//     directions of an update are 16 FMAs followed by a short select-light reduction:
+//        T.m   (reduce over columns): v_permlane16_swap (4 -> 2 values), one DPP step with a select (2 -> 1), two
+//              plain DPP steps;
+//        m^T.T (reduce over rows):    one DPP row_ror:8 step (the two column pairs sit in swapped registers in lanes
+//              with bit 3 set, so no select is needed), v_permlane32_swap, then the four waves meet in LDS;
+//     and the variable->factor product feeding an update is formed directly in the distribution the contraction
+//     needs (4 columns or 4 rows per lane) -- no LDS round trip between product and contraction;
+//   * every global load instruction of a table covers 128-byte contiguous pieces (8 lanes x 16 B).
+// One barrier per bundle of (at most two independent) updates, as before.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "mlbp_device.h"
+#include "mlbp_internal.h"
+
+using mlbp::fail;
+using namespace mlbp_dev;
+
+namespace {
+
+constexpr int WG = 256;
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) return fail(MLBP_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+// micro-op word 0
+constexpr int UOP_VAR = 1;          // bit 0: variable product only (stored, no contraction)
+constexpr int UOP_MT = 2;           // bit 1: out = m^T . T (else T . m)
+constexpr int UOP_PSLOT_SHIFT = 2;  // bits 2-4: pair slot (register-resident table)
+constexpr int UOP_NOP = 32;         // bit 5: empty second slot of a bundle
+constexpr int UOP_NSRC_SHIFT = 8;   // bits 8-11: number of sources (1..4)
+// micro-op words: 0 flags | 1-4 source byte offsets | 5 byte offset of the variable->factor message to store, or -1 |
+// 6 destination byte offset | 7 unused.  A bundle = two micro-ops = 16 words = one s_load_dwordx16.
+
+struct LeanDev {
+  const int32_t* image;   // bundles [n_bundles][16] | hoist [4][HL][2] | cprod lists [n_cprod][16] | written [4][WL] | pad
+  const int32_t* readout; // [n_vars][16]: count, base slot, varying slots... (build_lean_readout) or NULL
+  uint8_t* bail;          // [B]
+  int32_t n_bundles, HL, n_cprod, WL, n_ext, init, dense, keep;
+};
+
+// 16 consecutive words through the scalar data cache (s_load_dwordx16): wave-uniform program data lands in SGPRs.
+struct Words16 { int32_t w[16]; };
+typedef int v16i __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ Words16 sload16(const int32_t* p) {
+  const v16i v = *(const v16i __attribute__((address_space(4)))*)(uintptr_t)p;
+  Words16 r;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r.w[i] = v[i];
+  return r;
+}
+
+// Diagnostic build only (-DMLBP_LEAN_PROBE, tools/lean_probe.py): phase ablation by mask and shader-clock stamps of
+// wave 0 of selected workgroups into a side buffer no other code reads.  Never defined in the shipped library.
+#ifdef MLBP_LEAN_PROBE
+__device__ int g_probe_mask = 0;
+__device__ unsigned long long* g_probe_buf = nullptr;
+#define PROBE_DECL const int probe_mask_ = __builtin_amdgcn_readfirstlane(g_probe_mask); unsigned long long pst_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int pn_ = 0;
+#define PROBED(bit) (probe_mask_ & (1 << (bit)))
+#define PSTAMP { unsigned long long _t; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); pst_[pn_++] = _t; }
+#define PSTAMP_VM { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PSTAMP }
+#define PFLUSH if (g_probe_buf && threadIdx.x == 0 && (blockIdx.x & 63) == 0) { unsigned long long _rt; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_rt) :: "memory"); for (int _i = 0; _i < 10; ++_i) g_probe_buf[(blockIdx.x >> 6) * 12 + _i] = pst_[_i]; g_probe_buf[(blockIdx.x >> 6) * 12 + 10] = _rt; }
+#else
+#define PROBE_DECL
+#define PROBED(bit) 0
+#define PSTAMP
+#define PSTAMP_VM
+#define PFLUSH
+#endif
+
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// a' = [a.row0, b.row0, a.row2, b.row2], b' = [a.row1, b.row1, a.row3, b.row3] (rows of 16 lanes); a' + b'
+__device__ __forceinline__ double swapadd16(double a, double b) {
+  auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// a' = [a.lo32, b.lo32], b' = [a.hi32, b.hi32] (halves of 32 lanes); a' + b'
+__device__ __forceinline__ double swapadd32(double a, double b) {
+  auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+struct LaneGeo {
+  int tm0, tm1;   // byte offsets inside a message of the lane's column pairs held in table registers k = 0, 1
+  int mt;         // byte offset of the lane's four rows
+  int red_tm;     // byte offset (in a [64] array) of the row this lane reports after the T.m reduction
+  int red_mt;     // byte offset (in a [4][64] array) of the column this lane reports after the m^T.T reduction
+  bool up, st_tm, st_mt, wr_tm;
+};
+
+__device__ __forceinline__ double2 lds2(const char* p) { return *reinterpret_cast<const double2*>(p); }
+__device__ __forceinline__ void mul2(double2& a, const double2 b) { a.x *= b.x; a.y *= b.y; }
+
+// One table (T[r][k] = rows 4R + r, column pair k ^ b3) against one input vector; u = the micro-op's 8 words (scalars).
+template <bool MT>
+__device__ __forceinline__ void contract(const double2 (&T)[4][2], char* wb, const int32_t* u, const LaneGeo& G, char* redA) {
+  const int nsrc = (u[0] >> UOP_NSRC_SHIFT) & 15, vf = u[5];
+  if (MT) {
+    double2 ma = lds2(wb + u[1] + G.mt), mb = lds2(wb + u[1] + G.mt + 16);
+    if (nsrc > 1) {
+      const double2 a = lds2(wb + u[2] + G.mt), b = lds2(wb + u[2] + G.mt + 16);
+      mul2(ma, a); mul2(mb, b);
+      if (nsrc > 2) {
+        const double2 a2 = lds2(wb + u[3] + G.mt), b2 = lds2(wb + u[3] + G.mt + 16);
+        mul2(ma, a2); mul2(mb, b2);
+        if (nsrc > 3) { const double2 a3 = lds2(wb + u[4] + G.mt), b3 = lds2(wb + u[4] + G.mt + 16); mul2(ma, a3); mul2(mb, b3); }
+      }
+    }
+    if (vf >= 0 && G.st_mt) {
+      *reinterpret_cast<double2*>(wb + vf + G.mt) = ma;
+      *reinterpret_cast<double2*>(wb + vf + G.mt + 16) = mb;
+    }
+    double a00 = ma.x * T[0][0].x, a01 = ma.x * T[0][0].y, a10 = ma.x * T[0][1].x, a11 = ma.x * T[0][1].y;
+    a00 += ma.y * T[1][0].x; a01 += ma.y * T[1][0].y; a10 += ma.y * T[1][1].x; a11 += ma.y * T[1][1].y;
+    a00 += mb.x * T[2][0].x; a01 += mb.x * T[2][0].y; a10 += mb.x * T[2][1].x; a11 += mb.x * T[2][1].y;
+    a00 += mb.y * T[3][0].x; a01 += mb.y * T[3][0].y; a10 += mb.y * T[3][1].x; a11 += mb.y * T[3][1].y;
+    // rows: lane bit 3 (partner l ^ 8 keeps the other column pair in its register 0), lane bit 5, then the waves
+    a00 += dpp_mov<0x128>(a10);
+    a01 += dpp_mov<0x128>(a11);
+    *reinterpret_cast<double*>(redA + G.red_mt) = swapadd32(a00, a01);
+  } else {
+    double2 m0 = lds2(wb + u[1] + G.tm0), m1 = lds2(wb + u[1] + G.tm1);
+    if (nsrc > 1) {
+      const double2 a = lds2(wb + u[2] + G.tm0), b = lds2(wb + u[2] + G.tm1);
+      mul2(m0, a); mul2(m1, b);
+      if (nsrc > 2) {
+        const double2 a2 = lds2(wb + u[3] + G.tm0), b2 = lds2(wb + u[3] + G.tm1);
+        mul2(m0, a2); mul2(m1, b2);
+        if (nsrc > 3) { const double2 a3 = lds2(wb + u[4] + G.tm0), b3 = lds2(wb + u[4] + G.tm1); mul2(m0, a3); mul2(m1, b3); }
+      }
+    }
+    if (vf >= 0 && G.st_tm) {
+      *reinterpret_cast<double2*>(wb + vf + G.tm0) = m0;
+      *reinterpret_cast<double2*>(wb + vf + G.tm1) = m1;
+    }
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = T[r][0].x * m0.x;
+      v[r] += T[r][0].y * m0.y;
+      v[r] += T[r][1].x * m1.x;
+      v[r] += T[r][1].y * m1.y;
+    }
+    // columns: lane bit 4 (rows of 16 lanes exchange registers), lane bit 2 (select), lane bits 1 and 0 (plain)
+    const double u0 = swapadd16(v[0], v[2]), u1 = swapadd16(v[1], v[3]);
+    const double keep = G.up ? u1 : u0, send = G.up ? u0 : u1;
+    double w = keep + dpp_mov<0x141>(send);
+    w += dpp_mov<0xB1>(w);
+    w += dpp_mov<0x4E>(w);
+    *reinterpret_cast<double*>(redA + G.red_tm) = w;        // the four lanes of a quad hold (and store) the same row
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void front(const double2 (&tab)[NT][4][2], char* wb, const int32_t* u, const LaneGeo& G, char* redA) {
+  const int pslot = (u[0] >> UOP_PSLOT_SHIFT) & 7;
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+    if (p == pslot) {
+      if (u[0] & UOP_MT) contract<true>(tab[p], wb, u, G, redA);
+      else contract<false>(tab[p], wb, u, G, redA);
+    }
+  }
+}
+
+// The 64 partial results of one update (lane = state), rescaled by an exact power of two so that ONE normal element
+// lands in [1, 2) (the first one; which one is immaterial -- the scale cancels in everything normalised later).  False
+// when the vector cannot be carried this way: a negative / non-finite entry, or no normal entry at all (the
+// zero-sum -> uniform rule of LBP.py:655-657 would act): the graph then goes to the exact kernel.
+__device__ __forceinline__ bool rescale(double& r) {
+  const unsigned key = mag_key(r);
+  const unsigned long long normal = __ballot(key - KEY_MIN < KEY_BAD - KEY_MIN);
+  if (__builtin_expect(__any(key >= KEY_BAD) || normal == 0, 0)) return false;
+  const int ref = __builtin_amdgcn_readlane((int)key, __builtin_ctzll(normal));
+  r = __builtin_ldexp(r, 1023 - (ref >> 20));
+  return true;
+}
+
+template <int NT>
+__global__ __launch_bounds__(WG, (NT >= 4 ? 2 : 3)) void sweep_x64_lean_kernel(SweepDev d, LeanDev f) {
+  extern __shared__ double lds[];
+  double* work = lds;                                        // [n_msgs + n_ext][64] scaled messages
+  double* red = lds + (size_t)(d.n_msgs + f.n_ext) * 64;     // [2 parities][2 bundle slots][4][64]
+  int32_t* lflag = reinterpret_cast<int32_t*>(red + 4 * 256);
+
+  const int g = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const double uniform = 1.0 / 64.0;
+  double* gm = d.msgs + (size_t)g * d.n_msgs * 64;
+  const int32_t* img_hoist = f.image + 16 * (size_t)f.n_bundles;
+  const int32_t* img_cprod = img_hoist + 8 * (size_t)f.HL;
+  const int32_t* img_written = img_cprod + 16 * (size_t)f.n_cprod;
+
+  LaneGeo G;
+  const int c_ = (lane & 7) | ((lane >> 1) & 8), b3_ = (lane >> 3) & 1, R_ = 4 * wave + (b3_ | ((lane >> 5) << 1));
+  {
+    const int b5 = lane >> 5, b4 = (lane >> 4) & 1, b2 = (lane >> 2) & 1;
+    G.tm0 = (32 * b3_ + 2 * c_) * 8;
+    G.tm1 = (32 * (1 - b3_) + 2 * c_) * 8;
+    G.mt = 4 * R_ * 8;
+    G.red_tm = (4 * R_ + 2 * b4 + b2) * 8;
+    G.red_mt = (wave * 64 + 32 * b3_ + 2 * c_ + b5) * 8;
+    G.up = b2 != 0;
+    G.st_tm = wave == 0 && (lane & 0x28) == 0;
+    G.st_mt = (lane & 0x17) == 0;
+    G.wr_tm = (lane & 3) == 0;
+  }
+
+  PROBE_DECL
+  PSTAMP          // 0: start
+  if (t == 0) f.bail[g] = 0;
+  // ---- phase A: every HBM load of the graph is issued before anything waits: unary rows first (they are needed
+  //      first and vmcnt retires in order), then the tables, then the (dense) index check ----
+  bool ok = true;
+  constexpr int HB = 8;                       // unary rows per wave held in registers; more go round again below
+  double ur[HB];
+  int uslot[HB];
+  {
+    const Words16 hl = sload16(img_hoist + wave * 2 * f.HL);      // this wave's (unary slot, message slot) pairs, -1 padded
+#pragma unroll
+    for (int j = 0; j < HB; ++j) {
+      const int u = hl.w[2 * j];
+      uslot[j] = hl.w[2 * j + 1];
+      ur[j] = 0.0;
+      if (u >= 0) {
+        const int row = f.dense ? g * d.U + u : as_const(d.unary_tab)[(size_t)g * d.U + u];
+        if ((unsigned)row >= (unsigned)d.n_unary_tables) ok = false;
+        else if (!PROBED(5)) ur[j] = d.unary_tables[(size_t)row * 64 + lane];
+      }
+    }
+  }
+  double2 tab[NT][4][2];
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+    if (p < d.P) {
+      const int ti = f.dense ? g * d.P + p : as_const(d.pair_tab)[(size_t)g * d.P + p];
+      if ((unsigned)ti >= (unsigned)d.n_pair_tables) { ok = false; continue; }
+      if (PROBED(4)) continue;
+      const double* T = d.pair_tables + (size_t)ti * 4096 + (size_t)(4 * R_) * 64 + 2 * c_;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        tab[p][r][0] = *reinterpret_cast<const double2*>(T + r * 64 + 32 * b3_);
+        tab[p][r][1] = *reinterpret_cast<const double2*>(T + r * 64 + 32 * (1 - b3_));
+      }
+    }
+  }
+  // MLBP_SWEEP_DENSE_TABLES is a statement about the index arrays; it is checked off the critical path (the loads
+  // queue behind the tables and are looked at after the sweeps): a false one sends the graph to the exact kernel,
+  // which reads the arrays.
+  bool dense_ok = true;
+  if (f.dense)
+    for (int i = t; i < d.P + d.U; i += WG)
+      dense_ok &= i < d.P ? d.pair_tab[(size_t)g * d.P + i] == g * d.P + i : d.unary_tab[(size_t)g * d.U + (i - d.P)] == g * d.U + (i - d.P);
+  unsigned bad_key = 0;
+  {
+    double2* dst = reinterpret_cast<double2*>(work);
+    if (f.init) {
+      for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = make_double2(uniform, uniform);
+    } else {
+      const double2* src = reinterpret_cast<const double2*>(gm);
+      for (int i = t; i < d.n_msgs * 32; i += WG) {
+        const double2 v = src[i];
+        bad_key = max(bad_key, max(mag_key(v.x), mag_key(v.y)));
+        dst[i] = v;
+      }
+    }
+    if (t < 32) dst[d.n_msgs * 32 + t] = make_double2(uniform, uniform);               // ext slot 0: the uniform vector
+    if (t >= 32 && t < 64) dst[(d.n_msgs + f.n_ext - 1) * 32 + (t - 32)] = make_double2(1.0, 1.0);   // last ext slot: ones
+    if (t == 0) lflag[0] = 0;
+  }
+  PSTAMP          // 1: every load issued
+  lds_barrier();        // the fill above and the unary messages below write the same slots from different waves
+  // hoisted unary messages (exact values: they are outputs); further rounds only when a wave has more than HB rows
+#pragma unroll
+  for (int j = 0; j < HB; ++j) {
+    if (uslot[j] >= 0) {
+      const double s = wave_sum(ur[j]);
+      const double m = renorm(ur[j], s, uniform, true);
+      bad_key = max(bad_key, mag_key(m));
+      work[uslot[j] * 64 + lane] = m;
+    }
+  }
+  for (int j = HB; j < f.HL; ++j) {
+    const const_i32p hp = as_const(img_hoist + (wave * f.HL + j) * 2);
+    const int u = hp[0], slot = hp[1];
+    if (u < 0) break;
+    const int row = f.dense ? g * d.U + u : as_const(d.unary_tab)[(size_t)g * d.U + u];
+    double r = 0.0;
+    if ((unsigned)row < (unsigned)d.n_unary_tables) r = d.unary_tables[(size_t)row * 64 + lane];
+    else ok = false;
+    const double s = wave_sum(r);
+    const double m = renorm(r, s, uniform, true);
+    bad_key = max(bad_key, mag_key(m));
+    work[slot * 64 + lane] = m;
+  }
+  if (!__syncthreads_and(ok ? 1 : 0)) {       // an out-of-range table index: skip the graph, raise the status word
+    if (t == 0) atomicExch(d.status, 1);
+    return;
+  }
+  PSTAMP          // 2: unary messages normalised
+  // constant products: uniform x the hoisted messages a variable multiplies in, in facset order (LBP.py:381-386);
+  // lists are 16 words (count, 15 slots padded with the all-ones slot), wave k & 3 takes list k
+  for (int k = wave; k < f.n_cprod; k += 4) {
+    const Words16 cl = sload16(img_cprod + 16 * k);
+    double acc = uniform;
+#pragma unroll
+    for (int q0 = 1; q0 < 16; q0 += 5) {
+      if (cl.w[0] >= q0) {
+        double m[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) m[q] = work[cl.w[q0 + q] * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc *= m[q];
+      }
+    }
+    bad_key = max(bad_key, mag_key(acc));               // a non-finite intermediate stays non-finite: nan_to_num territory
+    work[(d.n_msgs + 1 + k) * 64 + lane] = acc;
+  }
+  if (__syncthreads_or(bad_key >= KEY_BAD ? 1 : 0)) {
+    if (t == 0) f.bail[g] = 1;                    // bail codes: 1 prologue, 2 main loop, 3 final pass
+    return;
+  }
+  PSTAMP          // 3: constant products
+#ifdef MLBP_LEAN_PROBE
+  PSTAMP_VM       // 4: tables arrived
+#else
+  PSTAMP
+#endif
+
+  // ---- main loop: identical in all four waves; one barrier per bundle; the next bundle's descriptor is fetched
+  //      (scalar load) while this one's partial sums cross the barrier ----
+  char* wb = reinterpret_cast<char*>(work);
+  int parity = 0;
+  Words16 D = sload16(f.image);
+  for (int k = 0; k < f.n_bundles && !PROBED(0); ++k) {
+    if (D.w[0] & UOP_VAR) {
+      // a lone variable update: the product, lane = state, the same in every wave; no contraction, no barrier
+      const int nsrc = (D.w[0] >> UOP_NSRC_SHIFT) & 15;
+      double m = work[(D.w[1] >> 3) + lane];
+      if (nsrc > 1) m *= work[(D.w[2] >> 3) + lane];
+      if (nsrc > 2) m *= work[(D.w[3] >> 3) + lane];
+      if (nsrc > 3) m *= work[(D.w[4] >> 3) + lane];
+      work[(D.w[5] >> 3) + lane] = m;
+      D = sload16(f.image + 16 * (k + 1));
+      continue;
+    }
+    char* redP = reinterpret_cast<char*>(red) + parity * 4096;
+    front<NT>(tab, wb, &D.w[0], G, redP);
+    const int two = !(D.w[8] & UOP_NOP);
+    if (two) front<NT>(tab, wb, &D.w[8], G, redP + 2048);
+    const int mtA = D.w[0] & UOP_MT, mtB = D.w[8] & UOP_MT, dstA = D.w[6], dstB = D.w[14];
+    D = sload16(f.image + 16 * (k + 1));          // the image is padded by one bundle
+    lds_barrier();
+    const double* rd = reinterpret_cast<const double*>(redP);
+    double rA = mtA ? ((rd[lane] + rd[64 + lane]) + (rd[128 + lane] + rd[192 + lane])) : rd[lane];
+    double rB = 1.0;
+    if (two) rB = mtB ? ((rd[256 + lane] + rd[320 + lane]) + (rd[384 + lane] + rd[448 + lane])) : rd[256 + lane];
+    // the same decision in every wave: the inputs are identical
+    if (__builtin_expect(!rescale(rA) || !rescale(rB), 0)) {
+      if (t == 0) f.bail[g] = 2;
+      return;
+    }
+    work[(dstA >> 3) + lane] = rA;
+    if (two) work[(dstB >> 3) + lane] = rB;
+    parity ^= 1;
+  }
+  lds_barrier();
+  PSTAMP          // 5: main loop
+  // ---- read-out (VariableNode.get_marginal, LBP.py:392-400) straight from the scaled messages: the marginal is
+  //      normalised, so the scales cancel; constant part = the variable's constant product ----
+  double marg[2] = {0.0, 0.0};
+  bool bad_out = !dense_ok;
+  if (f.readout && !PROBED(3)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int v = wave + 4 * j;
+      if (v < d.n_vars) {
+        const Words16 rl = sload16(f.readout + 16 * v);
+        double acc = work[rl.w[1] * 64 + lane];
+#pragma unroll
+        for (int q0 = 2; q0 < 16; q0 += 7) {
+          if (rl.w[0] >= q0) {
+            double m[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) m[q] = work[rl.w[q0 + q] * 64 + lane];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) acc *= m[q];
+          }
+        }
+        const unsigned key = wave_max_u32(mag_key(acc));
+        bad_out |= key >= KEY_BAD || key < KEY_MIN;
+        marg[j] = acc / wave_sum(acc);
+      }
+    }
+    for (int v = wave + 8; v < d.n_vars; v += 4) {       // graphs with more than 8 variables: one at a time
+      const Words16 rl = sload16(f.readout + 16 * v);
+      double acc = work[rl.w[1] * 64 + lane];
+      for (int q = 2; q <= rl.w[0]; ++q) acc *= work[as_const(f.readout + 16 * v)[q] * 64 + lane];
+      const unsigned key = wave_max_u32(mag_key(acc));
+      bad_out |= key >= KEY_BAD || key < KEY_MIN;
+      if (!bad_out) d.marginals[((size_t)g * d.n_vars + v) * 64 + lane] = acc / wave_sum(acc);   // (redone by the exact kernel when flagged)
+    }
+  }
+  lds_barrier();        // the normalisation below rewrites slots the read-out above has just read
+  // ---- the deferred normalisations (only when the messages go back to memory): exactly the slots the program wrote,
+  //      wave w takes its WL-entry list, four at a time ----
+  if (f.keep && !PROBED(1)) {
+    for (int j0 = 0; j0 < f.WL; j0 += 4) {
+      const const_i32p wl = as_const(img_written + wave * f.WL + j0);
+      int slot[4];
+      double v[4], s[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { slot[j] = wl[j]; v[j] = slot[j] >= 0 ? work[slot[j] * 64 + lane] : 1.0; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned key = wave_max_u32(mag_key(v[j]));
+        bad_out |= key >= KEY_BAD || key < KEY_MIN;       // a variable product underflowed or vanished
+        s[j] = wave_sum(v[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (slot[j] >= 0) work[slot[j] * 64 + lane] = v[j] / s[j];
+    }
+  }
+  PSTAMP          // 6: read-out + final normalisation
+  if (__syncthreads_or(bad_out ? 1 : 0)) {         // nothing of a flagged graph is written back
+    if (t == 0) f.bail[g] = 3;
+    return;
+  }
+  if (f.keep) {
+    const double2* src = reinterpret_cast<const double2*>(work);
+    double2* dst = reinterpret_cast<double2*>(gm);
+    for (int i = t; i < d.n_msgs * 32 && !PROBED(2); i += WG) dst[i] = src[i];
+  }
+  PSTAMP          // 7: write-back issued
+  if (f.readout && !PROBED(3)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int v = wave + 4 * j;
+      if (v < d.n_vars) d.marginals[((size_t)g * d.n_vars + v) * 64 + lane] = marg[j];
+    }
+  }
+  PSTAMP          // 8: marginals issued
+#ifdef MLBP_LEAN_PROBE
+  PSTAMP_VM       // 9: stores drained
+  PFLUSH
+#endif
+}
+
+int ensure_lds(const void* fn, size_t bytes) {
+  static std::vector<std::pair<const void*, size_t>> granted;
+  for (auto& g : granted)
+    if (g.first == fn && g.second >= bytes) return MLBP_OK;
+  HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  granted.push_back({fn, bytes});
+  return MLBP_OK;
+}
+
+}  // namespace
+
+namespace mlbp {
+
+// FusedProgram -> micro-ops.  Every operand becomes an LDS byte offset (slot * 512); a variable product with more
+// than four sources is split into a chain of variable-only micro-ops that accumulate in its destination slot.
+// Image: bundles [n_bundles][16] | per-wave hoist lists [4][HL][2] | constant-product lists [n_cprod][16] |
+// per-wave written-slot lists [4][WL] | one bundle of padding (the loop prefetches one bundle past the end).
+void build_lean_program(const FusedProgram& fp, int n_msgs, LeanProgram& out) {
+  out = LeanProgram();
+  if (fp.has_unary_fops) { out.why = "in-loop unary updates (not hoistable)"; return; }
+  std::vector<int32_t> U;                            // micro-ops, 8 words each
+  std::vector<char> second;                          // micro-op i is the second member of a bundle
+  auto emit_var = [&](const int32_t* src, int n, int c) {      // work[c] = prod(src[0..n))
+    int done = 0;
+    bool first = true;
+    while (done < n || first) {
+      int32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int k = 0;
+      if (!first) w[1 + k++] = c * 512;
+      while (k < 4 && done < n) w[1 + k++] = src[done++] * 512;
+      w[0] = UOP_VAR | (k << UOP_NSRC_SHIFT);
+      w[5] = c * 512;
+      U.insert(U.end(), w, w + 8);
+      second.push_back(0);
+      first = false;
+    }
+  };
+  const int n_fops = (int)fp.fops.size() / 8;
+  for (int i = 0; i < n_fops; ++i) {
+    const int32_t* w = &fp.fops[8 * (size_t)i];
+    const int kind = w[0] & 0xFF;
+    if (kind == FOP_VAR) { emit_var(&fp.psrcs[w[1]], w[2], w[3]); continue; }
+    // a bundle: pre-chains of both members first (they touch slots disjoint from the partner's), then the members
+    const int members = (w[0] & FOP_BUNDLED) ? 2 : 1;
+    for (int m = 0; m < members; ++m) {
+      const int32_t* q = &fp.fops[8 * (size_t)(i + m)];
+      const int kd = q[0] & 0xFF;
+      if ((kd == FOP_VAR_PAIR_TM || kd == FOP_VAR_PAIR_MT) && q[2] > 4) emit_var(&fp.psrcs[q[1]], q[2], q[3]);
+    }
+    for (int m = 0; m < members; ++m) {
+      const int32_t* q = &fp.fops[8 * (size_t)(i + m)];
+      const int kd = q[0] & 0xFF;
+      int32_t u[8] = {0, 0, 0, 0, 0, -1, 0, 0};
+      if (kd == FOP_PAIR_TM || kd == FOP_PAIR_MT) {
+        u[0] = (kd == FOP_PAIR_MT ? UOP_MT : 0) | (q[1] << UOP_PSLOT_SHIFT) | (1 << UOP_NSRC_SHIFT);
+        u[1] = q[2] * 512;
+        u[6] = q[3] * 512;
+      } else {
+        const bool chained = q[2] > 4;
+        const int n = chained ? 1 : q[2];
+        u[0] = (kd == FOP_VAR_PAIR_MT ? UOP_MT : 0) | (q[4] << UOP_PSLOT_SHIFT) | (n << UOP_NSRC_SHIFT);
+        if (chained) u[1] = q[3] * 512;
+        else for (int k = 0; k < n; ++k) u[1 + k] = fp.psrcs[q[1] + k] * 512;
+        u[5] = chained ? -1 : q[3] * 512;           // the variable->factor message itself (dropped below when dead)
+        u[6] = q[5] * 512;
+      }
+      U.insert(U.end(), u, u + 8);
+      second.push_back(m == 1);
+    }
+    i += members - 1;
+  }
+  const int n_uops = (int)U.size() / 8;
+  // a fused variable->factor message is stored only when something reads the slot before its next write, or when it
+  // is the slot's final value (the messages are an output of the call)
+  for (int i = 0; i < n_uops; ++i) {
+    int32_t* u = &U[8 * (size_t)i];
+    if ((u[0] & UOP_VAR) || u[5] < 0) continue;
+    const int c = u[5];
+    bool needed = true;
+    for (int j = i + 1; j < n_uops; ++j) {
+      const int32_t* v = &U[8 * (size_t)j];
+      const int n = (v[0] >> UOP_NSRC_SHIFT) & 15;
+      bool reads = false;
+      for (int k = 0; k < n; ++k) reads |= v[1 + k] == c;
+      if (reads) break;
+      const bool writes = v[5] == c || (!(v[0] & UOP_VAR) && v[6] == c);
+      if (writes) { needed = false; break; }
+    }
+    if (!needed) u[5] = -1;
+  }
+  std::vector<int32_t>& I = out.image;
+  const int32_t nop[8] = {UOP_NOP, 0, 0, 0, 0, -1, 0, 0};
+  for (int i = 0; i < n_uops; ++i) {
+    I.insert(I.end(), U.begin() + 8 * (size_t)i, U.begin() + 8 * (size_t)i + 8);
+    if (i + 1 < n_uops && second[i + 1]) { ++i; I.insert(I.end(), U.begin() + 8 * (size_t)i, U.begin() + 8 * (size_t)i + 8); }
+    else I.insert(I.end(), nop, nop + 8);
+  }
+  out.n_bundles = (int)I.size() / 16;
+  // per-wave hoist lists: entry h goes to wave h & 3
+  const int n_hoist = (int)fp.hoist.size() / 2;
+  out.HL = std::max(8, ((n_hoist + 3) / 4 + 7) / 8 * 8);
+  {
+    std::vector<int32_t> hl(4 * (size_t)out.HL * 2, -1);
+    for (int h = 0; h < n_hoist; ++h) {
+      hl[((size_t)(h & 3) * out.HL + (h >> 2)) * 2] = fp.hoist[2 * h];
+      hl[((size_t)(h & 3) * out.HL + (h >> 2)) * 2 + 1] = fp.hoist[2 * h + 1];
+    }
+    I.insert(I.end(), hl.begin(), hl.end());
+  }
+  // constant-product lists, 16 words each, padded with the all-ones ext slot
+  out.n_cprod = fp.n_cprod;
+  const int ones = n_msgs + 1 + fp.n_cprod;
+  out.cprods.clear();
+  for (size_t at = 0; at < fp.cpw.size();) {
+    const int cnt = fp.cpw[at];
+    if (cnt > 15) { out.why = "a constant product of more than 15 messages"; out.image.clear(); return; }
+    int32_t l[16];
+    l[0] = cnt;
+    for (int q = 0; q < 15; ++q) l[1 + q] = q < cnt ? fp.cpw[at + 1 + q] : ones;
+    I.insert(I.end(), l, l + 16);
+    out.cprods.push_back(std::vector<int32_t>(fp.cpw.begin() + at + 1, fp.cpw.begin() + at + 1 + cnt));
+    at += 1 + cnt;
+  }
+  out.hoisted.assign(n_msgs, 0);
+  for (int h = 0; h < n_hoist; ++h) out.hoisted[fp.hoist[2 * h + 1]] = 1;
+  // per-wave written-slot lists
+  const int n_written = (int)fp.written.size();
+  out.WL = std::max(4, ((n_written + 3) / 4 + 3) / 4 * 4);
+  {
+    std::vector<int32_t> wl(4 * (size_t)out.WL, -1);
+    for (int i = 0; i < n_written; ++i) wl[(size_t)(i & 3) * out.WL + (i >> 2)] = fp.written[i];
+    I.insert(I.end(), wl.begin(), wl.end());
+  }
+  for (int q = 0; q < 16; ++q) I.push_back(q == 0 || q == 8 ? UOP_NOP : 0);
+  out.ok = true;
+}
+
+// Read-out lists of the lean kernel: per variable 16 words -- count (base included), base slot (the variable's constant
+// product, or the uniform vector), then the varying incoming slots.  False when a variable has more than 15 entries.
+bool build_lean_readout(const LeanProgram& lp, int n_msgs, int n_vars, const int32_t* in_off, const int32_t* in_slots,
+                        std::vector<int32_t>& image) {
+  image.assign(16 * (size_t)n_vars, n_msgs);
+  for (int v = 0; v < n_vars; ++v) {
+    std::vector<int32_t> consts, vars;
+    for (int q = in_off[v]; q < in_off[v + 1]; ++q) (lp.hoisted[in_slots[q]] ? consts : vars).push_back(in_slots[q]);
+    int base = n_msgs;                               // the uniform vector
+    if (!consts.empty()) {
+      size_t k = 0;
+      for (; k < lp.cprods.size(); ++k)
+        if (lp.cprods[k] == consts) break;
+      if (k < lp.cprods.size()) base = n_msgs + 1 + (int)k;
+      else { vars.insert(vars.begin(), consts.begin(), consts.end()); }      // no matching product: multiply them in
+    }
+    if (vars.size() > 14) return false;
+    int32_t* l = &image[16 * (size_t)v];
+    l[0] = 1 + (int)vars.size();
+    l[1] = base;
+    const int ones = n_msgs + 1 + lp.n_cprod;
+    for (int q = 0; q < 14; ++q) l[2 + q] = q < (int)vars.size() ? vars[q] : ones;
+  }
+  return true;
+}
+
+#ifdef MLBP_LEAN_PROBE
+extern "C" int mlbp_debug_lean_probe(int mask, void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_mask), &mask, sizeof(mask)));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_buf), &p, sizeof(p)));
+  return MLBP_OK;
+}
+#endif
+
+int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched) {
+  *launched = false;
+  const LeanProgram& lp = prog->lean;
+  if (!lp.ok || !prog->d_limage || a->X != 64 || !a->normalize_messages || prog->P < 1 || prog->P > 4) return MLBP_OK;
+  if (a->gradient) return MLBP_OK;                // the fused gradient epilogue lives in the older kernels
+  if (a->marginals && !prog->d_lreadout) return MLBP_OK;
+  const int n_ext = 2 + lp.n_cprod;               // uniform, the constant products, ones
+  const size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 256) * sizeof(double) + 16;
+  if (lds > 64 * 1024) return MLBP_OK;            // large graphs: the older kernels' rules apply
+  const bool dense = (a->flags & MLBP_SWEEP_DENSE_TABLES) != 0;
+  if (dense && ((int64_t)a->B * prog->P > a->n_pair_tables || (int64_t)a->B * prog->U > a->n_unary_tables))
+    return fail(MLBP_EINVAL, "mlbp_sweep_f64: MLBP_SWEEP_DENSE_TABLES needs B*P pair tables and B*U unary columns");
+  mlbp_program* mp = const_cast<mlbp_program*>(prog);
+  if (mp->bail_cap < a->B)
+    if (int e = mlbp_program_reserve(mp, a->B)) return e;
+  SweepDev d;
+  d.pair_tables = a->pair_tables; d.pair_tab = a->pair_tab;
+  d.unary_tables = a->unary_tables; d.unary_tab = a->unary_tab;
+  d.msgs = a->msgs;
+  d.ops = nullptr; d.srcs = nullptr; d.sweeps = nullptr; d.pairseq = nullptr;
+  d.status = prog->d_status;
+  d.n_sweeps = prog->n_sweeps; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U; d.X = 64;
+  d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables;
+  d.marginals = a->marginals; d.readout = nullptr; d.n_vars = prog->n_vars;
+  LeanDev f;
+  f.image = prog->d_limage; f.readout = a->marginals ? prog->d_lreadout : nullptr; f.bail = mp->d_bail;
+  f.n_bundles = lp.n_bundles; f.HL = lp.HL; f.n_cprod = lp.n_cprod; f.WL = lp.WL;
+  f.n_ext = n_ext; f.init = a->init_messages; f.dense = dense ? 1 : 0;
+  // the messages go back to memory unless the caller waives them and takes the fused read-out instead
+  f.keep = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && a->marginals) ? 0 : 1;
+  void (*k)(SweepDev, LeanDev) = nullptr;
+  switch (prog->P) {
+    case 1: k = sweep_x64_lean_kernel<1>; break;
+    case 2: k = sweep_x64_lean_kernel<2>; break;
+    case 3: k = sweep_x64_lean_kernel<3>; break;
+    default: k = sweep_x64_lean_kernel<4>; break;
+  }
+  if (int e = ensure_lds((const void*)k, lds)) return e;
+  hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, (hipStream_t)stream, d, f);
+  HIP_TRY(hipGetLastError());
+  *launched = true;
+  return MLBP_OK;
+}
+
+}  // namespace mlbp

@@ -24,8 +24,10 @@
 #include <vector>
 
 #include "mlbp_internal.h"
+#include "mlbp_device.h"
 
 using mlbp::fail;
+using namespace mlbp_dev;
 
 namespace {
 
@@ -36,83 +38,6 @@ constexpr int WG = 256;
     hipError_t _e = (expr);                                                                \
     if (_e != hipSuccess) return fail(MLBP_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
   } while (0)
-
-__device__ __forceinline__ double nan_to_num(double x) {
-  // np.nan_to_num (LBP.py:729): NaN -> 0, +inf -> DBL_MAX, -inf -> -DBL_MAX
-  if (x != x) return 0.0;
-  if (x == __builtin_huge_val()) return DBL_MAX;
-  if (x == -__builtin_huge_val()) return -DBL_MAX;
-  return x;
-}
-
-// 64-bit DPP move: lane l receives the value of the lane selected by CTRL inside its row of 16.
-// 0xB1 = quad_perm[1,0,3,2] (l^1), 0x4E = quad_perm[2,3,0,1] (l^2), 0x1B = quad_perm[3,2,1,0] (3-l),
-// 0x141 = row_half_mirror (7-l within 8), 0x140 = row_mirror (15-l within 16).  VALU speed: no LDS
-// crossbar round trip as with ds_bpermute (__shfl_xor).
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);   // one v_mov_b32_dpp each (update_dpp adds a copy)
-  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double read_lane(double v, int lane) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
-                          __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-
-// Sum over the 64 lanes, the same bits in every lane: four DPP steps give each row of 16 its
-// sum (every pairing adds the same two operands in both partners, so the row agrees bitwise), then
-// the four row sums are combined through scalar registers.
-__device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_mov<0xB1>(v);
-  v += dpp_mov<0x4E>(v);
-  v += dpp_mov<0x141>(v);
-  v += dpp_mov<0x140>(v);
-  return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
-}
-
-// acc * m followed by nan_to_num; the three compares only run when some lane of the wave saw a
-// non-finite product (wave-uniform branch).
-__device__ __forceinline__ double mul_nan_to_num(double m, double acc) {
-  double p = m * acc;
-  if (__builtin_expect(__any(!__builtin_isfinite(p)), 0)) p = nan_to_num(p);
-  return p;
-}
-
-// Message.renormalize (LBP.py:649-657): positive total -> v / total, else uniform.
-__device__ __forceinline__ double renorm(double v, double total, double uniform, bool normalize) {
-  if (!normalize) return v;
-  return total > 0.0 ? v / total : uniform;
-}
-
-// Program data (op headers, source lists, sweep table) is read-only for the whole launch and
-// wave-uniform.  Reading it through the CONSTANT address space lets the compiler use scalar loads
-// (s_load -> SGPRs, lgkmcnt) instead of per-lane vector loads that queue behind the table stream
-// on vmcnt; a plain `const int32_t*` is not enough because the kernel also stores to global memory.
-typedef const int32_t __attribute__((address_space(4))) * const_i32p;
-__device__ __forceinline__ const_i32p as_const(const int32_t* p) {
-  return (const_i32p)(uintptr_t)p;
-}
-
-struct SweepDev {
-  const double* pair_tables;
-  const int32_t* pair_tab;
-  const double* unary_tables;
-  const int32_t* unary_tab;
-  double* msgs;
-  const int32_t* ops;
-  const int32_t* srcs;
-  const int32_t* sweeps;
-  const int32_t* pairseq;
-  int32_t* status;
-  int32_t n_sweeps, n_msgs, P, U, X, n_pair_tables, n_unary_tables;
-  // optional fused read-out of the variable marginals (LBP.py:392-400) from the on-chip messages
-  double* marginals;           // [B][n_vars][X] or NULL
-  const int32_t* readout;      // device: in_off [n_vars+1] then in_slots
-  int32_t n_vars;
-};
 
 // Uniform check of the graph's table indices; an out-of-range index would be an out-of-bounds
 // read, so the whole graph is skipped and the status word raised instead.
@@ -812,17 +737,6 @@ __device__ __forceinline__ void sweep_x64_fused_body(const SweepDev& d, const Fu
 // constant product make the workgroup leave its graph untouched and raise bail[g]; the launcher
 // then runs the exact kernel (sweep_x64_fused_kernel) on the flagged graphs only.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));
-  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true));
-  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true));
-  v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, true));
-  const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
-  const unsigned c = __builtin_amdgcn_readlane((int)v, 32), e = __builtin_amdgcn_readlane((int)v, 48);
-  return max(max(a, b), max(c, e));
-}
-
-
 // One workgroup per graph -- or, as the fix-up pass behind a fast kernel (f.only), one workgroup per 64 graphs that
 // walks their flags and redoes the (normally zero) flagged ones: 128 workgroups instead of 8192 that exit at once.
 template <bool NORM, int NT, bool GRAD>
@@ -842,10 +756,6 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
     if (todo) __syncthreads();
   }
 }
-
-__device__ __forceinline__ unsigned mag_key(double x) { return (unsigned)__double2hiint(x); }
-constexpr unsigned KEY_BAD = 0x7FF00000u;   // and above: negative or non-finite
-constexpr unsigned KEY_MIN = 0x00100000u;   // below: zero or subnormal maximum
 
 struct ScaleFreeDev {
   const int32_t* image;      // as FusedDev::image, followed by the written-slot list
@@ -1816,6 +1726,8 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
   p->n_sreadout = 0;
   mlbp::build_shared_program(fp, n_msgs, P, U, p->shared);
   if (p->shared.ok && e == hipSuccess) e = up(&p->d_simage, p->shared.image.data(), p->shared.image.size());
+  mlbp::build_lean_program(fp, n_msgs, p->lean);
+  if (p->lean.ok && e == hipSuccess) e = up(&p->d_limage, p->lean.image.data(), p->lean.image.size());
   if (e == hipSuccess) e = up(&p->d_fops, image.data(), image.size());
   if (e == hipSuccess) e = up(&p->d_fsweeps, fp.fsweeps.data(), fp.fsweeps.size());
   if (e == hipSuccess) e = up(&p->d_fpairseq, fp.pairseq.data(), fp.pairseq.size());
@@ -1832,7 +1744,7 @@ int mlbp_program_destroy(mlbp_program* p) {
   (void)hipFree(p->d_ops); (void)hipFree(p->d_srcs); (void)hipFree(p->d_sweeps);
   (void)hipFree(p->d_pairseq); (void)hipFree(p->d_status);
   (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq); (void)hipFree(p->d_bail); (void)hipFree(p->d_readout);
-  (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout); (void)hipFree(p->d_tfrag); (void)hipFree(p->d_spill);
+  (void)hipFree(p->d_limage); (void)hipFree(p->d_lreadout); (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout); (void)hipFree(p->d_tfrag); (void)hipFree(p->d_spill);
   delete p;
   return MLBP_OK;
 }
@@ -1869,7 +1781,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     // residency rule: tables stay in registers when the graph has at most 3 (4 for the scale-free
     // kernel, whose smaller working set still fits 3 workgroups per CU) of them
     int nt = (prog->P <= 3) ? prog->P : 0;
-    bool want_sf = norm && prog->sf_ok && prog->P >= 1 && prog->P <= 4 && variant != 3;
+    bool want_sf = norm && prog->sf_ok && prog->P >= 1 && prog->P <= 4 && variant != 3;     // variant 2: as 1 without the lean kernel
     if (variant >= 10 && variant < 20) { nt = (prog->P <= variant - 10) ? variant - 10 : 0; want_sf = false; }
     if (variant >= 20 && variant < 30) { want_sf = want_sf && prog->P <= variant - 20; nt = variant - 20; }
     else if (want_sf) nt = prog->P;
@@ -1892,7 +1804,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
           return fail(MLBP_EINVAL, "mlbp_sweep_f64: gradient arguments do not describe the same batch");
         grad_fused = norm && ga->F_ee == 3 && ga->F_ed == 6 && prog->P >= 1 && prog->P <= 3 && nt == prog->P &&
                      prog->n_hoist == prog->U && ga->phi_en_en_t && ga->phi_en_en_w1_t && ga->phi_en_de_t &&
-                     (variant == 1 || variant == 3 || variant >= 20 || variant == 10 + prog->P);
+                     (variant == 1 || variant == 2 || variant == 3 || variant >= 20 || variant == 10 + prog->P);
         if (grad_fused) {
           gf.pair_c_slot = ga->pair_c_slot; gf.pair_r_slot = ga->pair_r_slot; gf.pair_phi = ga->pair_phi; gf.pair_label = ga->pair_label;
           gf.unary_kind = ga->unary_kind; gf.unary_obs = ga->unary_obs; gf.unary_label = ga->unary_label;
@@ -1902,11 +1814,14 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
         }
       }
       bool shared_done = false;                // shared-table batches: 16 graphs per workgroup on the matrix cores
-      if (variant == 1 || variant == 30)
+      if (variant == 1 || variant == 2 || variant == 30)
         if (int e = mlbp::launch_shared_sweep(prog, a, stream, &shared_done)) return e;
       if (shared_done) { want_sf = false; grad_fused = false; gf = GradFusedDev{}; }
-      g_last_kernel = shared_done ? MLBP_KERNEL_SHARED_MFMA : (want_sf ? MLBP_KERNEL_SCALE_FREE : MLBP_KERNEL_EXACT);
-      if (want_sf) {
+      bool lean_done = false;                  // default scale-free path: the lean kernel (mlbp_lean.hip)
+      if (want_sf && !shared_done && variant == 1)
+        if (int e = mlbp::launch_lean_sweep(prog, a, stream, &lean_done)) return e;
+      g_last_kernel = shared_done ? MLBP_KERNEL_SHARED_MFMA : (lean_done ? MLBP_KERNEL_LEAN : (want_sf ? MLBP_KERNEL_SCALE_FREE : MLBP_KERNEL_EXACT));
+      if (want_sf && !lean_done) {
         if (mp->bail_cap < a->B)              // not reserved for this batch size: allocate now (a stream-
           if (int e = mlbp_program_reserve(mp, a->B)) return e;   // capturing caller reserves up front instead)
         ScaleFreeDev sf;
@@ -1927,7 +1842,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
         HIP_TRY(hipGetLastError());
       }
       FusedDev f;
-      f.only = (want_sf || shared_done) ? mp->d_bail : nullptr;     // after a fast pass: flagged graphs only
+      f.only = (want_sf || shared_done || lean_done) ? mp->d_bail : nullptr;     // after a fast pass: flagged graphs only
       f.image = prog->d_fops; f.fsweeps = prog->d_fsweeps;
       f.n_fops = prog->n_fops; f.n_psrcs = prog->n_psrcs; f.n_hoist = prog->n_hoist;
       f.n_cprod = prog->n_cprod; f.n_cpw = prog->n_cpw; f.n_ext = n_ext;
@@ -2077,6 +1992,13 @@ int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_
   HIP_TRY(hipMemcpy(p->d_readout, img.data(), img.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   p->n_vars = n_vars;
   p->n_readout = (int)img.size();
+  (void)hipFree(p->d_lreadout);
+  p->d_lreadout = nullptr;
+  std::vector<int32_t> limg;
+  if (p->lean.ok && mlbp::build_lean_readout(p->lean, p->n_msgs, n_vars, in_off, in_slots, limg)) {
+    HIP_TRY(hipMalloc(&p->d_lreadout, limg.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(p->d_lreadout, limg.data(), limg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   (void)hipFree(p->d_sreadout);
   p->d_sreadout = nullptr;
   p->n_sreadout = 0;
@@ -2090,7 +2012,7 @@ int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_
 }
 
 int mlbp_set_sweep_variant(int32_t variant) {
-  const bool known = variant == 0 || variant == 1 || variant == 3 || variant == 30 || (variant >= 10 && variant <= 14) || (variant >= 21 && variant <= 24);
+  const bool known = variant == 0 || variant == 1 || variant == 2 || variant == 3 || variant == 30 || (variant >= 10 && variant <= 14) || (variant >= 21 && variant <= 24);
   if (!known) return fail(MLBP_EINVAL, "unknown sweep variant %d", variant);
   g_sweep_variant = variant;
   return MLBP_OK;

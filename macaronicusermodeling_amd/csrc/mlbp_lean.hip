@@ -43,6 +43,7 @@ constexpr int UOP_VAR = 1;          // bit 0: variable product only (stored, no 
 constexpr int UOP_MT = 2;           // bit 1: out = m^T . T (else T . m)
 constexpr int UOP_PSLOT_SHIFT = 2;  // bits 2-4: pair slot (register-resident table)
 constexpr int UOP_NOP = 32;         // bit 5: empty second slot of a bundle
+constexpr int UOP_STORE_VF = 64;    // bit 6: the variable->factor message is stored (word 5)
 constexpr int UOP_NSRC_SHIFT = 8;   // bits 8-11: number of sources (1..4)
 // micro-op words: 0 flags | 1-4 source byte offsets | 5 byte offset of the variable->factor message to store, or -1 |
 // 6 destination byte offset | 7 unused.  A bundle = two micro-ops = 16 words = one s_load_dwordx16.
@@ -112,21 +113,24 @@ __device__ __forceinline__ double2 lds2(const char* p) { return *reinterpret_cas
 __device__ __forceinline__ void mul2(double2& a, const double2 b) { a.x *= b.x; a.y *= b.y; }
 
 // One table (T[r][k] = rows 4R + r, column pair k ^ b3) against one input vector; u = the micro-op's 8 words (scalars).
+// u0 = flags (wave-uniform scalar); s1..s4, vf = source / store byte offsets (same in every lane, kept in VGPRs).
 template <bool MT>
-__device__ __forceinline__ void contract(const double2 (&T)[4][2], char* wb, const int32_t* u, const LaneGeo& G, char* redA) {
-  const int nsrc = (u[0] >> UOP_NSRC_SHIFT) & 15, vf = u[5];
+__device__ __forceinline__ void contract(const double2 (&T)[4][2], char* wb, int u0, int s1, int s2, int s3, int s4, int vf,
+                                         const LaneGeo& G, char* redA) {
+  const int nsrc = (u0 >> UOP_NSRC_SHIFT) & 15;
+  const bool has_vf = (u0 & UOP_STORE_VF) != 0;
   if (MT) {
-    double2 ma = lds2(wb + u[1] + G.mt), mb = lds2(wb + u[1] + G.mt + 16);
+    double2 ma = lds2(wb + s1 + G.mt), mb = lds2(wb + s1 + G.mt + 16);
     if (nsrc > 1) {
-      const double2 a = lds2(wb + u[2] + G.mt), b = lds2(wb + u[2] + G.mt + 16);
+      const double2 a = lds2(wb + s2 + G.mt), b = lds2(wb + s2 + G.mt + 16);
       mul2(ma, a); mul2(mb, b);
       if (nsrc > 2) {
-        const double2 a2 = lds2(wb + u[3] + G.mt), b2 = lds2(wb + u[3] + G.mt + 16);
+        const double2 a2 = lds2(wb + s3 + G.mt), b2 = lds2(wb + s3 + G.mt + 16);
         mul2(ma, a2); mul2(mb, b2);
-        if (nsrc > 3) { const double2 a3 = lds2(wb + u[4] + G.mt), b3 = lds2(wb + u[4] + G.mt + 16); mul2(ma, a3); mul2(mb, b3); }
+        if (nsrc > 3) { const double2 a3 = lds2(wb + s4 + G.mt), b3 = lds2(wb + s4 + G.mt + 16); mul2(ma, a3); mul2(mb, b3); }
       }
     }
-    if (vf >= 0 && G.st_mt) {
+    if (has_vf && G.st_mt) {
       *reinterpret_cast<double2*>(wb + vf + G.mt) = ma;
       *reinterpret_cast<double2*>(wb + vf + G.mt + 16) = mb;
     }
@@ -139,17 +143,17 @@ __device__ __forceinline__ void contract(const double2 (&T)[4][2], char* wb, con
     a01 += dpp_mov<0x128>(a11);
     *reinterpret_cast<double*>(redA + G.red_mt) = swapadd32(a00, a01);
   } else {
-    double2 m0 = lds2(wb + u[1] + G.tm0), m1 = lds2(wb + u[1] + G.tm1);
+    double2 m0 = lds2(wb + s1 + G.tm0), m1 = lds2(wb + s1 + G.tm1);
     if (nsrc > 1) {
-      const double2 a = lds2(wb + u[2] + G.tm0), b = lds2(wb + u[2] + G.tm1);
+      const double2 a = lds2(wb + s2 + G.tm0), b = lds2(wb + s2 + G.tm1);
       mul2(m0, a); mul2(m1, b);
       if (nsrc > 2) {
-        const double2 a2 = lds2(wb + u[3] + G.tm0), b2 = lds2(wb + u[3] + G.tm1);
+        const double2 a2 = lds2(wb + s3 + G.tm0), b2 = lds2(wb + s3 + G.tm1);
         mul2(m0, a2); mul2(m1, b2);
-        if (nsrc > 3) { const double2 a3 = lds2(wb + u[4] + G.tm0), b3 = lds2(wb + u[4] + G.tm1); mul2(m0, a3); mul2(m1, b3); }
+        if (nsrc > 3) { const double2 a3 = lds2(wb + s4 + G.tm0), b3 = lds2(wb + s4 + G.tm1); mul2(m0, a3); mul2(m1, b3); }
       }
     }
-    if (vf >= 0 && G.st_tm) {
+    if (has_vf && G.st_tm) {
       *reinterpret_cast<double2*>(wb + vf + G.tm0) = m0;
       *reinterpret_cast<double2*>(wb + vf + G.tm1) = m1;
     }
@@ -172,28 +176,30 @@ __device__ __forceinline__ void contract(const double2 (&T)[4][2], char* wb, con
 }
 
 template <int NT>
-__device__ __forceinline__ void front(const double2 (&tab)[NT][4][2], char* wb, const int32_t* u, const LaneGeo& G, char* redA) {
-  const int pslot = (u[0] >> UOP_PSLOT_SHIFT) & 7;
+__device__ __forceinline__ void front(const double2 (&tab)[NT][4][2], char* wb, int u0, const int4& lo, const int4& hi, const LaneGeo& G,
+                                      char* redA) {
+  const int pslot = (u0 >> UOP_PSLOT_SHIFT) & 7;
 #pragma unroll
   for (int p = 0; p < NT; ++p) {
     if (p == pslot) {
-      if (u[0] & UOP_MT) contract<true>(tab[p], wb, u, G, redA);
-      else contract<false>(tab[p], wb, u, G, redA);
+      if (u0 & UOP_MT) contract<true>(tab[p], wb, u0, lo.y, lo.z, lo.w, hi.x, hi.y, G, redA);
+      else contract<false>(tab[p], wb, u0, lo.y, lo.z, lo.w, hi.x, hi.y, G, redA);
     }
   }
 }
 
 // The 64 partial results of one update (lane = state), rescaled by an exact power of two so that ONE normal element
-// lands in [1, 2) (the first one; which one is immaterial -- the scale cancels in everything normalised later).  False
-// when the vector cannot be carried this way: a negative / non-finite entry, or no normal entry at all (the
-// zero-sum -> uniform rule of LBP.py:655-657 would act): the graph then goes to the exact kernel.
-__device__ __forceinline__ bool rescale(double& r) {
+// lands in [1, 2) (the first one; which one is immaterial -- the scale cancels in everything normalised later).
+// `bad` is raised when the vector cannot be carried this way: a negative / non-finite entry, or no normal entry at all
+// (the zero-sum -> uniform rule of LBP.py:655-657 would act).  No branch: a bad graph keeps computing (harmlessly) and
+// is handed to the exact kernel when its sweeps are over.
+__device__ __forceinline__ double rescale(double r, int& bad) {
   const unsigned key = mag_key(r);
   const unsigned long long normal = __ballot(key - KEY_MIN < KEY_BAD - KEY_MIN);
-  if (__builtin_expect(__any(key >= KEY_BAD) || normal == 0, 0)) return false;
-  const int ref = __builtin_amdgcn_readlane((int)key, __builtin_ctzll(normal));
-  r = __builtin_ldexp(r, 1023 - (ref >> 20));
-  return true;
+  const unsigned long long wrong = __ballot(key >= KEY_BAD);
+  bad |= (wrong != 0) | (normal == 0);
+  const int ref = __builtin_amdgcn_readlane((int)key, normal ? __builtin_ctzll(normal) : 0);
+  return __builtin_ldexp(r, 1023 - ((ref >> 20) & 0x7FF));
 }
 
 template <int NT>
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : 3)) void sweep_x64_lean_kernel(S
   extern __shared__ double lds[];
   double* work = lds;                                        // [n_msgs + n_ext][64] scaled messages
   double* red = lds + (size_t)(d.n_msgs + f.n_ext) * 64;     // [2 parities][2 bundle slots][4][64]
-  int32_t* lflag = reinterpret_cast<int32_t*>(red + 4 * 256);
+  int32_t* limg = reinterpret_cast<int32_t*>(red + 4 * 256);      // [n_bundles + 1][16] micro-ops
 
   const int g = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -271,6 +277,12 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : 3)) void sweep_x64_lean_kernel(S
   if (f.dense)
     for (int i = t; i < d.P + d.U; i += WG)
       dense_ok &= i < d.P ? d.pair_tab[(size_t)g * d.P + i] == g * d.P + i : d.unary_tab[(size_t)g * d.U + (i - d.P)] == g * d.U + (i - d.P);
+  // the micro-op image, requested behind the tables (it is first read when the sweeps start, i.e. when the tables are
+  // there) and parked in registers until then
+  constexpr int PW = 2;
+  int32_t pre[PW];
+#pragma unroll
+  for (int q = 0; q < PW; ++q) pre[q] = (t + q * WG < 16 * (f.n_bundles + 1)) ? f.image[t + q * WG] : 0;
   unsigned bad_key = 0;
   {
     double2* dst = reinterpret_cast<double2*>(work);
@@ -286,7 +298,6 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : 3)) void sweep_x64_lean_kernel(S
     }
     if (t < 32) dst[d.n_msgs * 32 + t] = make_double2(uniform, uniform);               // ext slot 0: the uniform vector
     if (t >= 32 && t < 64) dst[(d.n_msgs + f.n_ext - 1) * 32 + (t - 32)] = make_double2(1.0, 1.0);   // last ext slot: ones
-    if (t == 0) lflag[0] = 0;
   }
   PSTAMP          // 1: every load issued
   lds_barrier();        // the fill above and the unary messages below write the same slots from different waves
@@ -347,42 +358,50 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : 3)) void sweep_x64_lean_kernel(S
   PSTAMP
 #endif
 
-  // ---- main loop: identical in all four waves; one barrier per bundle; the next bundle's descriptor is fetched
-  //      (scalar load) while this one's partial sums cross the barrier ----
+  // ---- main loop: identical in all four waves; one barrier per bundle.  The micro-ops sit in LDS; a bundle's 16 words
+  //      are read (broadcast) one bundle ahead ----
+#pragma unroll
+  for (int q = 0; q < PW; ++q)
+    if (t + q * WG < 16 * (f.n_bundles + 1)) limg[t + q * WG] = pre[q];
+  for (int i = t + PW * WG; i < 16 * (f.n_bundles + 1); i += WG) limg[i] = f.image[i];
+  lds_barrier();
   char* wb = reinterpret_cast<char*>(work);
-  int parity = 0;
-  Words16 D = sload16(f.image);
+  int parity = 0, bad = 0;
+  const int4* li = reinterpret_cast<const int4*>(limg);
+  int4 A0 = li[0], A1 = li[1], B0 = li[2], B1 = li[3];
   for (int k = 0; k < f.n_bundles && !PROBED(0); ++k) {
-    if (D.w[0] & UOP_VAR) {
+    const int4 nA0 = li[4 * k + 4], nA1 = li[4 * k + 5], nB0 = li[4 * k + 6], nB1 = li[4 * k + 7];     // the image is padded by one bundle
+    const int fA = __builtin_amdgcn_readfirstlane(A0.x), fB = __builtin_amdgcn_readfirstlane(B0.x);
+    if (fA & UOP_VAR) {
       // a lone variable update: the product, lane = state, the same in every wave; no contraction, no barrier
-      const int nsrc = (D.w[0] >> UOP_NSRC_SHIFT) & 15;
-      double m = work[(D.w[1] >> 3) + lane];
-      if (nsrc > 1) m *= work[(D.w[2] >> 3) + lane];
-      if (nsrc > 2) m *= work[(D.w[3] >> 3) + lane];
-      if (nsrc > 3) m *= work[(D.w[4] >> 3) + lane];
-      work[(D.w[5] >> 3) + lane] = m;
-      D = sload16(f.image + 16 * (k + 1));
-      continue;
+      const int nsrc = (fA >> UOP_NSRC_SHIFT) & 15;
+      double m = work[(A0.y >> 3) + lane];
+      if (nsrc > 1) m *= work[(A0.z >> 3) + lane];
+      if (nsrc > 2) m *= work[(A0.w >> 3) + lane];
+      if (nsrc > 3) m *= work[(A1.x >> 3) + lane];
+      work[(A1.y >> 3) + lane] = m;
+    } else {
+      char* redP = reinterpret_cast<char*>(red) + parity * 4096;
+      front<NT>(tab, wb, fA, A0, A1, G, redP);
+      const bool two = !(fB & UOP_NOP);
+      if (two) front<NT>(tab, wb, fB, B0, B1, G, redP + 2048);
+      lds_barrier();
+      const double* rd = reinterpret_cast<const double*>(redP);
+      double rA = rd[lane];
+      if (fA & UOP_MT) rA = (rA + rd[64 + lane]) + (rd[128 + lane] + rd[192 + lane]);
+      work[(A1.z >> 3) + lane] = rescale(rA, bad);
+      if (two) {
+        double rB = rd[256 + lane];
+        if (fB & UOP_MT) rB = (rB + rd[320 + lane]) + (rd[384 + lane] + rd[448 + lane]);
+        work[(B1.z >> 3) + lane] = rescale(rB, bad);
+      }
+      parity ^= 1;
     }
-    char* redP = reinterpret_cast<char*>(red) + parity * 4096;
-    front<NT>(tab, wb, &D.w[0], G, redP);
-    const int two = !(D.w[8] & UOP_NOP);
-    if (two) front<NT>(tab, wb, &D.w[8], G, redP + 2048);
-    const int mtA = D.w[0] & UOP_MT, mtB = D.w[8] & UOP_MT, dstA = D.w[6], dstB = D.w[14];
-    D = sload16(f.image + 16 * (k + 1));          // the image is padded by one bundle
-    lds_barrier();
-    const double* rd = reinterpret_cast<const double*>(redP);
-    double rA = mtA ? ((rd[lane] + rd[64 + lane]) + (rd[128 + lane] + rd[192 + lane])) : rd[lane];
-    double rB = 1.0;
-    if (two) rB = mtB ? ((rd[256 + lane] + rd[320 + lane]) + (rd[384 + lane] + rd[448 + lane])) : rd[256 + lane];
-    // the same decision in every wave: the inputs are identical
-    if (__builtin_expect(!rescale(rA) || !rescale(rB), 0)) {
-      if (t == 0) f.bail[g] = 2;
-      return;
-    }
-    work[(dstA >> 3) + lane] = rA;
-    if (two) work[(dstB >> 3) + lane] = rB;
-    parity ^= 1;
+    A0 = nA0; A1 = nA1; B0 = nB0; B1 = nB1;
+  }
+  if (bad) {                                      // the same in every wave: the inputs were identical
+    if (t == 0) f.bail[g] = 2;
+    return;
   }
   lds_barrier();
   PSTAMP          // 5: main loop
@@ -557,6 +576,11 @@ void build_lean_program(const FusedProgram& fp, int n_msgs, LeanProgram& out) {
     }
     if (!needed) u[5] = -1;
   }
+  for (int i = 0; i < n_uops; ++i) {
+    int32_t* u = &U[8 * (size_t)i];
+    if (!(u[0] & UOP_VAR) && u[5] >= 0) u[0] |= UOP_STORE_VF;
+    if (u[5] < 0) u[5] = 0;
+  }
   std::vector<int32_t>& I = out.image;
   const int32_t nop[8] = {UOP_NOP, 0, 0, 0, 0, -1, 0, 0};
   for (int i = 0; i < n_uops; ++i) {
@@ -646,7 +670,7 @@ int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* 
   if (a->gradient) return MLBP_OK;                // the fused gradient epilogue lives in the older kernels
   if (a->marginals && !prog->d_lreadout) return MLBP_OK;
   const int n_ext = 2 + lp.n_cprod;               // uniform, the constant products, ones
-  const size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 256) * sizeof(double) + 16;
+  const size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 256) * sizeof(double) + 16 * (size_t)(lp.n_bundles + 1) * sizeof(int32_t);
   if (lds > 64 * 1024) return MLBP_OK;            // large graphs: the older kernels' rules apply
   const bool dense = (a->flags & MLBP_SWEEP_DENSE_TABLES) != 0;
   if (dense && ((int64_t)a->B * prog->P > a->n_pair_tables || (int64_t)a->B * prog->U > a->n_unary_tables))

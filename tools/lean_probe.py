@@ -30,14 +30,14 @@ from macaronicusermodeling_amd.topology import GraphTopology  # noqa: E402
 
 workload = sys.argv[1] if len(sys.argv) > 1 else 'user_k3'
 spec, roots, sweeps, seed = bench.workload_spec(workload)
-X, B = spec['X'], 8192
+X, B = spec['X'], int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 topo = GraphTopology.from_spec(spec)
 dev = torch.device('cuda:0')
 fb = FactorGraphBatch(topo, X, B, device=dev)
 fb.set_pair_tables(torch.rand(B * topo.P, X, X, dtype=torch.float64, device=dev) + 0.01)
 fb.set_unary_tables(torch.rand(B * topo.U, X, dtype=torch.float64, device=dev) + 0.01)
 marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)
-buf = torch.zeros(1024 * 12, dtype=torch.int64, device=dev)
+buf = torch.zeros((B // 64 + 1) * 12, dtype=torch.int64, device=dev)
 masks = [(0, 'full kernel'), (1, '- main loop'), (2, '- final normalisation'), (4, '- message write-back'), (8, '- marginals'),
          (16, '- table loads'), (32, '- unary loads'), (1 | 2, '- loop, final norm'), (1 | 2 | 4 | 8, '- everything but the loads and the prologue'),
          (1 | 2 | 4 | 8 | 32, '- all but table loads + prologue'), (63, '- all of the above')]
@@ -61,8 +61,10 @@ for _ in range(3):
 torch.cuda.synchronize()
 raw = buf.cpu().numpy().reshape(-1, 12).astype(np.float64)
 raw = raw[raw[:, 0] > 0]
-names = ['cold start: first graph loads issue', 'first prologue', 'first main loop', 'first tail (next tables in flight)', 'second prologue', 'second main loop', 'second tail', 'third prologue', 'third main loop']
+names = ['issue loads (unary rows, tables, image), init LDS', 'unary normalisation + sync', 'constant products + sync', 'wait for tables',
+         'main loop', 'read-out + final normalisation', 'sync + write-back issue', 'marginals issue', 'drain stores']
 d = np.diff(raw[:, :10], axis=1)
-print('%d sampled workgroups (persistent: each walks ~%.1f graphs)' % (len(raw), B / 768.0))
+life = raw[:, 9] - raw[:, 0]
+print('B = %d: wave-0 lifetime: mean %.0f cycles (min %.0f, max %.0f) over %d sampled workgroups' % (B, life.mean(), life.min(), life.max(), len(life)))
 for i, n in enumerate(names):
-    print('  %-40s %8.0f cycles' % (n, d[:, i].mean()))
+    print('  %-50s %8.0f cycles  %5.1f %%' % (n, d[:, i].mean(), 100 * d[:, i].mean() / life.mean()))

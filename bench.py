@@ -53,8 +53,9 @@ KERNEL_NAMES = {0: 'sweep_x64_kernel (first generation)',
                 3: 'sweep_x64_shared_kernel (v_mfma_f64_16x16x4_f64; timed region also holds the flag memset and the fix-up pass)',
                 4: 'sweep_wide_kernel', 5: 'sweep_generic_kernel',
                 7: 'sweep_x64_lean_kernel (scale-free, micro-op form) + the ~5 us fix-up pass of sweep_x64_fused_kernel, timed together',
-                6: 'shared-table contraction over the whole batch + renormalise / variable-update kernels (mlbp_gemm.hip)'}
+                6: 'contract_kernel (mlbp_gemm.hip): one hand-written MFMA launch per factor->variable update over the whole batch, variable product and renormalisation fused (f64: v_mfma_f64_16x16x4_f64; f32 tables: v_mfma_f32_16x16x4_f32)'}
 HBM_PEAK_GBS = 8000.0           # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32-input MFMA = the f32 vector rate (155 TF measured)
 F64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix spec (= FP64 vector; 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz); the guide's
                                 # MFMA table has no f64 row
 
@@ -69,7 +70,7 @@ def workload_spec(name):
         return C.chain_spec(8, 64), [0] * 10, 10, 1235
     if name == 'ring8':
         return C.ring_spec(8, 64), [0] * 10, 10, 1235
-    if name in ('ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared'):
+    if name in ('ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared', 'ring8_x512_shared_f32'):
         return C.ring_spec(8, 512), [0] * 10, 10, 1238
     raise SystemExit('unknown workload %s' % name)
 
@@ -240,7 +241,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'user_k4', 'user_k4_shared', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared'],
+    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'user_k4', 'user_k4_shared', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared', 'ring8_x512_shared_f32'],
                     help='user_k3_shared = the same graphs with the reference\'s table layout: all graphs share the two '
                          'en_en pots (MFMA kernel, reported against the f64 matrix peak)')
     ap.add_argument('--no-writeback', action='store_true', help='shared workload: skip the message write-back (read-out only)')
@@ -294,11 +295,11 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed + 7919 * rank)
     fb = FactorGraphBatch(topo, X, B, device=dev)
-    shared = a.workload.endswith('_shared')
+    shared = '_shared' in a.workload
     unary = torch.rand(B * topo.U, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
     if shared and spec['style'] == 'explicit':      # one table per factor, the same for every graph (X = 512: batched DGEMMs)
         pair = torch.rand(topo.P, X, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
-        fb.set_pair_tables(pair, np.tile(np.arange(topo.P), (B, 1)))
+        fb.set_pair_tables(pair, np.tile(np.arange(topo.P), (B, 1)), dtype=torch.float32 if a.workload.endswith('_f32') else torch.float64)
     elif shared:    # LBP.py:456-467: pot_en_en behind the gap > 1 factors, pot_en_en_w1 behind the gap == 1 ones
         pair = torch.rand(2, X, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
         by_id = {f['id']: f for f in spec['factors']}
@@ -418,8 +419,9 @@ def main():
             n_pair = sum(int(np.isin(topo.compile_sweep(r)[0][:, 0], (_ffi.OP_PAIR_TM, _ffi.OP_PAIR_MT)).sum()) for r in roots)
             alg_flops = 2.0 * X * X * n_pair * B
             tfl = alg_flops / (avg_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'achieved': tfl, 'peak': F64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': tfl / F64_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+            peak = F32_MFMA_PEAK_TFLOPS if a.workload.endswith('_f32') else F64_MFMA_PEAK_TFLOPS
+            roof = {'bound': 'mfma', 'achieved': tfl, 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': tfl / peak, 'traffic': traffic, 'traffic_source': traffic_src,
                     'kernel': KERNEL_NAMES.get(last, str(last)), 'algorithmic_flops_per_launch': alg_flops,
                     'hbm_GBps_on_compulsory_bytes': achieved, 'compulsory_bytes': comp}
         else:

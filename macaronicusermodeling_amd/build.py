@@ -37,7 +37,7 @@ def build(force=False, verbose=False):
             subprocess.check_call(cmd)
         objs.append(obj)
     if force or _stale(LIB, objs):
-        subprocess.check_call([hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', LIB] + objs + ['-ldl'])
+        subprocess.check_call([hipcc, '-shared', '-fPIC', '--offload-arch=gfx950', '-o', LIB] + objs)
     return LIB
 
 

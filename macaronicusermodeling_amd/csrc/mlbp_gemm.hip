@@ -1,23 +1,32 @@
-// Shared pairwise tables at large state spaces (X >= 128): update by update over the whole batch.
+// Shared pairwise tables at large state spaces (X = 128 .. 512): every factor->variable update of the WHOLE batch is
+// one dense contraction on the matrix cores, written here (no library call).
 //
-// With one table behind factor p for every graph (the reference's layout, LBP.py:456-467; X = |V_en| there) the
-// factor->variable update of ALL B graphs is one plain dense product
-//     OUT[X x B] = T[X x X] . M[X x B]        (or T^T . M)
-// -- SURVEY.md section 8(d)'s "shared-table (GEMM/MFMA) variant" of config 5.  At X = 64 the whole sweep fits one
-// workgroup per 16 graphs (mlbp_shared.hip); at X = 512 a table is 2 MiB and a message tile of 16 graphs 64 KiB,
-// so the sweep is run op by op instead: the contraction is a library DGEMM straight on the strided message
-// buffer (rocBLAS; column-major views of msgs[:, slot, :] with leading dimension n_msgs * X, no copies), the rest
-// -- Message.renormalize, the variable->factor products with nan_to_num, the unary messages -- are the small
-// kernels below.  Same updates in the same order as every other path; only the summation order inside the
-// contraction differs.
+// With one table behind factor p for every graph (the reference's layout, LBP.py:456-467; X = |V_en| there) the update
+// of all B graphs is      OUT[X x B] = T[X x X] . M[X x B]      (or T^T . M)
+// -- SURVEY.md section 8(d)'s "shared-table (GEMM/MFMA) variant" of BASELINE config 5.  At X = 64 the whole sweep
+// fits one workgroup per 16 graphs (mlbp_shared.hip); at X = 512 a table is 2 MiB, so the sweep runs update by update
+// over the batch, ONE launch of contract_kernel per update:
 //
-// rocBLAS is bound at first use with dlopen (no link-time dependency: the library and every other path work
-// without it; this path then returns MLBP_EUNSUPPORTED).
+//   prologue   the input message of N_T = 16 or 32 graphs is formed and parked in LDS: either a stored slot, or --
+//              fused -- the variable->factor product of VariableNode.update_message_to (LBP.py:377-389: uniform x the
+//              listed incoming messages, nan_to_num after each product, renormalised), which is also stored;
+//   main loop  v_mfma_f64_16x16x4_f64: wave w owns the row tiles w, w+4, ...; its A fragments (table rows) come straight
+//              from L2 as one coalesced 16-byte load per lane and two k-steps, out of a copy of the table laid out in
+//              fragment order once per call (table_frag_kernel), with a register double buffer; the B fragments
+//              (messages) are 8-byte LDS reads out of a [graph][state + 2] image (conflict-free);
+//   epilogue   the accumulators go back through the same LDS image transposed, so that Message.renormalize
+//              (LBP.py:649-657) sees whole columns and the result leaves in full 512-byte rows.
+//
+// float32 tables (MLBP_SWEEP_PAIR_TABLES_F32, the "batched f32 MFMA message contraction" of config 5): the same
+// structure on v_mfma_f32_16x16x4_f32 -- table and message fragments in float32, products summed in float32 over 64
+// states at a time, the 64-state partial sums added into float64 accumulators (tolerance study: DESIGN.md 4.2b).
+//
+// Same updates in the same order as every other path (the fused program of build_fused_program); only the summation
+// order inside a contraction differs.
 #include <hip/hip_runtime.h>
 
-#include <dlfcn.h>
-
 #include <cfloat>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -28,43 +37,6 @@ namespace {
 
 constexpr int WG = 256;
 
-// ---- the four rocBLAS entry points this path needs (ABI as in rocblas/internal/rocblas-functions.h) ----
-typedef void* rb_handle;
-typedef int (*rb_create_t)(rb_handle*);
-typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
-typedef int (*rb_dgemm_t)(rb_handle, int, int, int, int, int, const double*, const double*, int, const double*, int,
-                          const double*, double*, int);
-constexpr int RB_OP_NONE = 111, RB_OP_TRANSPOSE = 112;      // rocblas_operation_none / _transpose
-
-struct RocBlas {
-  rb_create_t create = nullptr;
-  rb_set_stream_t set_stream = nullptr;
-  rb_dgemm_t dgemm = nullptr;
-  rb_handle handle = nullptr;
-  bool tried = false, ok = false;
-};
-RocBlas g_rb;
-std::mutex g_rb_mutex;
-
-int rocblas_ready() {
-  std::lock_guard<std::mutex> lock(g_rb_mutex);
-  if (!g_rb.tried) {
-    g_rb.tried = true;
-    void* h = nullptr;
-    for (const char* name : {"librocblas.so", "librocblas.so.5", "librocblas.so.4"}) {
-      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (h) break;
-    }
-    if (h) {
-      g_rb.create = (rb_create_t)dlsym(h, "rocblas_create_handle");
-      g_rb.set_stream = (rb_set_stream_t)dlsym(h, "rocblas_set_stream");
-      g_rb.dgemm = (rb_dgemm_t)dlsym(h, "rocblas_dgemm");
-      g_rb.ok = g_rb.create && g_rb.set_stream && g_rb.dgemm && g_rb.create(&g_rb.handle) == 0;
-    }
-  }
-  return g_rb.ok ? MLBP_OK : fail(MLBP_EUNSUPPORTED, "shared-table GEMM path: rocBLAS could not be loaded");
-}
-
 __device__ __forceinline__ double nan_to_num(double x) {
   if (x != x) return 0.0;
   if (x == __builtin_huge_val()) return DBL_MAX;
@@ -72,29 +44,331 @@ __device__ __forceinline__ double nan_to_num(double x) {
   return x;
 }
 
-__device__ __forceinline__ double block_sum(double v, double* scratch /*[4]*/) {
+__device__ __forceinline__ double wave_sum64(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ double block_sum(double v, double* scratch /*[4]*/) {
+  v = wave_sum64(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
   __syncthreads();
   return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
 }
 
-// Message.renormalize (LBP.py:649-657) of slot `c` of every graph, in place: total > 0 -> v / total, else uniform.
-__global__ __launch_bounds__(WG) void renormalize_slot_kernel(double* msgs, int n_msgs, int X, int c) {
-  __shared__ double scratch[4];
-  double* m = msgs + ((size_t)blockIdx.x * n_msgs + c) * X;
-  double part = 0.0;
-  for (int j = threadIdx.x; j < X; j += WG) part += m[j];
-  const double total = block_sum(part, scratch);
-  const double uniform = 1.0 / (double)X;
-  for (int j = threadIdx.x; j < X; j += WG) m[j] = total > 0.0 ? m[j] / total : uniform;
+// ---- the table in fragment order ----------------------------------------------------------------------------------
+// A operand of the contraction: Aop[i][k] = T[i][k] (out = T . m) or T[k][i] (out = m^T . T), optionally times a feature
+// plane (the gradient's T (.) phi_k).  MFMA 16x16x4 lane map: lane l holds A[i = l & 15][k = l >> 4].
+//   float64: frag[rt][kp][l][e]  = Aop[16 rt + (l & 15)][8 kp + 4 e + (l >> 4)],  e = 0, 1      (one double2 per lane)
+//   float32: frag[rt][kq][l][e]  = Aop[16 rt + (l & 15)][16 kq + 4 e + (l >> 4)], e = 0 .. 3    (one float4 per lane)
+template <typename TT, int E>
+__global__ void table_frag_kernel(const TT* T, const double* plane, int X, int transpose, TT* frag) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // one output element
+  if (idx >= (size_t)X * X) return;
+  const int e = idx % E, l = (idx / E) % 64;
+  const size_t blk = idx / (E * 64);
+  const int KB = X / (4 * E);
+  const int kb = blk % KB, rt = blk / KB;
+  const int i = 16 * rt + (l & 15), k = 4 * E * kb + 4 * e + (l >> 4);
+  const size_t at = transpose ? (size_t)k * X + i : (size_t)i * X + k;
+  double v = (double)T[at];
+  if (plane) v *= plane[at];
+  frag[idx] = (TT)v;
 }
 
-// VariableNode.update_message_to (LBP.py:377-389): uniform times the listed incoming messages, nan_to_num after
-// each product, renormalised when asked.
-__global__ __launch_bounds__(WG) void variable_update_kernel(double* msgs, int n_msgs, int X, const int32_t* srcs, int a, int b,
-                                                            int c, int normalize) {
+struct ContractDev {
+  const void* frag;          // the table in fragment order (table_frag_kernel)
+  const double* in;          // source messages: (b, slot, x) at in[b * in_ld + slot * X + x]
+  double* out;               // results:         (b, slot, x) at out[b * out_ld + slot * X + x]
+  int32_t src[8];            // source slots of the fused variable product, reference order (n_src <= 8)
+  size_t in_ld, out_ld;
+  int32_t n_src;             // 0: the input is slot in_slot as it stands
+  int32_t in_slot, vf_slot, dst_slot;      // vf_slot: where the variable->factor message itself is stored, or -1
+  int32_t B, normalize;
+};
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+template <typename TT> struct Frag;
+template <> struct Frag<double> {
+  typedef double2 vec;                      // two k-steps per 16-byte load
+  static constexpr int KSTEPS = 2;
+  typedef double lds_t;
+};
+template <> struct Frag<float> {
+  typedef float4 vec;                       // four k-steps per 16-byte load
+  static constexpr int KSTEPS = 4;
+  typedef float lds_t;
+};
+
+// X = 64 * RT states; N_T = 16 * NCT graphs per workgroup.
+template <typename TT, int RT, int NCT, int DEPTH>
+__global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
+  constexpr int X = 64 * RT, NT_G = 16 * NCT, XP = X + 2;
+  constexpr int KS = Frag<TT>::KSTEPS, KB = X / (4 * KS);       // 16-byte fragment blocks along k
+  typedef typename Frag<TT>::vec avec;
+  typedef typename Frag<TT>::lds_t mt_t;
+  extern __shared__ double lds_raw[];
+  mt_t* Mt = reinterpret_cast<mt_t*>(lds_raw);                   // [NT_G][XP] input messages (later: the results, float64)
+  double* Ot = lds_raw;                                          // [NT_G][XP] float64 view for the epilogue
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b0 = blockIdx.x * NT_G;
+  const double uniform = 1.0 / (double)X;
+
+  // ---- prologue: the input messages of this workgroup's graphs -> LDS.  A wave takes NT_G / 4 consecutive graphs, four
+  //      at a time, so that one round of memory latency covers four graphs; lane l holds states 2l, 2l+1 (+128 j) ----
+  constexpr int GPW = NT_G / 4, H = RT / 2 + (RT & 1);        // graphs per wave; double2 pieces per lane (odd RT: last half-used)
+  static_assert(RT % 2 == 0, "X must be a multiple of 128 here");
+  for (int g4 = 0; g4 < GPW; g4 += 4) {
+    double2 v[4][H];
+    const double* gin[4];
+    bool live[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + wave * GPW + g4 + u;
+      live[u] = b < d.B;
+      gin[u] = d.in + (size_t)(live[u] ? b : 0) * d.in_ld;
+    }
+    if (d.n_src == 0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < H; ++j) v[u][j] = reinterpret_cast<const double2*>(gin[u] + (size_t)d.in_slot * X)[lane + 64 * j];
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < H; ++j) v[u][j] = make_double2(uniform, uniform);
+      for (int q = 0; q < d.n_src; ++q) {
+        const size_t so = (size_t)d.src[q] * X;
+        double2 m[4][H];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < H; ++j) m[u][j] = reinterpret_cast<const double2*>(gin[u] + so)[lane + 64 * j];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < H; ++j) {
+            double px = m[u][j].x * v[u][j].x, py = m[u][j].y * v[u][j].y;
+            if (__builtin_expect(__any(!__builtin_isfinite(px) || !__builtin_isfinite(py)), 0)) { px = nan_to_num(px); py = nan_to_num(py); }
+            v[u][j] = make_double2(px, py);
+          }
+      }
+      if (d.normalize) {
+        double tot[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          double part = 0.0;
+#pragma unroll
+          for (int j = 0; j < H; ++j) part += v[u][j].x + v[u][j].y;
+          tot[u] = wave_sum64(part);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < H; ++j)
+            v[u][j] = tot[u] > 0.0 ? make_double2(v[u][j].x / tot[u], v[u][j].y / tot[u]) : make_double2(uniform, uniform);
+      }
+      if (d.vf_slot >= 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (live[u]) {
+            double2* o = reinterpret_cast<double2*>(d.out + (size_t)(b0 + wave * GPW + g4 + u) * d.out_ld + (size_t)d.vf_slot * X);
+#pragma unroll
+            for (int j = 0; j < H; ++j) o[lane + 64 * j] = v[u][j];
+          }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      mt_t* row = Mt + (wave * GPW + g4 + u) * XP;
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        row[2 * lane + 128 * j] = live[u] ? (mt_t)v[u][j].x : (mt_t)0;
+        row[2 * lane + 128 * j + 1] = live[u] ? (mt_t)v[u][j].y : (mt_t)0;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- main loop ----
+  const avec* Af = reinterpret_cast<const avec*>(d.frag);
+  const int gcol = lane & 15, krow = lane >> 4;
+  double4_t acc[RT][NCT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[r][c] = double4_t{0.0, 0.0, 0.0, 0.0};
+  // DEPTH register sets of A fragments in rotation, each requested DEPTH / 2 whole steps before it is used (the loop is
+  // unrolled by DEPTH so that no set is ever copied)
+  constexpr int DIST = DEPTH / 2;
+#ifdef MLBP_CONTRACT_NOLOOP          // diagnostic build (tools/contract_probe.py): prologue + epilogue only
+  constexpr int KB_RUN = 4;
+#else
+  constexpr int KB_RUN = KB;
+#endif
+  avec a[DEPTH][RT];
+  auto load_a = [&](avec (&dst)[RT], int kb) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r) dst[r] = Af[((size_t)(wave + 4 * r) * KB + kb) * 64 + lane];
+  };
+#pragma unroll
+  for (int s0 = 0; s0 < DIST; ++s0) load_a(a[s0], s0);
+  static_assert(KB % 4 == 0 && (DEPTH == 2 || DEPTH == 4), "");
+  if constexpr (sizeof(TT) == 8) {
+    auto step = [&](const avec (&af)[RT], int kb) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        double bf[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) bf[c] = Mt[(16 * c + gcol) * XP + 8 * kb + 4 * e + krow];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int c = 0; c < NCT; ++c)
+            acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(e ? af[r].y : af[r].x, bf[c], acc[r][c], 0, 0, 0);
+      }
+    };
+#pragma unroll 1
+    for (int kb = 0; kb < KB_RUN; kb += DEPTH) {
+#pragma unroll
+      for (int s0 = 0; s0 < DEPTH; ++s0) {
+        if (kb + s0 + DIST < KB) load_a(a[(s0 + DIST) % DEPTH], kb + s0 + DIST);
+        step(a[s0], kb + s0);
+      }
+    }
+  } else {
+    // float32 products, summed in float32 over 64 states (4 fragment blocks) at a time, then added in float64
+    float4_t part[RT][NCT];
+    auto step = [&](const avec (&af4)[RT], int kb) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float bf[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) bf[c] = Mt[(16 * c + gcol) * XP + 16 * kb + 4 * e + krow];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+          const float af = e == 0 ? af4[r].x : (e == 1 ? af4[r].y : (e == 2 ? af4[r].z : af4[r].w));
+#pragma unroll
+          for (int c = 0; c < NCT; ++c) part[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[c], part[r][c], 0, 0, 0);
+        }
+      }
+    };
+#pragma unroll 1
+    for (int kb = 0; kb < KB_RUN; kb += 4) {
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) part[r][c] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s0 = 0; s0 < 4; ++s0) {
+        if (kb + s0 + DIST < KB) load_a(a[(s0 + DIST) % DEPTH], kb + s0 + DIST);
+        step(a[s0 % DEPTH], kb + s0);
+      }
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[r][c][i] += (double)part[r][c][i];
+    }
+  }
+  __syncthreads();                       // every wave has read its last message fragment: the image becomes the output
+  // ---- epilogue: accumulators -> LDS transposed ([graph][state], float64), renormalise, store whole rows ----
+  // result element (row, col) of a 16 x 16 tile: col = lane & 15 (graph); float64 MFMA: row = (lane >> 4) + 4 i;
+  // float32 MFMA: row = 4 (lane >> 4) + i
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = sizeof(TT) == 8 ? krow + 4 * i : 4 * krow + i;
+        Ot[(16 * c + gcol) * XP + 16 * (wave + 4 * r) + row] = acc[r][c][i];
+      }
+  __syncthreads();
+  for (int g4 = 0; g4 < GPW; g4 += 4) {
+    double2 v[4][H];
+    double tot[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double* row = Ot + (wave * GPW + g4 + u) * XP;
+      double part = 0.0;
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        v[u][j] = make_double2(row[2 * lane + 128 * j], row[2 * lane + 128 * j + 1]);
+        part += v[u][j].x + v[u][j].y;
+      }
+      tot[u] = d.normalize ? wave_sum64(part) : 1.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int b = b0 + wave * GPW + g4 + u;
+      if (b < d.B) {
+        double2* o = reinterpret_cast<double2*>(d.out + (size_t)b * d.out_ld + (size_t)d.dst_slot * X);
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+          if (!d.normalize) o[lane + 64 * j] = v[u][j];
+          else o[lane + 64 * j] = tot[u] > 0.0 ? make_double2(v[u][j].x / tot[u], v[u][j].y / tot[u]) : make_double2(uniform, uniform);
+        }
+      }
+    }
+  }
+}
+
+template <typename TT>
+size_t contract_lds_bytes(int X, int nct) {
+  // the float32 image is reused as the float64 output image
+  (void)sizeof(TT);
+  return (size_t)16 * nct * (X + 2) * sizeof(double);
+}
+
+template <typename TT, int RT>
+int launch_contract_rt(const ContractDev& d, int nct, hipStream_t st) {
+  const int X = 64 * RT;
+  const int ntg = 16 * nct;
+  const size_t lds = contract_lds_bytes<TT>(X, nct);
+  // 32 graphs per workgroup: one workgroup per CU, deep fragment prefetch; 16: two per CU hide each other's stalls
+  void (*k)(ContractDev) = nct == 2 ? contract_kernel<TT, RT, 2, 4> : (sizeof(TT) == 8 ? contract_kernel<TT, RT, 1, 2> : contract_kernel<TT, RT, 1, 4>);
+  static std::mutex mu;
+  static std::vector<const void*> granted;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    bool have = false;
+    for (const void* g : granted) have |= g == (const void*)k;
+    if (!have) {
+      if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)) != hipSuccess)
+        return fail(MLBP_EHIP, "contract_kernel: cannot raise the dynamic LDS limit");
+      granted.push_back((const void*)k);
+    }
+  }
+  hipLaunchKernelGGL(k, dim3((d.B + ntg - 1) / ntg), dim3(WG), lds, st, d);
+  return MLBP_OK;
+}
+
+// graphs per workgroup: 32 when the batch still fills the chip twice over and the accumulators fit, else 16
+template <typename TT>
+int launch_contract(const ContractDev& d, int X, hipStream_t st) {
+  const bool f32 = sizeof(TT) == 4;
+  int nct = (!f32 && X <= 256 && d.B >= 32 * 512) ? 2 : 1;     // small tables: fewer passes over the table per graph
+  if (const char* e = getenv("MLBP_CONTRACT_NCT")) nct = atoi(e) == 2 && !f32 ? 2 : 1;       // A/B measurements
+  switch (X) {
+    case 128: return launch_contract_rt<TT, 2>(d, nct, st);
+    case 256: return launch_contract_rt<TT, 4>(d, nct, st);
+    case 384: return launch_contract_rt<TT, 6>(d, nct, st);
+    case 512: return launch_contract_rt<TT, 8>(d, nct, st);
+  }
+  return fail(MLBP_EUNSUPPORTED, "shared-table contraction: X = %d (128, 256, 384 or 512)", X);
+}
+
+// ---- the small kernels around the contraction --------------------------------------------------------------------
+// VariableNode.update_message_to (LBP.py:377-389) when it does NOT feed the next contraction: uniform times the listed
+// incoming messages, nan_to_num after each product, renormalised when asked.
+__global__ __launch_bounds__(WG) void variable_update_kernel(double* msgs, int n_msgs, int X, const int32_t* srcs, int b, int c,
+                                                            int normalize) {
   __shared__ double scratch[4];
   extern __shared__ double raw[];
   double* gm = msgs + (size_t)blockIdx.x * n_msgs * X;
@@ -102,7 +376,7 @@ __global__ __launch_bounds__(WG) void variable_update_kernel(double* msgs, int n
   double part = 0.0;
   for (int j = threadIdx.x; j < X; j += WG) {
     double acc = uniform;
-    for (int q = 0; q < b; ++q) acc = nan_to_num(gm[(size_t)srcs[a + q] * X + j] * acc);
+    for (int q = 0; q < b; ++q) acc = nan_to_num(gm[(size_t)srcs[q] * X + j] * acc);
     raw[j] = acc;
     part += acc;
   }
@@ -146,13 +420,8 @@ __global__ void check_shared_claim_kernel(const int32_t* pair_tab, int B, int P,
   if (pair_tab[i] != want || (unsigned)want >= (unsigned)n_pair_tables) atomicExch(status, 2);
 }
 
-// ---- pairwise part of the gradient (LBP.py:528-619, 301-320) as DGEMMs ----
-// W = T (.) phi_k (k = 0..2) or T (k = 3), row-major like T
-__global__ void weight_table_kernel(const double* T, const double* phi_plane, int n, double* W) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) W[i] = phi_plane ? T[i] * phi_plane[i] : T[i];
-}
-// S[k][b] = sum_i c[b][i] * Y[i][b]   (Y column-major X x B: Y[b * X + i])
+// ---- pairwise part of the gradient (LBP.py:528-619, 301-320) ----
+// S[b] = sum_i c[b][i] * Y[b][i]
 __global__ __launch_bounds__(WG) void row_dot_kernel(const double* msgs, int n_msgs, int X, int c_slot, const double* Y, double* S) {
   __shared__ double scratch[4];
   const double* c = msgs + ((size_t)blockIdx.x * n_msgs + c_slot) * X;
@@ -174,108 +443,166 @@ __global__ void pair_gradient_combine_kernel(const double* S /*[4][B]*/, int B, 
     grad_en_en[(size_t)b * 3 + k] += phi[((size_t)l0 * X + l1) * 3 + k] - (Z > 0.0 ? S[k * (size_t)B + b] / Z : 0.0);
 }
 
+// One device-wide scratch buffer per purpose, grown on demand (launches on different streams must not overlap; a
+// stream-capturing caller runs one eager step first so that nothing is allocated under capture).
+std::mutex g_scratch_mutex;
+int ensure_scratch(void** p, size_t* cap, size_t need) {
+  if (need <= *cap) return MLBP_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  if (hipMalloc(p, need) != hipSuccess) return fail(MLBP_EHIP, "shared-table contraction: scratch allocation of %zu bytes failed", need);
+  *cap = need;
+  return MLBP_OK;
+}
+
+template <typename TT>
+void launch_table_frag(const TT* T, const double* plane, int X, int transpose, TT* frag, hipStream_t st) {
+  constexpr int E = sizeof(TT) == 8 ? 2 : 4;
+  hipLaunchKernelGGL((table_frag_kernel<TT, E>), dim3((X * X + 255) / 256), dim3(256), 0, st, T, plane, X, transpose, frag);
+}
+
+bool contract_supports(int X) { return X >= 128 && X <= 512 && X % 128 == 0; }
+
 }  // namespace
 
-int gemm_path_ready() { return rocblas_ready(); }
+int gemm_path_ready() { return MLBP_OK; }          // hand-written: nothing to load
+bool gemm_path_supports(int X) { return contract_supports(X); }
 
 int launch_gemm_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void* stream) {
-  if (int e = rocblas_ready()) return e;
+  if (!contract_supports(a->X)) return fail(MLBP_EUNSUPPORTED, "shared-table gradient: X = %d", a->X);
   hipStream_t st = (hipStream_t)stream;
-  const int B = a->B, X = a->X, ld = a->n_msgs * X;
-  // scratch: W [X][X], Y [B][X] (column-major X x B), S [4][B]; one device-wide buffer, grown on demand (launches on
-  // different streams must not overlap; a stream-capturing caller runs one eager step first)
-  static double* scratch = nullptr;
+  const int B = a->B, X = a->X;
+  // scratch: W fragments [X][X], Y [B][X], S [4][B]
+  static void* scratch = nullptr;
   static size_t cap = 0;
-  std::lock_guard<std::mutex> lock(g_rb_mutex);
-  const size_t need = (size_t)X * X + (size_t)B * X + 4 * (size_t)B;
-  if (need > cap) {
-    if (scratch) (void)hipFree(scratch);
-    scratch = nullptr; cap = 0;
-    if (hipMalloc(&scratch, need * sizeof(double)) != hipSuccess) return fail(MLBP_EHIP, "gradient GEMM scratch allocation failed");
-    cap = need;
-  }
-  double* W = scratch; double* Y = W + (size_t)X * X; double* S = Y + (size_t)B * X;
-  if (g_rb.set_stream(g_rb.handle, st) != 0) return fail(MLBP_EHIP, "rocblas_set_stream failed");
-  const double one = 1.0, zero = 0.0;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (int e = ensure_scratch(&scratch, &cap, ((size_t)X * X + (size_t)B * X + 4 * (size_t)B) * sizeof(double))) return e;
+  double* W = (double*)scratch; double* Y = W + (size_t)X * X; double* S = Y + (size_t)B * X;
   // slots come from DEVICE arrays in the ABI (pair_c_slot / pair_r_slot / pair_phi): fetch the few ints once
   int32_t h_c[16], h_r[16], h_phi[16];
   if (hipMemcpyAsync(h_c, a->pair_c_slot, sizeof(int32_t) * a->P, hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipMemcpyAsync(h_r, a->pair_r_slot, sizeof(int32_t) * a->P, hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipMemcpyAsync(h_phi, a->pair_phi, sizeof(int32_t) * a->P, hipMemcpyDeviceToHost, st) != hipSuccess ||
       hipStreamSynchronize(st) != hipSuccess)
-    return fail(MLBP_EHIP, "gradient GEMM path: reading the slot tables failed");
+    return fail(MLBP_EHIP, "shared-table gradient: reading the slot tables failed");
   for (int p = 0; p < a->P; ++p) {
     if ((unsigned)h_c[p] >= (unsigned)a->n_msgs || (unsigned)h_r[p] >= (unsigned)a->n_msgs ||
         (unsigned)a->pair_tab_host[p] >= (unsigned)a->n_pair_tables)
-      return fail(MLBP_EINVAL, "gradient GEMM path: slot or table index of factor %d out of range", p);
+      return fail(MLBP_EINVAL, "shared-table gradient: slot or table index of factor %d out of range", p);
     const double* T = a->pair_tables + (size_t)a->pair_tab_host[p] * X * X;
     const double* planes = h_phi[p] ? a->phi_en_en_w1_p : a->phi_en_en_p;
     for (int k = 0; k < 4; ++k) {
-      const double* A = T;
-      if (k < 3) {
-        hipLaunchKernelGGL(weight_table_kernel, dim3((X * X + 255) / 256), dim3(256), 0, st, T, planes + (size_t)k * X * X, X * X, W);
-        A = W;
-      }
-      // Y[:, b] = A . r_b  (A row-major = A^T column-major -> op transpose), r = msgs[:, r_slot, :]
-      const int rc = g_rb.dgemm(g_rb.handle, RB_OP_TRANSPOSE, RB_OP_NONE, X, B, X, &one, A, X, a->msgs + (size_t)h_r[p] * X, ld, &zero, Y, X);
-      if (rc != 0) return fail(MLBP_EHIP, "rocblas_dgemm failed with status %d", rc);
+      // Y[b][:] = (T (.) phi_k) . r_b   (k = 3: T . r_b, the normaliser), r = msgs[:, r_slot, :]
+      launch_table_frag<double>(T, k < 3 ? planes + (size_t)k * X * X : nullptr, X, 0, W, st);
+      ContractDev d = {};
+      d.frag = W; d.in = a->msgs; d.in_ld = (size_t)a->n_msgs * X; d.out = Y; d.out_ld = X;
+      d.n_src = 0; d.in_slot = h_r[p]; d.vf_slot = -1; d.dst_slot = 0; d.B = B; d.normalize = 0;
+      if (int e = launch_contract<double>(d, X, st)) return e;
       hipLaunchKernelGGL(row_dot_kernel, dim3(B), dim3(WG), 0, st, a->msgs, a->n_msgs, X, h_c[p], Y, S + (size_t)k * B);
     }
     hipLaunchKernelGGL(pair_gradient_combine_kernel, dim3((B + 255) / 256), dim3(256), 0, st, S, B, X, a->pair_label, a->P, p,
                        h_phi[p] ? a->phi_en_en_w1 : a->phi_en_en, a->grad_en_en, status);
   }
-  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "gradient GEMM path: a launch failed");
+  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table gradient: a launch failed");
   return MLBP_OK;
 }
 
 int launch_gemm_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream) {
-  if (!a->pair_tab_host) return fail(MLBP_EINVAL, "shared-table GEMM path: pair_tab_host (host int32 [P]) is required");
-  if (prog->P > 16) return fail(MLBP_EUNSUPPORTED, "shared-table GEMM path: at most 16 pairwise factors (got %d)", prog->P);
+  if (!a->pair_tab_host) return fail(MLBP_EINVAL, "shared-table contraction path: pair_tab_host (host int32 [P]) is required");
+  if (prog->P > 16) return fail(MLBP_EUNSUPPORTED, "shared-table contraction path: at most 16 pairwise factors (got %d)", prog->P);
+  if (!contract_supports(a->X)) return fail(MLBP_EUNSUPPORTED, "shared-table contraction path: X = %d", a->X);
   for (int p = 0; p < prog->P; ++p)
     if ((unsigned)a->pair_tab_host[p] >= (unsigned)a->n_pair_tables)
       return fail(MLBP_EINVAL, "pair_tab_host[%d] = %d out of [0,%d)", p, a->pair_tab_host[p], a->n_pair_tables);
-  if (int e = rocblas_ready()) return e;
   hipStream_t st = (hipStream_t)stream;
   const int B = a->B, X = a->X, n_msgs = prog->n_msgs, norm = a->normalize_messages ? 1 : 0;
-  const int ld = n_msgs * X;
+  const bool f32 = (a->flags & MLBP_SWEEP_PAIR_TABLES_F32) != 0;
+  const size_t elem = f32 ? sizeof(float) : sizeof(double);
+  const FusedProgram& fp = prog->fused;
+  // fragment-ordered copies of the distinct tables, both orientations: [P][2][X*X]
+  static void* frag = nullptr;
+  static size_t frag_cap = 0;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (int e = ensure_scratch(&frag, &frag_cap, (size_t)prog->P * 2 * X * X * elem)) return e;
   {
     HostRow row = {};
     for (int p = 0; p < prog->P; ++p) row.v[p] = a->pair_tab_host[p];
     hipLaunchKernelGGL(check_shared_claim_kernel, dim3((B * prog->P + 255) / 256), dim3(256), 0, st, a->pair_tab, B, prog->P,
                        a->n_pair_tables, row, prog->d_status);
   }
+  for (int p = 0; p < prog->P; ++p)
+    for (int tr = 0; tr < 2; ++tr) {
+      const size_t off = ((size_t)p * 2 + tr) * X * X;
+      if (f32) launch_table_frag<float>(a->pair_tables_f32 + (size_t)a->pair_tab_host[p] * X * X, nullptr, X, tr, (float*)frag + off, st);
+      else launch_table_frag<double>(a->pair_tables + (size_t)a->pair_tab_host[p] * X * X, nullptr, X, tr, (double*)frag + off, st);
+    }
   if (a->init_messages)
     hipLaunchKernelGGL(fill_uniform_kernel, dim3(1024), dim3(256), 0, st, a->msgs, (size_t)B * n_msgs * X, 1.0 / (double)X);
-  std::lock_guard<std::mutex> lock(g_rb_mutex);          // one handle: its stream is set per launch sequence
-  if (g_rb.set_stream(g_rb.handle, st) != 0) return fail(MLBP_EHIP, "rocblas_set_stream failed");
-  const double one = 1.0, zero = 0.0;
-  // unary messages are constants (LBP.py:494-498): when nothing else ever writes their slots (the same test that
-  // lets the X = 64 kernels hoist them) each is computed once per call, not once per sweep
-  const bool unary_once = prog->n_hoist == prog->U;
-  std::vector<char> unary_done(prog->n_msgs, 0);
-  for (int s = 0; s < prog->n_sweeps; ++s) {
-    const int first = prog->h_sweeps[2 * s], cnt = prog->h_sweeps[2 * s + 1];
-    for (int o = first; o < first + cnt; ++o) {
-      const int kind = prog->h_ops[4 * o], x = prog->h_ops[4 * o + 1], y = prog->h_ops[4 * o + 2], c = prog->h_ops[4 * o + 3];
-      if (kind == MLBP_OP_PAIR_TM || kind == MLBP_OP_PAIR_MT) {
-        // column-major views: C = msgs[:, c, :]^T (X x B, ld), Bm = msgs[:, y, :]^T; the row-major table is T^T
-        // column-major, so T . m needs op(A) = transpose and m^T . T none
-        const double* T = a->pair_tables + (size_t)a->pair_tab_host[x] * X * X;
-        const int rc = g_rb.dgemm(g_rb.handle, kind == MLBP_OP_PAIR_TM ? RB_OP_TRANSPOSE : RB_OP_NONE, RB_OP_NONE, X, B, X, &one, T, X,
-                                  a->msgs + (size_t)y * X, ld, &zero, a->msgs + (size_t)c * X, ld);
-        if (rc != 0) return fail(MLBP_EHIP, "rocblas_dgemm failed with status %d", rc);
-        if (norm) hipLaunchKernelGGL(renormalize_slot_kernel, dim3(B), dim3(WG), 0, st, a->msgs, n_msgs, X, c);
-      } else if (kind == MLBP_OP_VAR) {
-        hipLaunchKernelGGL(variable_update_kernel, dim3(B), dim3(WG), (size_t)X * sizeof(double), st, a->msgs, n_msgs, X,
-                           prog->d_srcs, x, y, c, norm);
-      } else if (!(unary_once && unary_done[c])) {
-        unary_done[c] = 1;
-        hipLaunchKernelGGL(unary_update_kernel, dim3(B), dim3(WG), 0, st, a->msgs, n_msgs, X, a->unary_tables, a->unary_tab,
-                           prog->U, a->n_unary_tables, x, c, norm, prog->d_status);
+  // unary messages the program could hoist are constants (LBP.py:494-498): once per call
+  for (size_t h = 0; h + 1 < fp.hoist.size(); h += 2)
+    hipLaunchKernelGGL(unary_update_kernel, dim3(B), dim3(WG), 0, st, a->msgs, n_msgs, X, a->unary_tables, a->unary_tab, prog->U,
+                       a->n_unary_tables, fp.hoist[h], fp.hoist[h + 1], norm, prog->d_status);
+  const size_t ld = (size_t)n_msgs * X;
+  const int n_fops = (int)fp.fops.size() / 8;
+  // a fused variable->factor message goes to memory only when something reads the slot before its next write, or when
+  // it is the slot's final value (the messages are an output of the call): in a 10-sweep call most are neither
+  std::vector<char> store_vf(n_fops, 1);
+  for (int i = 0; i < n_fops; ++i) {
+    const int32_t* w = &fp.fops[8 * (size_t)i];
+    const int kd = w[0] & 0xFF;
+    if (kd != FOP_VAR_PAIR_TM && kd != FOP_VAR_PAIR_MT) continue;
+    const int c = w[3];
+    for (int j = i + 1; j < n_fops; ++j) {
+      const int32_t* v = &fp.fops[8 * (size_t)j];
+      const int kj = v[0] & 0xFF;
+      bool reads = false, writes = false;
+      if (kj == FOP_PAIR_TM || kj == FOP_PAIR_MT) { reads = v[2] == c; writes = v[3] == c; }
+      else if (kj == FOP_UNARY) { writes = v[3] == c; }
+      else {
+        for (int q = 0; q < v[7]; ++q) reads |= fp.psrcs[v[6] + q] == c;
+        writes = v[3] == c || (kj != FOP_VAR && v[5] == c);
       }
+      if (reads) break;
+      if (writes) { store_vf[i] = 0; break; }
     }
   }
-  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table GEMM path: a launch failed");
+  for (int i = 0; i < n_fops; ++i) {
+    const int32_t* w = &fp.fops[8 * (size_t)i];
+    const int kind = w[0] & 0xFF;
+    if (kind == FOP_UNARY) {
+      hipLaunchKernelGGL(unary_update_kernel, dim3(B), dim3(WG), 0, st, a->msgs, n_msgs, X, a->unary_tables, a->unary_tab, prog->U,
+                         a->n_unary_tables, w[1], w[3], norm, prog->d_status);
+      continue;
+    }
+    if (kind == FOP_VAR) {          // exact source list: psrcs[w[6] .. w[6] + w[7])
+      hipLaunchKernelGGL(variable_update_kernel, dim3(B), dim3(WG), (size_t)X * sizeof(double), st, a->msgs, n_msgs, X,
+                         (prog->d_fops + 8 * (size_t)prog->n_fops) + w[6], w[7], w[3], norm);
+      continue;
+    }
+    ContractDev d = {};
+    d.in = a->msgs; d.out = a->msgs; d.in_ld = ld; d.out_ld = ld; d.B = B; d.normalize = norm;
+    int pslot, tm;
+    if (kind == FOP_PAIR_TM || kind == FOP_PAIR_MT) {
+      pslot = w[1]; tm = kind == FOP_PAIR_TM;
+      d.n_src = 0; d.in_slot = w[2]; d.vf_slot = -1; d.dst_slot = w[3];
+    } else {
+      pslot = w[4]; tm = kind == FOP_VAR_PAIR_TM;
+      d.n_src = w[7]; d.in_slot = 0; d.vf_slot = w[3]; d.dst_slot = w[5];
+      if (d.n_src == 0 || d.n_src > 8) {      // no other factor (the message is the uniform vector), or a long list: its own launch
+        hipLaunchKernelGGL(variable_update_kernel, dim3(B), dim3(WG), (size_t)X * sizeof(double), st, a->msgs, n_msgs, X,
+                           (prog->d_fops + 8 * (size_t)prog->n_fops) + w[6], w[7], w[3], norm);
+        d.n_src = 0; d.in_slot = w[3]; d.vf_slot = -1;
+      } else {
+        for (int q = 0; q < d.n_src; ++q) d.src[q] = fp.psrcs[w[6] + q];
+        if (!store_vf[i]) d.vf_slot = -1;
+      }
+    }
+    // out = T . m contracts over the table's columns: A = T; out = m^T . T over its rows: A = T^T
+    const size_t off = ((size_t)pslot * 2 + (tm ? 0 : 1)) * X * X;
+    d.frag = f32 ? (const void*)((const float*)frag + off) : (const void*)((const double*)frag + off);
+    if (int e = f32 ? launch_contract<float>(d, X, st) : launch_contract<double>(d, X, st)) return e;
+  }
+  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table contraction path: a launch failed");
   return MLBP_OK;
 }
 

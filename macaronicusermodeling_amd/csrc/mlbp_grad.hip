@@ -520,7 +520,7 @@ int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream) {
     return MLBP_OK;
   }
   // shared pairwise tables at a large state space: pairwise part as DGEMMs over the whole batch (mlbp_gemm.hip)
-  const bool gemm_pairs = (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->pair_tab_host && a->X >= 128 && a->F_ee == 3 &&
+  const bool gemm_pairs = (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->pair_tab_host && mlbp::gemm_path_supports(a->X) && a->F_ee == 3 &&
                           a->P > 0 && a->P <= 16 && a->phi_en_en_p && a->phi_en_en_w1_p && mlbp::gemm_path_ready() == MLBP_OK;
   d.skip_pairs = gemm_pairs ? 1 : 0;
   if (a->F_ee == 3) hipLaunchKernelGGL((gradient_kernel<3, 6>), dim3(a->B), dim3(WG), 0, st, d);

@@ -60,9 +60,11 @@ bool build_shared_readout(const SharedProgram& sp, int n_msgs, int n_vars, const
 int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched);
 // Pairwise part of the gradient for shared tables (X = 64, F_ee = 3), ADDED to a->grad_en_en.
 int launch_shared_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void* stream);
-// Shared tables at X >= 128: the sweeps op by op over the whole batch, contractions as DGEMMs (mlbp_gemm.hip).
+// Shared tables at X = 128 .. 512: the sweeps update by update over the whole batch, every contraction one launch of the
+// hand-written MFMA kernel of mlbp_gemm.hip (float64 tables, or float32 with MLBP_SWEEP_PAIR_TABLES_F32).
 int launch_gemm_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
-int gemm_path_ready();      // MLBP_OK when rocBLAS could be bound
+int gemm_path_ready();      // always MLBP_OK (kept for the callers' sake)
+bool gemm_path_supports(int X);
 // Pairwise part of the gradient for shared tables at X >= 128 (F_ee = 3), ADDED to a->grad_en_en.
 int launch_gemm_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void* stream);
 }  // namespace mlbp
@@ -89,6 +91,7 @@ struct mlbp_program {
   int32_t* d_fsweeps;     // [n_sweeps][2]
   int32_t* d_fpairseq;    // pair slot of the k-th executed pairwise update of the fused form (-1 terminated)
   int device;
+  mlbp::FusedProgram fused;      // host copy (the update-by-update contraction path walks it)
   mlbp::LeanProgram lean;
   int32_t* d_limage = nullptr;   // LeanProgram::image
   int32_t* d_lreadout = nullptr; // build_lean_readout

@@ -1726,6 +1726,7 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
   p->n_sreadout = 0;
   mlbp::build_shared_program(fp, n_msgs, P, U, p->shared);
   if (p->shared.ok && e == hipSuccess) e = up(&p->d_simage, p->shared.image.data(), p->shared.image.size());
+  p->fused = fp;
   mlbp::build_lean_program(fp, n_msgs, p->lean);
   if (p->lean.ok && e == hipSuccess) e = up(&p->d_limage, p->lean.image.data(), p->lean.image.size());
   if (e == hipSuccess) e = up(&p->d_fops, image.data(), image.size());
@@ -1892,11 +1893,13 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       return MLBP_OK;
     }
   }
-  if ((a->flags & MLBP_SWEEP_SHARED_PAIR_TABLES) && a->pair_tab_host && a->X >= 128 && !(a->flags & MLBP_SWEEP_PAIR_TABLES_F32) &&
-      prog->P >= 1 && prog->P <= 16 && (variant == 1 || variant == 30)) {
-    // shared tables at a large state space: every contraction is one DGEMM over the whole batch
+  if ((a->flags & MLBP_SWEEP_SHARED_PAIR_TABLES) && a->pair_tab_host && mlbp::gemm_path_supports(a->X) &&
+      prog->P >= 1 && prog->P <= 16 && (variant == 1 || variant == 2 || variant == 30)) {
+    // shared tables at a large state space: every contraction is one MFMA launch over the whole batch
+    if ((a->flags & MLBP_SWEEP_PAIR_TABLES_F32) && a->gradient)
+      return fail(MLBP_EUNSUPPORTED, "mlbp_sweep_f64: no gradient with float32 pairwise tables");
     const int eg = mlbp::launch_gemm_sweep(prog, a, stream);
-    if (eg != MLBP_EUNSUPPORTED) {                 // unsupported (no rocBLAS on this machine): the per-graph kernels below
+    if (eg != MLBP_EUNSUPPORTED) {                 // unsupported shape: the per-graph kernels below
       if (eg) return eg;
       g_last_kernel = MLBP_KERNEL_SHARED_GEMM;
       if (a->marginals)

@@ -216,17 +216,18 @@ def test_full_size_properties_of_the_shared_kernel():
     np.testing.assert_allclose(g1.cpu().numpy(), marg[:64].cpu().numpy(), rtol=1e-11, atol=1e-300)
 
 
-@pytest.mark.parametrize('X', [128, 512])
+@pytest.mark.parametrize('X', [128, 384, 512])
 def test_large_state_shared_tables_run_as_batched_gemms(X):
-    """X >= 128 with shared pairwise tables: the sweeps run op by op over the whole batch, every factor->variable
-    update one DGEMM (mlbp_gemm.hip).  Against the oracle per graph and against the per-graph wide kernel on the
+    """X = 128 .. 512 with shared pairwise tables: the sweeps run update by update over the whole batch, every
+    factor->variable update one launch of the hand-written float64 MFMA contraction (mlbp_gemm.hip; the variable
+    product fused into its prologue, Message.renormalize into its epilogue).  Against the oracle per graph and against the per-graph wide kernel on the
     same inputs (same updates, only the summation order inside the contraction differs)."""
     from macaronicusermodeling_amd import _ffi
     from macaronicusermodeling_amd.batch import FactorGraphBatch
     from macaronicusermodeling_amd.topology import GraphTopology
     spec = C.ring_spec(5, X)
     topo = GraphTopology.from_spec(spec)
-    B = 9
+    B = 37                                      # three workgroups of 16 graphs, the last one ragged
     inputs = [C.make_inputs(spec, 31 + 1000 * b) for b in range(B)]
     g = O.Graph(spec)
     pair = np.stack([O.factor_table(g, inputs[0], g.by_id[topo.factor_ids[j]]).reshape(X, X) for j in topo.pair_factors])
@@ -250,12 +251,12 @@ def test_large_state_shared_tables_run_as_batched_gemms(X):
     try:
         _ffi.check(_ffi.lib.mlbp_set_sweep_variant(3))                             # per-graph kernels on the same inputs
         fb.sweep(roots, init=True, marginals=marg)
-        assert _ffi.lib.mlbp_last_sweep_kernel() == 4
+        assert _ffi.lib.mlbp_last_sweep_kernel() == (5 if X == 384 else 4)
     finally:
         _ffi.check(_ffi.lib.mlbp_set_sweep_variant(1))
     np.testing.assert_allclose(got.cpu().numpy(), fb.msgs.cpu().numpy(), rtol=1e-11, atol=1e-300)
     np.testing.assert_allclose(gm.cpu().numpy(), marg.cpu().numpy(), rtol=1e-11, atol=1e-300)
-    for b in (0, B - 1):
+    for b in (0, 17, B - 1):
         _, _, want = oracle_msgs(spec, inputs[b], roots)
         np.testing.assert_allclose(got[b].cpu().numpy(), want, rtol=RTOL, atol=1e-300)
     # a false sharing statement is reported, not silently computed
@@ -300,3 +301,53 @@ def test_shared_kernel_with_most_tiles_spilled(which):
         np.testing.assert_allclose(got[b], want, rtol=RTOL, atol=1e-300)
         for k, v in enumerate(topo.var_ids):
             np.testing.assert_allclose(gm[b, k], O.marginal(gg, msgs, v).reshape(-1), rtol=RTOL, atol=1e-300)
+
+
+@pytest.mark.parametrize('X', [256, 512])
+def test_large_state_shared_float32_tables_on_the_f32_matrix_cores(X):
+    """BASELINE config 5's "batched f32 MFMA message contraction": shared float32 tables at X = 256 / 512 run on
+    v_mfma_f32_16x16x4_f32 (float32 table and message fragments, float32 sums over 64 states, float64 across them).
+    Tolerance study (the numbers DESIGN.md 4.2b quotes): against the float64 oracle on the UNROUNDED tables the
+    messages stay inside the north star's 1e-5 relative; against the float64 contraction fed the float32-rounded
+    tables the difference is what the float32 message fragments and partial sums add."""
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.batch import FactorGraphBatch
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = C.ring_spec(6, X)
+    topo = GraphTopology.from_spec(spec)
+    B = 20
+    inputs = [C.make_inputs(spec, 77 + 1000 * b, 'uniform') for b in range(B)]
+    g = O.Graph(spec)
+    pair = np.stack([O.factor_table(g, inputs[0], g.by_id[topo.factor_ids[j]]).reshape(X, X) for j in topo.pair_factors])
+    for b in range(1, B):
+        tabs = list(inputs[b]['tables'])
+        for f in spec['factors']:
+            if len(f['vars']) == 2:
+                tabs[f['table']] = inputs[0]['tables'][f['table']]
+        inputs[b] = dict(tables=tabs)
+    unary = np.stack([O.factor_table(g, inputs[b], g.by_id[topo.factor_ids[j]]).reshape(X) for b in range(B) for j in topo.unary_factors])
+    roots = [0, 2, 4, 0, 2, 4, 0, 2, 4, 0]            # ten sweeps, as config 5 runs
+    idx = np.tile(np.arange(topo.P), (B, 1))
+    fb32 = FactorGraphBatch(topo, X, B)
+    fb32.set_pair_tables(pair, idx, dtype=torch.float32)
+    fb32.set_unary_tables(unary)
+    m32 = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=fb32.device)
+    prog = fb32.sweep(roots, init=True, marginals=m32)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 6, _ffi.lib.mlbp_last_error()
+    assert prog.status() == 0
+    fb64 = FactorGraphBatch(topo, X, B)
+    fb64.set_pair_tables(pair.astype(np.float32).astype(np.float64), idx)
+    fb64.set_unary_tables(unary)
+    m64 = torch.empty_like(m32)
+    fb64.sweep(roots, init=True, marginals=m64)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 6
+    got32, got64 = fb32.msgs.cpu().numpy(), fb64.msgs.cpu().numpy()
+    rel_arith = float(np.abs(got32 / got64 - 1).max())
+    rel_marg = float(np.abs(m32.cpu().numpy() / m64.cpu().numpy() - 1).max())
+    worst = 0.0
+    for b in (0, 7, B - 1):
+        _, _, want = oracle_msgs(spec, inputs[b], roots)
+        worst = max(worst, float(np.abs(got32[b] / want.reshape(got32[b].shape) - 1).max()))
+    print('X=%d f32 MFMA path: vs f64 contraction on rounded tables %.2e (messages) %.2e (marginals); vs unrounded oracle %.2e'
+          % (X, rel_arith, rel_marg, worst))
+    assert rel_arith < 2e-6 and rel_marg < 2e-6 and worst < 1e-5

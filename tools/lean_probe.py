@@ -17,7 +17,7 @@ lib = os.path.join(OUT, 'libmlbp_probe.so')
 csrc = os.path.join(ROOT, 'macaronicusermodeling_amd', 'csrc')
 from macaronicusermodeling_amd import build as B_  # noqa: E402
 subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fno-fast-math',
-                       '-DMLBP_LEAN_PROBE', '-shared', '-x', 'hip'] + [os.path.join(csrc, f) for f in B_.SOURCES] + ['-o', lib, '-ldl'])
+                       '-DMLBP_LEAN_PROBE', '-shared', '-x', 'hip'] + [os.path.join(csrc, f) for f in B_.SOURCES] + ['-o', lib])
 import macaronicusermodeling_amd._ffi as ffi  # noqa: E402
 ffi.LIB_PATH = lib
 ffi.lib = ffi._load()

@@ -62,7 +62,7 @@ F64_MFMA_PEAK_TFLOPS = 78.6     # MI355X FP64 matrix spec (= FP64 vector; 32 flo
 
 def workload_spec(name):
     import cases as C
-    if name in ('user_k3', 'user_k3_shared'):
+    if name in ('user_k3', 'user_k3_shared', 'user_k3_trainlayout'):
         return C.user_spec(10, [1, 4, 7], 64, 64, seed=1), [1, 4, 7], 3, 1236
     if name in ('user_k4', 'user_k4_shared'):     # four predicted words: K4 = 6 pairwise + 28 unary factors
         return C.user_spec(10, [1, 3, 5, 8], 64, 64, seed=2), [1, 3, 5], 3, 1237
@@ -241,7 +241,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'user_k4', 'user_k4_shared', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared', 'ring8_x512_shared_f32'],
+    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'user_k3_trainlayout', 'user_k4', 'user_k4_shared', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared', 'ring8_x512_shared_f32'],
                     help='user_k3_shared = the same graphs with the reference\'s table layout: all graphs share the two '
                          'en_en pots (MFMA kernel, reported against the f64 matrix peak)')
     ap.add_argument('--no-writeback', action='store_true', help='shared workload: skip the message write-back (read-out only)')
@@ -295,8 +295,19 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed + 7919 * rank)
     fb = FactorGraphBatch(topo, X, B, device=dev)
-    shared = '_shared' in a.workload
+    shared = '_shared' in a.workload or a.workload.endswith('_trainlayout')
     unary = torch.rand(B * topo.U, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
+    unary_tab = None
+    if a.workload.endswith('_trainlayout'):
+        # the reference's real layout (train_mp.py:178-255, LBP.py:695-706): a unary factor's table is one column of a pot
+        # shared by every instance under one theta -- 3 pots x 64 observed columns = 192 rows, stored transposed; which
+        # row a factor reads is its observed word.  (UserGraphTrainer builds exactly this.)
+        unary = torch.rand(3 * 64, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
+        by_id = {f['id']: f for f in spec['factors']}
+        kind = np.array([2 if by_id[topo.factor_ids[j]]['factor_type'] == 'en_de' else (0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1)
+                         for j in topo.unary_factors])
+        rs = np.random.RandomState(seed + rank)
+        unary_tab = kind[None, :] * 64 + rs.randint(0, 64, size=(B, topo.U))
     if shared and spec['style'] == 'explicit':      # one table per factor, the same for every graph (X = 512: batched DGEMMs)
         pair = torch.rand(topo.P, X, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
         fb.set_pair_tables(pair, np.tile(np.arange(topo.P), (B, 1)), dtype=torch.float32 if a.workload.endswith('_f32') else torch.float64)
@@ -311,7 +322,7 @@ def main():
     else:
         pair = torch.rand(B * topo.P, X, X, dtype=torch.float64, device=dev, generator=gen) + 0.01
         fb.set_pair_tables(pair)
-    fb.set_unary_tables(unary)
+    fb.set_unary_tables(unary, unary_tab)
     labels = np.tile(np.array([dict(zip(spec['var_ids'], spec['labels']))[v] for v in topo.var_ids]), (B, 1))
     labels_d = torch.from_numpy(labels.astype(np.int32)).to(dev)
     # two statistics buffers: the all-reduce of step i is asynchronous and overlaps step i+1's sweeps

@@ -41,7 +41,7 @@ constexpr int WG = 256;
 // micro-op word 0
 constexpr int UOP_VAR = 1;          // bit 0: variable product only (stored, no contraction)
 constexpr int UOP_MT = 2;           // bit 1: out = m^T . T (else T . m)
-constexpr int UOP_PSLOT_SHIFT = 2;  // bits 2-4: pair slot (register-resident table)
+constexpr int UOP_PSLOT_SHIFT = 2;  // bits 2-4: pair slot (register-resident table; 0..7)
 constexpr int UOP_NOP = 32;         // bit 5: empty second slot of a bundle
 constexpr int UOP_STORE_VF = 64;    // bit 6: the variable->factor message is stored (word 5)
 constexpr int UOP_NSRC_SHIFT = 8;   // bits 8-11: number of sources (1..4)
@@ -203,7 +203,7 @@ __device__ __forceinline__ double rescale(double r, int& bad) {
 }
 
 template <int NT>
-__global__ __launch_bounds__(WG, (NT >= 4 ? 2 : 3)) void sweep_x64_lean_kernel(SweepDev d, LeanDev f) {
+__global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x64_lean_kernel(SweepDev d, LeanDev f) {
   extern __shared__ double lds[];
   double* work = lds;                                        // [n_msgs + n_ext][64] scaled messages
   double* red = lds + (size_t)(d.n_msgs + f.n_ext) * 64;     // [2 parities][2 bundle slots][4][64]
@@ -666,7 +666,7 @@ extern "C" int mlbp_debug_lean_probe(int mask, void* buf) {
 int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched) {
   *launched = false;
   const LeanProgram& lp = prog->lean;
-  if (!lp.ok || !prog->d_limage || a->X != 64 || !a->normalize_messages || prog->P < 1 || prog->P > 4) return MLBP_OK;
+  if (!lp.ok || !prog->d_limage || a->X != 64 || !a->normalize_messages || prog->P < 1 || prog->P > 8) return MLBP_OK;
   if (a->gradient) return MLBP_OK;                // the fused gradient epilogue lives in the older kernels
   if (a->marginals && !prog->d_lreadout) return MLBP_OK;
   const int n_ext = 2 + lp.n_cprod;               // uniform, the constant products, ones
@@ -698,7 +698,9 @@ int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* 
     case 1: k = sweep_x64_lean_kernel<1>; break;
     case 2: k = sweep_x64_lean_kernel<2>; break;
     case 3: k = sweep_x64_lean_kernel<3>; break;
-    default: k = sweep_x64_lean_kernel<4>; break;
+    case 4: k = sweep_x64_lean_kernel<4>; break;
+    case 5: case 6: k = sweep_x64_lean_kernel<6>; break;
+    default: k = sweep_x64_lean_kernel<8>; break;        // 7, 8: part of the tables lives in the accumulator registers
   }
   if (int e = ensure_lds((const void*)k, lds)) return e;
   hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, (hipStream_t)stream, d, f);

@@ -1818,8 +1818,8 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       if (variant == 1 || variant == 2 || variant == 30)
         if (int e = mlbp::launch_shared_sweep(prog, a, stream, &shared_done)) return e;
       if (shared_done) { want_sf = false; grad_fused = false; gf = GradFusedDev{}; }
-      bool lean_done = false;                  // default scale-free path: the lean kernel (mlbp_lean.hip)
-      if (want_sf && !shared_done && variant == 1)
+      bool lean_done = false;                  // default scale-free path: the lean kernel (mlbp_lean.hip), up to 8 resident tables
+      if (norm && prog->sf_ok && prog->P >= 1 && prog->P <= 8 && !shared_done && variant == 1)
         if (int e = mlbp::launch_lean_sweep(prog, a, stream, &lean_done)) return e;
       g_last_kernel = shared_done ? MLBP_KERNEL_SHARED_MFMA : (lean_done ? MLBP_KERNEL_LEAN : (want_sf ? MLBP_KERNEL_SCALE_FREE : MLBP_KERNEL_EXACT));
       if (want_sf && !lean_done) {

@@ -16,7 +16,7 @@ lib = os.path.join(OUT, 'libmlbp_stamps.so')
 csrc = os.path.join(ROOT, 'macaronicusermodeling_amd', 'csrc')
 subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fno-fast-math',
                        '-DMLBP_STAMPS', '-shared', '-x', 'hip', os.path.join(csrc, 'mlbp_host.cpp'),
-                       os.path.join(csrc, 'mlbp_sweep.hip'), os.path.join(csrc, 'mlbp_shared.hip'), os.path.join(csrc, 'mlbp_gemm.hip'), os.path.join(csrc, 'mlbp_prims.hip'),
+                       os.path.join(csrc, 'mlbp_sweep.hip'), os.path.join(csrc, 'mlbp_lean.hip'), os.path.join(csrc, 'mlbp_shared.hip'), os.path.join(csrc, 'mlbp_gemm.hip'), os.path.join(csrc, 'mlbp_prims.hip'),
                        os.path.join(csrc, 'mlbp_grad.hip'), '-o', lib])
 import macaronicusermodeling_amd._ffi as ffi  # noqa: E402
 ffi.LIB_PATH = lib

@@ -16,7 +16,7 @@ lib = os.path.join(OUT, 'libmlbp_stamps.so')
 csrc = os.path.join(ROOT, 'macaronicusermodeling_amd', 'csrc')
 subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fno-fast-math',
                        '-DMLBP_STAMPS', '-shared', '-x', 'hip'] +
-                      [os.path.join(csrc, f) for f in ('mlbp_host.cpp', 'mlbp_sweep.hip', 'mlbp_shared.hip', 'mlbp_gemm.hip', 'mlbp_prims.hip',
+                      [os.path.join(csrc, f) for f in ('mlbp_host.cpp', 'mlbp_sweep.hip', 'mlbp_lean.hip', 'mlbp_shared.hip', 'mlbp_gemm.hip', 'mlbp_prims.hip',
                                                        'mlbp_grad.hip')] + ['-o', lib])
 import macaronicusermodeling_amd._ffi as ffi  # noqa: E402
 ffi.LIB_PATH = lib

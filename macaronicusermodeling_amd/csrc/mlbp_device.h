@@ -101,6 +101,10 @@ struct SweepDev {
   double* marginals;           // [B][n_vars][X] or NULL
   const int32_t* readout;      // device: in_off [n_vars+1] then in_slots
   int32_t n_vars;
+  // fix-up mode of the generic kernel behind a fast kernel: only graphs with only[g] != 0 are computed, from uniform
+  // messages when fill_uniform is set (FactorGraph.initialize fused)
+  const uint8_t* only;
+  int32_t fill_uniform;
 };
 
 }  // namespace mlbp_dev

@@ -202,7 +202,8 @@ __device__ __forceinline__ double rescale(double r, int& bad) {
   return __builtin_ldexp(r, 1023 - ((ref >> 20) & 0x7FF));
 }
 
-template <int NT>
+// PADX: X = d.X < 64 states, vectors and tables zero-padded to 64 on the way in, the first X entries written back.
+template <int NT, bool PADX>
 __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x64_lean_kernel(SweepDev d, LeanDev f) {
   extern __shared__ double lds[];
   double* work = lds;                                        // [n_msgs + n_ext][64] scaled messages
@@ -211,8 +212,10 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
 
   const int g = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const double uniform = 1.0 / 64.0;
-  double* gm = d.msgs + (size_t)g * d.n_msgs * 64;
+  const int X = PADX ? d.X : 64;
+  const double uniform = 1.0 / (double)X;
+  const double uni_l = (!PADX || lane < X) ? uniform : 0.0;      // the uniform vector, lane = state
+  double* gm = d.msgs + (size_t)g * d.n_msgs * X;
   const int32_t* img_hoist = f.image + 16 * (size_t)f.n_bundles;
   const int32_t* img_cprod = img_hoist + 8 * (size_t)f.HL;
   const int32_t* img_written = img_cprod + 16 * (size_t)f.n_cprod;
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
       if (u >= 0) {
         const int row = f.dense ? g * d.U + u : as_const(d.unary_tab)[(size_t)g * d.U + u];
         if ((unsigned)row >= (unsigned)d.n_unary_tables) ok = false;
-        else if (!PROBED(5)) ur[j] = d.unary_tables[(size_t)row * 64 + lane];
+        else if (!PROBED(5) && (!PADX || lane < X)) ur[j] = d.unary_tables[(size_t)row * X + lane];
       }
     }
   }
@@ -262,11 +265,23 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
       const int ti = f.dense ? g * d.P + p : as_const(d.pair_tab)[(size_t)g * d.P + p];
       if ((unsigned)ti >= (unsigned)d.n_pair_tables) { ok = false; continue; }
       if (PROBED(4)) continue;
-      const double* T = d.pair_tables + (size_t)ti * 4096 + (size_t)(4 * R_) * 64 + 2 * c_;
+      if (!PADX) {
+        const double* T = d.pair_tables + (size_t)ti * 4096 + (size_t)(4 * R_) * 64 + 2 * c_;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        tab[p][r][0] = *reinterpret_cast<const double2*>(T + r * 64 + 32 * b3_);
-        tab[p][r][1] = *reinterpret_cast<const double2*>(T + r * 64 + 32 * (1 - b3_));
+        for (int r = 0; r < 4; ++r) {
+          tab[p][r][0] = *reinterpret_cast<const double2*>(T + r * 64 + 32 * b3_);
+          tab[p][r][1] = *reinterpret_cast<const double2*>(T + r * 64 + 32 * (1 - b3_));
+        }
+      } else {
+        const double* T = d.pair_tables + (size_t)ti * X * X;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int row = 4 * R_ + r, col = 32 * (k ? 1 - b3_ : b3_) + 2 * c_;
+            tab[p][r][k].x = (row < X && col < X) ? T[(size_t)row * X + col] : 0.0;
+            tab[p][r][k].y = (row < X && col + 1 < X) ? T[(size_t)row * X + col + 1] : 0.0;
+          }
       }
     }
   }
@@ -286,17 +301,26 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
   unsigned bad_key = 0;
   {
     double2* dst = reinterpret_cast<double2*>(work);
+    const int x0 = (2 * t) & 63;                                  // states of the double2 this thread writes (stride 256 keeps them)
+    const double2 uni2 = PADX ? make_double2(x0 < X ? uniform : 0.0, x0 + 1 < X ? uniform : 0.0) : make_double2(uniform, uniform);
     if (f.init) {
-      for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = make_double2(uniform, uniform);
-    } else {
+      for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = uni2;
+    } else if (!PADX) {
       const double2* src = reinterpret_cast<const double2*>(gm);
       for (int i = t; i < d.n_msgs * 32; i += WG) {
         const double2 v = src[i];
         bad_key = max(bad_key, max(mag_key(v.x), mag_key(v.y)));
         dst[i] = v;
       }
+    } else {
+      for (int i = t; i < d.n_msgs * 64; i += WG) {
+        const int slot = i >> 6, x = i & 63;
+        const double v = x < X ? gm[(size_t)slot * X + x] : 0.0;
+        bad_key = max(bad_key, mag_key(v));
+        work[i] = v;
+      }
     }
-    if (t < 32) dst[d.n_msgs * 32 + t] = make_double2(uniform, uniform);               // ext slot 0: the uniform vector
+    if (t < 32) dst[d.n_msgs * 32 + t] = uni2;                                           // ext slot 0: the uniform vector
     if (t >= 32 && t < 64) dst[(d.n_msgs + f.n_ext - 1) * 32 + (t - 32)] = make_double2(1.0, 1.0);   // last ext slot: ones
   }
   PSTAMP          // 1: every load issued
@@ -306,7 +330,7 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
   for (int j = 0; j < HB; ++j) {
     if (uslot[j] >= 0) {
       const double s = wave_sum(ur[j]);
-      const double m = renorm(ur[j], s, uniform, true);
+      const double m = renorm(ur[j], s, uni_l, true);
       bad_key = max(bad_key, mag_key(m));
       work[uslot[j] * 64 + lane] = m;
     }
@@ -317,10 +341,10 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
     if (u < 0) break;
     const int row = f.dense ? g * d.U + u : as_const(d.unary_tab)[(size_t)g * d.U + u];
     double r = 0.0;
-    if ((unsigned)row < (unsigned)d.n_unary_tables) r = d.unary_tables[(size_t)row * 64 + lane];
-    else ok = false;
+    if ((unsigned)row >= (unsigned)d.n_unary_tables) ok = false;
+    else if (!PADX || lane < X) r = d.unary_tables[(size_t)row * X + lane];
     const double s = wave_sum(r);
-    const double m = renorm(r, s, uniform, true);
+    const double m = renorm(r, s, uni_l, true);
     bad_key = max(bad_key, mag_key(m));
     work[slot * 64 + lane] = m;
   }
@@ -333,7 +357,7 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
   // lists are 16 words (count, 15 slots padded with the all-ones slot), wave k & 3 takes list k
   for (int k = wave; k < f.n_cprod; k += 4) {
     const Words16 cl = sload16(img_cprod + 16 * k);
-    double acc = uniform;
+    double acc = uni_l;
 #pragma unroll
     for (int q0 = 1; q0 < 16; q0 += 5) {
       if (cl.w[0] >= q0) {
@@ -466,10 +490,13 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
     if (t == 0) f.bail[g] = 3;
     return;
   }
-  if (f.keep) {
+  if (f.keep && !PADX) {
     const double2* src = reinterpret_cast<const double2*>(work);
     double2* dst = reinterpret_cast<double2*>(gm);
     for (int i = t; i < d.n_msgs * 32 && !PROBED(2); i += WG) dst[i] = src[i];
+  } else if (f.keep) {
+    for (int i = t; i < d.n_msgs * 64; i += WG)
+      if ((i & 63) < X) gm[(size_t)(i >> 6) * X + (i & 63)] = work[i];
   }
   PSTAMP          // 7: write-back issued
   if (f.readout && !PROBED(3)) {
@@ -666,9 +693,11 @@ extern "C" int mlbp_debug_lean_probe(int mask, void* buf) {
 int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched) {
   *launched = false;
   const LeanProgram& lp = prog->lean;
-  if (!lp.ok || !prog->d_limage || a->X != 64 || !a->normalize_messages || prog->P < 1 || prog->P > 8) return MLBP_OK;
+  if (!lp.ok || !prog->d_limage || a->X > 64 || a->X < 2 || !a->normalize_messages || prog->P < 1 || prog->P > 8) return MLBP_OK;
+  const bool padx = a->X < 64;
+  if (padx && prog->P > 4) return MLBP_OK;
   if (a->gradient) return MLBP_OK;                // the fused gradient epilogue lives in the older kernels
-  if (a->marginals && !prog->d_lreadout) return MLBP_OK;
+  if (a->marginals && !prog->d_lreadout && !padx) return MLBP_OK;
   const int n_ext = 2 + lp.n_cprod;               // uniform, the constant products, ones
   const size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 256) * sizeof(double) + 16 * (size_t)(lp.n_bundles + 1) * sizeof(int32_t);
   if (lds > 64 * 1024) return MLBP_OK;            // large graphs: the older kernels' rules apply
@@ -684,23 +713,33 @@ int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* 
   d.msgs = a->msgs;
   d.ops = nullptr; d.srcs = nullptr; d.sweeps = nullptr; d.pairseq = nullptr;
   d.status = prog->d_status;
-  d.n_sweeps = prog->n_sweeps; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U; d.X = 64;
+  d.n_sweeps = prog->n_sweeps; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U; d.X = a->X;
   d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables;
-  d.marginals = a->marginals; d.readout = nullptr; d.n_vars = prog->n_vars;
+  d.marginals = padx ? nullptr : a->marginals; d.readout = nullptr; d.n_vars = prog->n_vars;
+  d.only = nullptr; d.fill_uniform = 0;
   LeanDev f;
-  f.image = prog->d_limage; f.readout = a->marginals ? prog->d_lreadout : nullptr; f.bail = mp->d_bail;
+  f.image = prog->d_limage; f.readout = (a->marginals && !padx) ? prog->d_lreadout : nullptr; f.bail = mp->d_bail;
   f.n_bundles = lp.n_bundles; f.HL = lp.HL; f.n_cprod = lp.n_cprod; f.WL = lp.WL;
   f.n_ext = n_ext; f.init = a->init_messages; f.dense = dense ? 1 : 0;
   // the messages go back to memory unless the caller waives them and takes the fused read-out instead
-  f.keep = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && a->marginals) ? 0 : 1;
+  f.keep = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && a->marginals && !padx) ? 0 : 1;     // (small X: the read-out is a separate launch over the messages)
   void (*k)(SweepDev, LeanDev) = nullptr;
-  switch (prog->P) {
-    case 1: k = sweep_x64_lean_kernel<1>; break;
-    case 2: k = sweep_x64_lean_kernel<2>; break;
-    case 3: k = sweep_x64_lean_kernel<3>; break;
-    case 4: k = sweep_x64_lean_kernel<4>; break;
-    case 5: case 6: k = sweep_x64_lean_kernel<6>; break;
-    default: k = sweep_x64_lean_kernel<8>; break;        // 7, 8: part of the tables lives in the accumulator registers
+  if (padx) {
+    switch (prog->P) {
+      case 1: k = sweep_x64_lean_kernel<1, true>; break;
+      case 2: k = sweep_x64_lean_kernel<2, true>; break;
+      case 3: k = sweep_x64_lean_kernel<3, true>; break;
+      default: k = sweep_x64_lean_kernel<4, true>; break;
+    }
+  } else {
+    switch (prog->P) {
+      case 1: k = sweep_x64_lean_kernel<1, false>; break;
+      case 2: k = sweep_x64_lean_kernel<2, false>; break;
+      case 3: k = sweep_x64_lean_kernel<3, false>; break;
+      case 4: k = sweep_x64_lean_kernel<4, false>; break;
+      case 5: case 6: k = sweep_x64_lean_kernel<6, false>; break;
+      default: k = sweep_x64_lean_kernel<8, false>; break;        // 7, 8: part of the tables lives in the accumulator registers
+    }
   }
   if (int e = ensure_lds((const void*)k, lds)) return e;
   hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, (hipStream_t)stream, d, f);

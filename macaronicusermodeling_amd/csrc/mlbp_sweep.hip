@@ -1048,10 +1048,13 @@ __global__ __launch_bounds__(WG) void sweep_generic_kernel(SweepDev d) {
   double* scratch = lds + X;    // [4]
   double* lmsg = lds + X + 4;   // [n_msgs][X] when LDSMSG
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (d.only && !d.only[g]) return;
   if (!tables_in_range(d, g)) return;
   double* gm = d.msgs + (size_t)g * d.n_msgs * X;
   double* msg = LDSMSG ? lmsg : gm;
-  if (LDSMSG) {
+  if (d.fill_uniform) {
+    for (int i = t; i < d.n_msgs * X; i += WG) msg[i] = 1.0 / (double)X;
+  } else if (LDSMSG) {
     for (int i = t; i < d.n_msgs * X; i += WG) lmsg[i] = gm[i];
   }
   const int32_t* ptab = d.pair_tab + (size_t)g * d.P;
@@ -1120,28 +1123,47 @@ __global__ __launch_bounds__(WG) void sweep_generic_kernel(SweepDev d) {
 // Table element type TT: double (V = 2 columns per lane and piece) or float (V = 4, the optional f32
 // table mode of SURVEY.md section 8 / BASELINE config 5: half the bytes per update; products and sums stay
 // in float64, so the only difference from the f64 path is the rounding of the table entries themselves).
-template <typename TT, int V> struct WidePiece;
-template <> struct WidePiece<double, 2> {
-  __device__ static __forceinline__ void load(const double* row, int idx, double (&o)[2]) {
+// PAD: 0 = X is exactly 64 V Q; 1 = any even X <= 64 V Q (pieces of a row that reach past X are masked: a pair of
+// columns lies wholly inside or wholly outside the row, and every row starts 16-byte aligned); 2 = any odd X (8-byte
+// loads, masked per column).  Real vocabularies (train_mp.py:591-594: X = len(en_domain)) are not powers of two.
+template <typename TT, int V, int PAD> struct WidePiece;
+template <> struct WidePiece<double, 2, 0> {
+  __device__ static __forceinline__ void load(const double* row, int idx, int, double (&o)[2]) {
     const double2 v = reinterpret_cast<const double2*>(row)[idx];
     o[0] = v.x; o[1] = v.y;
   }
 };
-template <> struct WidePiece<float, 4> {
-  __device__ static __forceinline__ void load(const float* row, int idx, double (&o)[4]) {
+template <> struct WidePiece<double, 2, 1> {
+  __device__ static __forceinline__ void load(const double* row, int idx, int X, double (&o)[2]) {
+    o[0] = 0.0; o[1] = 0.0;
+    if (2 * idx < X) {
+      const double2 v = reinterpret_cast<const double2*>(row)[idx];
+      o[0] = v.x; o[1] = v.y;
+    }
+  }
+};
+template <> struct WidePiece<double, 2, 2> {
+  __device__ static __forceinline__ void load(const double* row, int idx, int X, double (&o)[2]) {
+    o[0] = 2 * idx < X ? row[2 * idx] : 0.0;
+    o[1] = 2 * idx + 1 < X ? row[2 * idx + 1] : 0.0;
+  }
+};
+template <> struct WidePiece<float, 4, 0> {
+  __device__ static __forceinline__ void load(const float* row, int idx, int, double (&o)[4]) {
     const float4 v = reinterpret_cast<const float4*>(row)[idx];
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
   }
 };
 
-template <bool NORM, int Q, typename TT, int V>
+template <bool NORM, int Q, typename TT, int V, int PAD>
 __global__ __launch_bounds__(WG) void sweep_wide_kernel(SweepDev d) {
-  constexpr int X = 64 * V * Q;
+  constexpr int XP = 64 * V * Q;           // padded width
+  const int X = PAD ? d.X : XP;
   extern __shared__ double lds[];
-  double* vin = lds;             // [X] input message of the update in flight
-  double* raw = lds + X;         // [X] un-normalised result
-  double* part = lds + 2 * X;    // [4][X] per-wave column accumulators (MT)
-  double* scratch = part + 4 * X;  // [4]
+  double* vin = lds;             // [XP] input message of the update in flight (zero beyond X)
+  double* raw = lds + XP;        // [XP] un-normalised result
+  double* part = lds + 2 * XP;   // [4][XP] per-wave column accumulators (MT)
+  double* scratch = part + 4 * XP;  // [4]
   const int g = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (!tables_in_range(d, g)) return;
   double* gm = d.msgs + (size_t)g * d.n_msgs * X;
@@ -1156,7 +1178,7 @@ __global__ __launch_bounds__(WG) void sweep_wide_kernel(SweepDev d) {
       if (kind == MLBP_OP_PAIR_TM || kind == MLBP_OP_PAIR_MT) {
         const TT* T = reinterpret_cast<const TT*>(d.pair_tables) + (size_t)ptab[a] * X * X;
         const double* m = gm + (size_t)b * X;
-        for (int j = t; j < X; j += WG) vin[j] = m[j];
+        for (int j = t; j < XP; j += WG) vin[j] = j < X ? m[j] : 0.0;
         __syncthreads();
         if (kind == MLBP_OP_PAIR_TM) {
           double mj[Q][V];
@@ -1167,10 +1189,12 @@ __global__ __launch_bounds__(WG) void sweep_wide_kernel(SweepDev d) {
           for (int i0 = wave; i0 < X; i0 += 16) {          // rows i0, i0+4, i0+8, i0+12 of this wave
             double r[4][Q][V];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
+              const int row = PAD ? min(i0 + 4 * u, X - 1) : i0 + 4 * u;     // past the table: re-read the last row, result dropped
 #pragma unroll
               for (int q = 0; q < Q; ++q)
-                WidePiece<TT, V>::load(T + (size_t)(i0 + 4 * u) * X, 64 * q + lane, r[u][q]);
+                WidePiece<TT, V, PAD>::load(T + (size_t)row * X, 64 * q + lane, X, r[u][q]);
+            }
             double v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -1204,7 +1228,7 @@ __global__ __launch_bounds__(WG) void sweep_wide_kernel(SweepDev d) {
               const int src = ((u >> 1) << 3) | ((u & 1) << 2);
               const double tot = (read_lane(v[0], src) + read_lane(v[0], 16 + src)) +
                                  (read_lane(v[0], 32 + src) + read_lane(v[0], 48 + src));
-              if (lane == 0) raw[i0 + 4 * u] = tot;
+              if (lane == 0 && (!PAD || i0 + 4 * u < X)) raw[i0 + 4 * u] = tot;
             }
           }
         } else {
@@ -1218,10 +1242,11 @@ __global__ __launch_bounds__(WG) void sweep_wide_kernel(SweepDev d) {
             double mi[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              mi[u] = vin[i0 + 4 * u];
+              const int row = PAD ? min(i0 + 4 * u, X - 1) : i0 + 4 * u;
+              mi[u] = (!PAD || i0 + 4 * u < X) ? vin[i0 + 4 * u] : 0.0;
 #pragma unroll
               for (int q = 0; q < Q; ++q)
-                WidePiece<TT, V>::load(T + (size_t)(i0 + 4 * u) * X, 64 * q + lane, r[u][q]);
+                WidePiece<TT, V, PAD>::load(T + (size_t)row * X, 64 * q + lane, X, r[u][q]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -1233,9 +1258,9 @@ __global__ __launch_bounds__(WG) void sweep_wide_kernel(SweepDev d) {
 #pragma unroll
           for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int e = 0; e < V; ++e) part[wave * X + 64 * V * q + V * lane + e] = acc[q][e];
+            for (int e = 0; e < V; ++e) part[wave * XP + 64 * V * q + V * lane + e] = acc[q][e];
           __syncthreads();
-          for (int j = t; j < X; j += WG) raw[j] = (part[j] + part[X + j]) + (part[2 * X + j] + part[3 * X + j]);
+          for (int j = t; j < X; j += WG) raw[j] = (part[j] + part[XP + j]) + (part[2 * XP + j] + part[3 * XP + j]);
         }
       } else if (kind == MLBP_OP_VAR) {
         for (int j = t; j < X; j += WG) {
@@ -1770,6 +1795,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   d.n_sweeps = prog->n_sweeps; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U; d.X = a->X;
   d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables;
   d.marginals = nullptr; d.readout = prog->d_readout; d.n_vars = prog->n_vars;
+  d.only = nullptr; d.fill_uniform = 0;
   if (a->marginals && !prog->d_readout)
     return fail(MLBP_EINVAL, "mlbp_sweep_f64: marginals requested but mlbp_program_set_readout was not called");
   hipStream_t st = (hipStream_t)stream;
@@ -1874,7 +1900,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       return MLBP_OK;
     }
   }
-  if (a->init_messages) {
+  const bool small_lean_candidate = a->X < 64 && a->X >= 2 && norm && prog->sf_ok && prog->P >= 1 && prog->P <= 4 && variant == 1 &&
+                                    !a->gradient && prog->lean.ok && prog->d_limage;
+  if (a->init_messages && !small_lean_candidate) {
     int e = mlbp_init_messages_f64(a->msgs, (int64_t)a->B * prog->n_msgs, a->X, stream);
     if (e) return e;
   }
@@ -1914,17 +1942,34 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     return fail(MLBP_EUNSUPPORTED, "mlbp_sweep_f64: float32 pairwise tables need X = 256 or 512 (got %d)", a->X);
   if (f32_tables && a->gradient)
     return fail(MLBP_EUNSUPPORTED, "mlbp_sweep_f64: no gradient with float32 pairwise tables");
-  if ((a->X == 128 || a->X == 256 || a->X == 512) && (variant != 0 || f32_tables)) {
+  // large state spaces: the wide kernel for X = 128 / 256 / 512 exactly, and (normalised messages, float64 tables) for
+  // any X in (64, 1024] with the last pieces of each row masked
+  const bool wide_exact = a->X == 128 || a->X == 256 || a->X == 512;
+  const bool wide_padded = !wide_exact && !f32_tables && norm && a->X > 64 && a->X <= 1024;
+  if ((wide_exact || wide_padded) && (variant != 0 || f32_tables)) {
     g_last_kernel = MLBP_KERNEL_WIDE;
-    const size_t ldsw = ((size_t)6 * a->X + 4) * sizeof(double);
     void (*kw)(SweepDev) = nullptr;
+    int xp = a->X;
     if (f32_tables) {
       d.pair_tables = reinterpret_cast<const double*>(a->pair_tables_f32);
-      if (a->X == 256) kw = norm ? sweep_wide_kernel<true, 1, float, 4> : sweep_wide_kernel<false, 1, float, 4>;
-      else kw = norm ? sweep_wide_kernel<true, 2, float, 4> : sweep_wide_kernel<false, 2, float, 4>;
-    } else if (a->X == 128) kw = norm ? sweep_wide_kernel<true, 1, double, 2> : sweep_wide_kernel<false, 1, double, 2>;
-    else if (a->X == 256) kw = norm ? sweep_wide_kernel<true, 2, double, 2> : sweep_wide_kernel<false, 2, double, 2>;
-    else kw = norm ? sweep_wide_kernel<true, 4, double, 2> : sweep_wide_kernel<false, 4, double, 2>;
+      if (a->X == 256) kw = norm ? sweep_wide_kernel<true, 1, float, 4, 0> : sweep_wide_kernel<false, 1, float, 4, 0>;
+      else kw = norm ? sweep_wide_kernel<true, 2, float, 4, 0> : sweep_wide_kernel<false, 2, float, 4, 0>;
+    } else if (a->X == 128) kw = norm ? sweep_wide_kernel<true, 1, double, 2, 0> : sweep_wide_kernel<false, 1, double, 2, 0>;
+    else if (a->X == 256) kw = norm ? sweep_wide_kernel<true, 2, double, 2, 0> : sweep_wide_kernel<false, 2, double, 2, 0>;
+    else if (a->X == 512) kw = norm ? sweep_wide_kernel<true, 4, double, 2, 0> : sweep_wide_kernel<false, 4, double, 2, 0>;
+    else {
+      const int q = (a->X + 127) / 128;              // 128-column pieces per row
+      const bool odd = (a->X & 1) != 0;
+#define MLBP_WIDE_PAD(QQ) (kw = odd ? sweep_wide_kernel<true, QQ, double, 2, 2> : sweep_wide_kernel<true, QQ, double, 2, 1>, xp = 128 * QQ)
+      if (q <= 1) MLBP_WIDE_PAD(1);
+      else if (q <= 2) MLBP_WIDE_PAD(2);
+      else if (q <= 3) MLBP_WIDE_PAD(3);
+      else if (q <= 4) MLBP_WIDE_PAD(4);
+      else if (q <= 6) MLBP_WIDE_PAD(6);
+      else MLBP_WIDE_PAD(8);
+#undef MLBP_WIDE_PAD
+    }
+    const size_t ldsw = ((size_t)6 * xp + 4) * sizeof(double);
     hipLaunchKernelGGL(kw, dim3(a->B), dim3(WG), ldsw, st, d);
     HIP_TRY(hipGetLastError());
     if (a->marginals)
@@ -1933,7 +1978,19 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     if (a->gradient) return mlbp_gradient_f64(a->gradient, stream);
     return MLBP_OK;
   }
-  g_last_kernel = MLBP_KERNEL_GENERIC;
+  // small state spaces (X < 64): the lean X = 64 kernel on zero-padded vectors and tables; the graphs it flags are redone
+  // by the generic kernel below in its fix-up mode
+  bool lean_small = false;
+  if (a->X < 64 && a->X >= 2 && norm && prog->sf_ok && prog->P >= 1 && prog->P <= 4 && variant == 1 && !a->gradient) {
+    if (int e = mlbp::launch_lean_sweep(prog, a, stream, &lean_small)) return e;
+    if (lean_small) {
+      d.only = const_cast<mlbp_program*>(prog)->d_bail;
+      d.fill_uniform = a->init_messages;
+    } else if (small_lean_candidate && a->init_messages) {       // the lean kernel declined after all: initialise here
+      if (int e = mlbp_init_messages_f64(a->msgs, (int64_t)a->B * prog->n_msgs, a->X, stream)) return e;
+    }
+  }
+  g_last_kernel = lean_small ? MLBP_KERNEL_LEAN : MLBP_KERNEL_GENERIC;
   size_t base = ((size_t)a->X + 4) * sizeof(double);
   size_t with_msgs = base + (size_t)prog->n_msgs * a->X * sizeof(double);
   if (with_msgs <= 64 * 1024) {

@@ -251,7 +251,7 @@ def test_large_state_shared_tables_run_as_batched_gemms(X):
     try:
         _ffi.check(_ffi.lib.mlbp_set_sweep_variant(3))                             # per-graph kernels on the same inputs
         fb.sweep(roots, init=True, marginals=marg)
-        assert _ffi.lib.mlbp_last_sweep_kernel() == (5 if X == 384 else 4)
+        assert _ffi.lib.mlbp_last_sweep_kernel() == 4             # the wide kernel (X = 384: its padded instance)
     finally:
         _ffi.check(_ffi.lib.mlbp_set_sweep_variant(1))
     np.testing.assert_allclose(got.cpu().numpy(), fb.msgs.cpu().numpy(), rtol=1e-11, atol=1e-300)

@@ -21,6 +21,19 @@
  *     int32 unless stated; matrices are row-major;
  *   - no CPU fallback exists: a device function on a machine without a gfx950 device fails with
  *     MLBP_ENODEVICE.
+ *
+ * Concurrency (what the deployment model -- one process per GPU, train_mp.py:634 -- needs, stated exactly)
+ *   - host functions and mlbp_last_error() are thread-safe; the sweep-kernel diagnostic mlbp_last_sweep_kernel() is
+ *     per calling thread;
+ *   - a mlbp_program belongs to the device that was current when it was created (mlbp_sweep_f64 checks this) and owns
+ *     per-program device state (status word, per-graph redo flags): calls that use the SAME program must be enqueued
+ *     on one stream, or be ordered by the caller;
+ *   - calls with DIFFERENT programs may run on different streams concurrently, with two exceptions that share
+ *     process-wide scratch and must not overlap across streams: the shared-table path at X >= 128 (sweeps and gradient;
+ *     its fragment and product buffers) and mlbp_log_posterior_sum_f64 (its block partials);
+ *   - scratch buffers (redo flags, fragment copies, spill areas) are allocated at the first call that needs them -- that
+ *     call is not enqueue-only; mlbp_program_reserve and one eager step before stream capture move all of it up front;
+ *   - mlbp_set_sweep_variant and the status words behind mlbp_gradient_status are process-wide.
  */
 #ifndef MLBP_H
 #define MLBP_H

@@ -13,6 +13,7 @@ runs ALL sweeps in one fused launch; `graph.messages` is a lazy dict view over t
 There is no CPU fallback.
 """
 import ctypes as C
+import zlib
 import random
 import sys
 import time
@@ -78,6 +79,7 @@ class _Engine:
         self.host_fresh = True
         self.dev_fresh = False
         self._one_op = {}
+        self._table_sig = None
 
     # ---- message mirror -------------------------------------------------------------------------
     def to_host(self):
@@ -95,18 +97,33 @@ class _Engine:
         self.host_fresh = False
         self.dev_fresh = True
 
-    # ---- tables: re-read from the PotentialTables on every run, like the reference does -----------
+    # ---- tables: the reference reads PotentialTable.table afresh on every update, so edits made between two calls
+    #      must be seen -- but re-sending every table for one message update is O(P X^2) bytes over PCIe.  The device
+    #      copies are kept; each call fingerprints the host arrays (address, shape, CRC of the bytes) and re-sends
+    #      only the tables that changed.  An unchanged graph moves no table bytes at all.
+    @staticmethod
+    def _fingerprint(arr):
+        return (arr.ctypes.data, arr.shape, zlib.crc32(arr))
+
     def upload_tables(self):
         t, X = self.topo, self.X
         by_index = {self.topo.factor_index[f.id]: f for f in self.fg.factors}
-        if t.P:
-            pair = np.stack([np.asarray(by_index[j].potential_table.table, dtype=np.float64).reshape(X, X)
-                             for j in t.pair_factors])
-            self.batch.set_pair_tables(pair)
-        if t.U:
-            un = np.stack([np.asarray(by_index[j].potential_table.table, dtype=np.float64).reshape(X)
-                           for j in t.unary_factors])
-            self.batch.set_unary_tables(un)
+        pair = [np.ascontiguousarray(by_index[j].potential_table.table, dtype=np.float64).reshape(X, X) for j in t.pair_factors]
+        un = [np.ascontiguousarray(by_index[j].potential_table.table, dtype=np.float64).reshape(X) for j in t.unary_factors]
+        sig = [self._fingerprint(a) for a in pair + un]
+        if self._table_sig is None:
+            if t.P:
+                self.batch.set_pair_tables(np.stack(pair))
+            if t.U:
+                self.batch.set_unary_tables(np.stack(un))
+        else:
+            for k, a in enumerate(pair):
+                if sig[k] != self._table_sig[k]:
+                    self.batch.pair_tables[k].copy_(torch.from_numpy(a))
+            for k, a in enumerate(un):
+                if sig[t.P + k] != self._table_sig[t.P + k]:
+                    self.batch.unary_tables[k].copy_(torch.from_numpy(a))
+        self._table_sig = sig
         self.batch.normalize_messages = bool(self.fg.normalize_messages)
 
     def run_sweeps(self, roots):
@@ -399,21 +416,19 @@ class VariableNode():
     """LBP.py:336-411."""
 
     def __init__(self, id, var_type, domain_type, domain, supervised_label):
+        # LBP.py:337-352: a non-integer id is only reported; a supervised label outside the domain ends the process
+        # with status -1 (the messages and the exit status are part of the behaviour callers see)
         if not isinstance(id, int):
             print('id ', id, 'not an int')
-        if supervised_label not in domain:
+        try:
+            label_index = domain.index(supervised_label)
+        except ValueError:
             print(supervised_label, 'not in', domain)
-            exit(-1)
-        self.id = id
-        self.var_type = var_type
-        self.domain = domain
-        self.facset = []
-        self.graph = None
-        self.supervised_label = supervised_label
-        self.supervised_label_index = self.domain.index(supervised_label)
-        self.domain_type = domain_type
-        self.truth_label = None
-        self.truth_label_index = None
+            sys.exit(-1)
+        self.id, self.var_type, self.domain_type, self.domain = id, var_type, domain_type, domain
+        self.supervised_label, self.supervised_label_index = supervised_label, label_index
+        self.truth_label = self.truth_label_index = None
+        self.facset, self.graph = [], None
 
     def set_truth_label(self, tl):
         self.truth_label = tl

@@ -1786,6 +1786,12 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     return fail(MLBP_EINVAL, "mlbp_sweep_f64: program has %d unary factors but no unary tables", prog->U);
   if (a->X > 4096) return fail(MLBP_EUNSUPPORTED, "mlbp_sweep_f64: X=%d > 4096", a->X);
   if (int e = check_device()) return e;
+  {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != prog->device)
+      return fail(MLBP_EINVAL, "mlbp_sweep_f64: the program was created on device %d, the calling thread's current device is %d",
+                  prog->device, dev);
+  }
   SweepDev d;
   d.pair_tables = a->pair_tables; d.pair_tab = a->pair_tab;
   d.unary_tables = a->unary_tables; d.unary_tab = a->unary_tab;
@@ -2136,7 +2142,13 @@ int mlbp_log_posterior_sum_f64(const double* marginals, const int32_t* labels, i
   const int blocks = (B + 127) / 128;
   if (sum_out && blocks > LP_MAX_BLOCKS)
     return fail(MLBP_EUNSUPPORTED, "mlbp_log_posterior_sum_f64: at most %d graphs with sum_out", LP_MAX_BLOCKS * 128);
-  // the block partials live in one device-wide scratch array: launches on DIFFERENT streams must not overlap
+  // the block partials live in one device-wide scratch array: launches on DIFFERENT streams must not overlap.  The
+  // arrival counter is re-armed on the stream before every launch, so a launch that was aborted cannot wedge the next
+  if (sum_out) {
+    static unsigned* done_addr = nullptr;
+    if (!done_addr) HIP_TRY(hipGetSymbolAddress((void**)&done_addr, HIP_SYMBOL(g_lp_done)));
+    HIP_TRY(hipMemsetAsync(done_addr, 0, sizeof(unsigned), (hipStream_t)stream));
+  }
   hipLaunchKernelGGL(log_posterior_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, marginals, labels, B, n_vars, X, out,
                      sum_out, status);
   HIP_TRY(hipGetLastError());

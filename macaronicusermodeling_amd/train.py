@@ -302,8 +302,12 @@ class TiDirTrainer:
     params written in the reference's text format."""
 
     def __init__(self, ti_path, en_vocab, de_vocab, phi_pmi, phi_pmi_w1, phi_ed, phi_ped, device='cuda:0', sweeps=3,
-                 rank=0, world=1, use_planes=True, adapt=None, domains=None, reg_param_ua_scale=1.0):
-        """adapt: None, 'user' (--user_adapt: domain = ti.user_id) or 'experience' (--experience_adapt: domain =
+                 rank=0, world=1, use_planes=True, adapt=None, domains=None, reg_param_ua_scale=1.0,
+                 use_correct_feat=True, history=True, session_history=True):
+        """use_planes switches the three per-instance feature planes on as a whole; use_correct_feat / history /
+        session_history gate them one by one as the reference's options of the same names do (train_mp.py:178, 192,
+        206: the 'correct', 'full_history' and 'hit_history' planes).
+        adapt: None, 'user' (--user_adapt: domain = ti.user_id) or 'experience' (--experience_adapt: domain =
         len(ti.past_sentences_seen)), train_mp.py:162-171; `domains`: the domain names in file order (the
         reference reads <ti>.users / <ti>.experience, train_mp.py:504-516) -- default: the names that occur."""
         from . import tidir
@@ -341,8 +345,8 @@ class TiDirTrainer:
                 extra = dict(domains=dom[order], theta_dom_en_en=self.theta_dom_en_en, theta_dom_en_de=self.theta_dom_en_de)
             planes = None
             if use_planes:
-                feat = {'correct': tidir.ED_NAMES.index('correct'), 'full_history': tidir.ED_NAMES.index('full_history'),
-                        'hit_history': tidir.ED_NAMES.index('hit_history')}
+                feat = {name: tidir.ED_NAMES.index(name)
+                        for name, on in (('correct', use_correct_feat), ('full_history', history), ('hit_history', session_history)) if on}
                 planes = []
                 for r in b['rows']:
                     cells = {}
@@ -378,8 +382,11 @@ class TiDirTrainer:
 
     def train(self, epochs=3, reg_param=0.2, save_params=None):
         """lr = 0.1 / (1 + 0.3 epoch) (train_mp.py:627-630); regularisation reg_param / N (train_mp.py:160);
-        params saved as <save_params>.iter<epoch> and <save_params> (train_mp.py:654-656, 688-690)."""
+        params saved as <save_params><ext>.iter<epoch> and <save_params><ext> with ext = '.user_adapt' / '.exp_adapt' /
+        '' by adapt mode (train_mp.py:654-656, 688-690)."""
         from . import tidir
+        if save_params:
+            save_params = save_params + {'user': '.user_adapt', 'experience': '.exp_adapt', None: ''}[self.adapt]
         history = []
         for epoch in range(epochs):
             history.append(self.epoch(0.1 / (1.0 + 0.3 * epoch), float(reg_param) / float(self.n_total)))

@@ -383,8 +383,10 @@ def test_tidir_trainer_user_adapt(tmp_path):
             ee, ed = O.unregularized_gradient(g, inp, msgs)
             row = np.concatenate([ee.reshape(-1), ed.reshape(-1), [O.log_posterior(g, msgs), 1.0]])
             tot[0] += row; tot[1 + tt.domains.index(str(r['user_id']))] += row
-    save = os.path.join(str(tmp_path), 'params.user_adapt')
+    save = os.path.join(str(tmp_path), 'params')
     hist = tt.train(epochs=1, reg_param=0.2, save_params=save)
+    assert os.path.exists(save + '.user_adapt.iter0')            # train_mp.py:653-654: the adapt mode is part of the file name
+    save = save + '.user_adapt'
     np.testing.assert_allclose(hist[0], tot[0, 9] / 30, rtol=1e-9)
     np.testing.assert_allclose(tt.theta_en_de.cpu().numpy(), 0.1 * tot[0, 3:9], rtol=1e-8, atol=1e-11)
     for d in range(D):

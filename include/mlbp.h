@@ -227,6 +227,14 @@ typedef struct mlbp_sweep_args {
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
 
+/* A minibatch of mixed graphs in one go: n_groups (program, arguments) pairs -- every group its own topology, root
+ * sequence (the reference draws a fresh root per instance and sweep, LBP.py:223-225, and builds a different K_n per
+ * instance, train_mp.py:257-299), tables and message buffer.  Equivalent to calling mlbp_sweep_f64 on the groups one
+ * after the other; when every group qualifies for the fast X = 64 kernel (float64 tables, normalised messages, at most
+ * 8 pairwise factors, no gradient, the same init / write-back / read-out choices, distinct programs) that kernel runs
+ * ALL groups in a single launch, followed by one small fix-up launch per group.  progs / args are HOST arrays. */
+int mlbp_sweep_groups_f64(const mlbp_program* const* progs, const mlbp_sweep_args* args, int32_t n_groups, void* stream);
+
 /* Kernel-variant selector for A/B measurement (not needed in normal use; also settable through the
  * MLBP_SWEEP_VARIANT environment variable):
  *   1     default: for X = 64 the scale-free kernel (messages carried with an exact power-of-two

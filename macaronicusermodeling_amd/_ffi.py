@@ -80,6 +80,7 @@ SIGNATURES = {
     'mlbp_program_status': (C.c_int, [_vp]),
     'mlbp_set_sweep_variant': (C.c_int, [_i32]),
     'mlbp_sweep_f64': (C.c_int, [_vp, C.POINTER(SweepArgs), _vp]),
+    'mlbp_sweep_groups_f64': (C.c_int, [C.POINTER(_vp), C.POINTER(SweepArgs), _i32, _vp]),
     'mlbp_init_messages_f64': (C.c_int, [_vp, _i64, _i32, _vp]),
     'mlbp_marginals_f64': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     'mlbp_log_posterior_f64': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),

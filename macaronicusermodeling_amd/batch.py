@@ -134,7 +134,7 @@ class FactorGraphBatch:
             self._programs[key] = Program(self.topo, key, max_graphs=self.B)
         return self._programs[key]
 
-    def sweep(self, roots, init=False, marginals=None, gradient=None, keep_messages=True):
+    def sweep(self, roots, init=False, marginals=None, gradient=None, keep_messages=True, _collect=None):
         """Runs len(roots) sweeps, sweep s rooted at variable id roots[s], on every graph, in one
         launch.  init=True starts from uniform messages (initialize() fused into the launch);
         marginals: optional [B][n_vars][X] device tensor that receives every variable's marginal
@@ -179,6 +179,9 @@ class FactorGraphBatch:
         if gradient is not None:
             ga = self._gradient_args(*gradient)
             a.gradient = C.addressof(ga)
+        if _collect is not None:                  # sweep_groups(): gather instead of launching
+            _collect.append((prog, a, gradient and ga))
+            return prog
         _ffi.check(_ffi.lib.mlbp_sweep_f64(prog.handle, C.byref(a), _stream_ptr(self.device)))
         return prog
 
@@ -386,3 +389,24 @@ class FactorGraphBatch:
         _ffi.check(_ffi.lib.mlbp_sum_rows_f64(t2.data_ptr(), t2.shape[0], t2.shape[1], out.data_ptr(),
                                               _stream_ptr(self.device)))
         return out
+
+
+def sweep_groups(batches, roots, init=False, marginals=None, keep_messages=True):
+    """One minibatch of mixed graphs: batches[k] (a FactorGraphBatch: one topology, its tables and messages) is swept
+    with its own root sequence roots[k] -- the reference draws roots per instance (LBP.py:223-225) and builds a
+    different K_n per instance (train_mp.py:257-299).  Same results as batches[k].sweep(roots[k], ...) one by one; when
+    every group qualifies, the fast kernel runs them all in ONE launch (mlbp_sweep_groups_f64).
+    marginals: None or one [B_k][n_vars_k][X] tensor per group."""
+    if len(batches) != len(roots) or not batches:
+        raise ValueError('one root sequence per batch')
+    dev = batches[0].device
+    got = []
+    for k, fb in enumerate(batches):
+        if fb.device != dev:
+            raise ValueError('all groups live on one device')
+        fb.sweep(roots[k], init=init, marginals=None if marginals is None else marginals[k], keep_messages=keep_messages, _collect=got)
+    n = len(got)
+    handles = (C.c_void_p * n)(*[p.handle for p, _, _ in got])
+    args = (_ffi.SweepArgs * n)(*[a for _, a, _ in got])
+    _ffi.check(_ffi.lib.mlbp_sweep_groups_f64(handles, args, n, _stream_ptr(dev)))
+    return [p for p, _, _ in got]

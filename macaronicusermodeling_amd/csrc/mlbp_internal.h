@@ -36,6 +36,8 @@ bool build_lean_readout(const LeanProgram& lp, int n_msgs, int n_vars, const int
                         std::vector<int32_t>& image);
 // Enqueues the lean scale-free kernel when it applies (sets *launched); flagged graphs are left in prog->d_bail.
 int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched);
+// The same for several (program, arguments) groups in one launch; *launched false = some group does not qualify.
+int launch_lean_groups(const mlbp_program* const* progs, const mlbp_sweep_args* args, int n_groups, void* stream, bool* launched);
 
 // Shared-table (MFMA) form, mlbp_shared.hip: 16 graphs per workgroup, messages kept as [state][graph]
 // tiles in LDS, only the "live" slots (read or written inside the sweeps) resident.

@@ -20,6 +20,7 @@
 // One barrier per bundle of (at most two independent) updates, as before.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <vector>
 
 #include "mlbp_device.h"
@@ -45,6 +46,7 @@ constexpr int UOP_PSLOT_SHIFT = 2;  // bits 2-4: pair slot (register-resident ta
 constexpr int UOP_NOP = 32;         // bit 5: empty second slot of a bundle
 constexpr int UOP_STORE_VF = 64;    // bit 6: the variable->factor message is stored (word 5)
 constexpr int UOP_NSRC_SHIFT = 8;   // bits 8-11: number of sources (1..4)
+constexpr int GROUP_WORDS = 48;     // one group descriptor of a MULTI launch (see launch_lean_groups)
 // micro-op words: 0 flags | 1-4 source byte offsets | 5 byte offset of the variable->factor message to store, or -1 |
 // 6 destination byte offset | 7 unused.  A bundle = two micro-ops = 16 words = one s_load_dwordx16.
 
@@ -203,14 +205,39 @@ __device__ __forceinline__ double rescale(double r, int& bad) {
 }
 
 // PADX: X = d.X < 64 states, vectors and tables zero-padded to 64 on the way in, the first X entries written back.
-template <int NT, bool PADX>
-__global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x64_lean_kernel(SweepDev d, LeanDev f) {
+// MULTI: the launch holds several GROUPS of graphs -- each group its own program (topology and root sequence), tables,
+// messages -- described by a device table; the workgroup looks its group up and from then on runs as if launched for
+// that group alone.  This is what lets a minibatch of mixed sentence shapes, each with its own roots (LBP.py:223-225,
+// train_mp.py:257-299), sweep in one launch.
+template <int NT, bool PADX, bool MULTI>
+__global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x64_lean_kernel(SweepDev d, LeanDev f, const int32_t* groups,
+                                                                                             int n_groups) {
+  int g = blockIdx.x;
+  if (MULTI) {
+    // groups[k * GROUP_WORDS] = first graph of group k (ascending): the last k with start <= g
+    int lo = 0, hi = n_groups - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (as_const(groups)[(size_t)mid * GROUP_WORDS] <= g) lo = mid; else hi = mid - 1;
+    }
+    const int32_t* G = groups + (size_t)lo * GROUP_WORDS;
+    const Words16 w0 = sload16(G), w1 = sload16(G + 16), w2 = sload16(G + 32);
+    auto ptr = [](int32_t a, int32_t b) { return (uintptr_t)(uint32_t)a | ((uintptr_t)(uint32_t)b << 32); };
+    g -= w0.w[0];
+    f.image = (const int32_t*)ptr(w0.w[2], w0.w[3]); f.readout = (const int32_t*)ptr(w0.w[4], w0.w[5]);
+    f.bail = (uint8_t*)ptr(w0.w[6], w0.w[7]); d.msgs = (double*)ptr(w0.w[8], w0.w[9]);
+    d.marginals = (double*)ptr(w0.w[10], w0.w[11]); d.pair_tables = (const double*)ptr(w0.w[12], w0.w[13]);
+    d.pair_tab = (const int32_t*)ptr(w0.w[14], w0.w[15]); d.unary_tables = (const double*)ptr(w1.w[0], w1.w[1]);
+    d.unary_tab = (const int32_t*)ptr(w1.w[2], w1.w[3]); d.status = (int32_t*)ptr(w1.w[4], w1.w[5]);
+    f.n_bundles = w1.w[6]; f.HL = w1.w[7]; f.n_cprod = w1.w[8]; f.WL = w1.w[9]; f.n_ext = w1.w[10];
+    d.n_msgs = w1.w[11]; d.P = w1.w[12]; d.U = w1.w[13]; d.n_vars = w1.w[14]; d.n_pair_tables = w1.w[15];
+    d.n_unary_tables = w2.w[0]; f.dense = w2.w[1];
+  }
   extern __shared__ double lds[];
   double* work = lds;                                        // [n_msgs + n_ext][64] scaled messages
   double* red = lds + (size_t)(d.n_msgs + f.n_ext) * 64;     // [2 parities][2 bundle slots][4][64]
   int32_t* limg = reinterpret_cast<int32_t*>(red + 4 * 256);      // [n_bundles + 1][16] micro-ops
 
-  const int g = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int X = PADX ? d.X : 64;
   const double uniform = 1.0 / (double)X;
@@ -690,8 +717,9 @@ extern "C" int mlbp_debug_lean_probe(int mask, void* buf) {
 }
 #endif
 
-int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched) {
-  *launched = false;
+// Does the lean kernel apply to this (program, arguments) pair?  Fills the device-side descriptions when it does.
+static int lean_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, SweepDev* d, LeanDev* f, size_t* lds) {
+  *ok = false;
   const LeanProgram& lp = prog->lean;
   if (!lp.ok || !prog->d_limage || a->X > 64 || a->X < 2 || !a->normalize_messages || prog->P < 1 || prog->P > 8) return MLBP_OK;
   const bool padx = a->X < 64;
@@ -699,50 +727,117 @@ int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* 
   if (a->gradient) return MLBP_OK;                // the fused gradient epilogue lives in the older kernels
   if (a->marginals && !prog->d_lreadout && !padx) return MLBP_OK;
   const int n_ext = 2 + lp.n_cprod;               // uniform, the constant products, ones
-  const size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 256) * sizeof(double) + 16 * (size_t)(lp.n_bundles + 1) * sizeof(int32_t);
-  if (lds > 64 * 1024) return MLBP_OK;            // large graphs: the older kernels' rules apply
+  *lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 256) * sizeof(double) + 16 * (size_t)(lp.n_bundles + 1) * sizeof(int32_t);
+  if (*lds > 64 * 1024) return MLBP_OK;           // large graphs: the older kernels' rules apply
   const bool dense = (a->flags & MLBP_SWEEP_DENSE_TABLES) != 0;
   if (dense && ((int64_t)a->B * prog->P > a->n_pair_tables || (int64_t)a->B * prog->U > a->n_unary_tables))
     return fail(MLBP_EINVAL, "mlbp_sweep_f64: MLBP_SWEEP_DENSE_TABLES needs B*P pair tables and B*U unary columns");
   mlbp_program* mp = const_cast<mlbp_program*>(prog);
   if (mp->bail_cap < a->B)
     if (int e = mlbp_program_reserve(mp, a->B)) return e;
-  SweepDev d;
-  d.pair_tables = a->pair_tables; d.pair_tab = a->pair_tab;
-  d.unary_tables = a->unary_tables; d.unary_tab = a->unary_tab;
-  d.msgs = a->msgs;
-  d.ops = nullptr; d.srcs = nullptr; d.sweeps = nullptr; d.pairseq = nullptr;
-  d.status = prog->d_status;
-  d.n_sweeps = prog->n_sweeps; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U; d.X = a->X;
-  d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables;
-  d.marginals = padx ? nullptr : a->marginals; d.readout = nullptr; d.n_vars = prog->n_vars;
-  d.only = nullptr; d.fill_uniform = 0;
-  LeanDev f;
-  f.image = prog->d_limage; f.readout = (a->marginals && !padx) ? prog->d_lreadout : nullptr; f.bail = mp->d_bail;
-  f.n_bundles = lp.n_bundles; f.HL = lp.HL; f.n_cprod = lp.n_cprod; f.WL = lp.WL;
-  f.n_ext = n_ext; f.init = a->init_messages; f.dense = dense ? 1 : 0;
+  d->pair_tables = a->pair_tables; d->pair_tab = a->pair_tab;
+  d->unary_tables = a->unary_tables; d->unary_tab = a->unary_tab;
+  d->msgs = a->msgs;
+  d->ops = nullptr; d->srcs = nullptr; d->sweeps = nullptr; d->pairseq = nullptr;
+  d->status = prog->d_status;
+  d->n_sweeps = prog->n_sweeps; d->n_msgs = prog->n_msgs; d->P = prog->P; d->U = prog->U; d->X = a->X;
+  d->n_pair_tables = a->n_pair_tables; d->n_unary_tables = a->n_unary_tables;
+  d->marginals = padx ? nullptr : a->marginals; d->readout = nullptr; d->n_vars = prog->n_vars;
+  d->only = nullptr; d->fill_uniform = 0;
+  f->image = prog->d_limage; f->readout = (a->marginals && !padx) ? prog->d_lreadout : nullptr; f->bail = mp->d_bail;
+  f->n_bundles = lp.n_bundles; f->HL = lp.HL; f->n_cprod = lp.n_cprod; f->WL = lp.WL;
+  f->n_ext = n_ext; f->init = a->init_messages; f->dense = dense ? 1 : 0;
   // the messages go back to memory unless the caller waives them and takes the fused read-out instead
-  f.keep = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && a->marginals && !padx) ? 0 : 1;     // (small X: the read-out is a separate launch over the messages)
-  void (*k)(SweepDev, LeanDev) = nullptr;
+  f->keep = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && a->marginals && !padx) ? 0 : 1;     // (small X: the read-out is a separate launch over the messages)
+  *ok = true;
+  return MLBP_OK;
+}
+
+template <bool MULTI>
+static void (*pick_lean(int P, bool padx))(SweepDev, LeanDev, const int32_t*, int) {
   if (padx) {
-    switch (prog->P) {
-      case 1: k = sweep_x64_lean_kernel<1, true>; break;
-      case 2: k = sweep_x64_lean_kernel<2, true>; break;
-      case 3: k = sweep_x64_lean_kernel<3, true>; break;
-      default: k = sweep_x64_lean_kernel<4, true>; break;
-    }
-  } else {
-    switch (prog->P) {
-      case 1: k = sweep_x64_lean_kernel<1, false>; break;
-      case 2: k = sweep_x64_lean_kernel<2, false>; break;
-      case 3: k = sweep_x64_lean_kernel<3, false>; break;
-      case 4: k = sweep_x64_lean_kernel<4, false>; break;
-      case 5: case 6: k = sweep_x64_lean_kernel<6, false>; break;
-      default: k = sweep_x64_lean_kernel<8, false>; break;        // 7, 8: part of the tables lives in the accumulator registers
+    switch (P) {
+      case 1: return sweep_x64_lean_kernel<1, true, MULTI>;
+      case 2: return sweep_x64_lean_kernel<2, true, MULTI>;
+      case 3: return sweep_x64_lean_kernel<3, true, MULTI>;
+      default: return sweep_x64_lean_kernel<4, true, MULTI>;
     }
   }
+  switch (P) {
+    case 1: return sweep_x64_lean_kernel<1, false, MULTI>;
+    case 2: return sweep_x64_lean_kernel<2, false, MULTI>;
+    case 3: return sweep_x64_lean_kernel<3, false, MULTI>;
+    case 4: return sweep_x64_lean_kernel<4, false, MULTI>;
+    case 5: case 6: return sweep_x64_lean_kernel<6, false, MULTI>;
+    default: return sweep_x64_lean_kernel<8, false, MULTI>;       // 7, 8: part of the tables lives in the accumulator registers
+  }
+}
+
+int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched) {
+  *launched = false;
+  SweepDev d;
+  LeanDev f;
+  size_t lds = 0;
+  bool ok = false;
+  if (int e = lean_plan(prog, a, &ok, &d, &f, &lds)) return e;
+  if (!ok) return MLBP_OK;
+  void (*k)(SweepDev, LeanDev, const int32_t*, int) = pick_lean<false>(prog->P, a->X < 64);
   if (int e = ensure_lds((const void*)k, lds)) return e;
-  hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, (hipStream_t)stream, d, f);
+  hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, (hipStream_t)stream, d, f, nullptr, 0);
+  HIP_TRY(hipGetLastError());
+  *launched = true;
+  return MLBP_OK;
+}
+
+// Several (program, arguments) groups in ONE launch of the lean kernel.  *launched stays false when some group does not
+// qualify (the caller then runs the groups one by one).  The group table lives in a process-wide device buffer that
+// is rewritten, stream-ordered, by every call: calls on different streams must not overlap.
+int launch_lean_groups(const mlbp_program* const* progs, const mlbp_sweep_args* args, int n_groups, void* stream, bool* launched) {
+  *launched = false;
+  if (n_groups < 1) return MLBP_OK;
+  std::vector<int32_t> table((size_t)n_groups * GROUP_WORDS, 0);
+  size_t lds_max = 0;
+  int p_max = 0, total = 0;
+  SweepDev d0;
+  LeanDev f0;
+  for (int k = 0; k < n_groups; ++k) {
+    if (!progs[k] || args[k].X != 64) return MLBP_OK;
+    for (int j = 0; j < k; ++j)
+      if (progs[j] == progs[k]) return MLBP_OK;      // two groups would share one set of redo flags
+    SweepDev d;
+    LeanDev f;
+    size_t lds = 0;
+    bool ok = false;
+    if (int e = lean_plan(progs[k], &args[k], &ok, &d, &f, &lds)) return e;
+    if (!ok) return MLBP_OK;
+    if (k == 0) { d0 = d; f0 = f; }
+    else if (f.init != f0.init || f.keep != f0.keep || (f.readout != nullptr) != (f0.readout != nullptr)) return MLBP_OK;
+    lds_max = std::max(lds_max, lds);
+    p_max = std::max(p_max, (int)progs[k]->P);
+    int32_t* w = &table[(size_t)k * GROUP_WORDS];
+    auto put = [&](int at, const void* p) { const uintptr_t v = (uintptr_t)p; w[at] = (int32_t)(uint32_t)v; w[at + 1] = (int32_t)(uint32_t)(v >> 32); };
+    w[0] = total; w[1] = args[k].B;
+    put(2, f.image); put(4, f.readout); put(6, f.bail); put(8, d.msgs); put(10, d.marginals); put(12, d.pair_tables);
+    put(14, d.pair_tab); put(16, d.unary_tables); put(18, d.unary_tab); put(20, d.status);
+    w[22] = f.n_bundles; w[23] = f.HL; w[24] = f.n_cprod; w[25] = f.WL; w[26] = f.n_ext; w[27] = d.n_msgs; w[28] = d.P; w[29] = d.U;
+    w[30] = d.n_vars; w[31] = d.n_pair_tables; w[32] = d.n_unary_tables; w[33] = f.dense;
+    total += args[k].B;
+  }
+  static int32_t* d_table = nullptr;
+  static size_t cap = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (table.size() > cap) {
+    if (d_table) (void)hipFree(d_table);
+    d_table = nullptr; cap = 0;
+    HIP_TRY(hipMalloc(&d_table, table.size() * sizeof(int32_t)));
+    cap = table.size();
+  }
+  HIP_TRY(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));        // the host vector is about to go away (pageable copy: already staged; belt and braces)
+  void (*k)(SweepDev, LeanDev, const int32_t*, int) = pick_lean<true>(p_max, false);
+  if (int e = ensure_lds((const void*)k, lds_max)) return e;
+  hipLaunchKernelGGL(k, dim3(total), dim3(WG), lds_max, (hipStream_t)stream, d0, f0, d_table, n_groups);
   HIP_TRY(hipGetLastError());
   *launched = true;
   return MLBP_OK;

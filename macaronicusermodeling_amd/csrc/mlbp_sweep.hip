@@ -1571,6 +1571,7 @@ void build_fused_program(const int32_t* ops_in, const int32_t* srcs, const int32
 // tables (N = 0 streams).
 int g_sweep_variant = -1;
 thread_local int g_last_kernel = -1;       // mlbp_last_sweep_kernel()
+thread_local bool g_lean_predone = false;  // set by mlbp_sweep_groups_f64 around the per-group fix-up calls
 int sweep_variant() {
   if (g_sweep_variant < 0) {
     const char* e = getenv("MLBP_SWEEP_VARIANT");
@@ -1847,11 +1848,12 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
         }
       }
       bool shared_done = false;                // shared-table batches: 16 graphs per workgroup on the matrix cores
-      if (variant == 1 || variant == 2 || variant == 30)
+      if ((variant == 1 || variant == 2 || variant == 30) && !g_lean_predone)
         if (int e = mlbp::launch_shared_sweep(prog, a, stream, &shared_done)) return e;
       if (shared_done) { want_sf = false; grad_fused = false; gf = GradFusedDev{}; }
       bool lean_done = false;                  // default scale-free path: the lean kernel (mlbp_lean.hip), up to 8 resident tables
-      if (norm && prog->sf_ok && prog->P >= 1 && prog->P <= 8 && !shared_done && variant == 1)
+      if (g_lean_predone) lean_done = true;     // mlbp_sweep_groups_f64 ran the lean kernel for this group already
+      else if (norm && prog->sf_ok && prog->P >= 1 && prog->P <= 8 && !shared_done && variant == 1)
         if (int e = mlbp::launch_lean_sweep(prog, a, stream, &lean_done)) return e;
       g_last_kernel = shared_done ? MLBP_KERNEL_SHARED_MFMA : (lean_done ? MLBP_KERNEL_LEAN : (want_sf ? MLBP_KERNEL_SCALE_FREE : MLBP_KERNEL_EXACT));
       if (want_sf && !lean_done) {
@@ -2012,6 +2014,20 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
                                    prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;
   if (a->gradient) return mlbp_gradient_f64(a->gradient, stream);
   return MLBP_OK;
+}
+
+int mlbp_sweep_groups_f64(const mlbp_program* const* progs, const mlbp_sweep_args* args, int32_t n_groups, void* stream) {
+  if (!progs || !args || n_groups < 1) return fail(MLBP_EINVAL, "mlbp_sweep_groups_f64: bad arguments");
+  bool one_launch = false;
+  if (sweep_variant() == 1)
+    if (int e = mlbp::launch_lean_groups(progs, args, n_groups, stream, &one_launch)) return e;
+  // the fast kernel has run every group (one_launch): what is left per group is the fix-up pass over the graphs it
+  // flagged; otherwise the groups run one after the other exactly as separate calls would
+  int rc = MLBP_OK;
+  g_lean_predone = one_launch;
+  for (int k = 0; k < n_groups && rc == MLBP_OK; ++k) rc = mlbp_sweep_f64(progs[k], &args[k], stream);
+  g_lean_predone = false;
+  return rc;
 }
 
 #ifdef MLBP_ABLATE

@@ -217,6 +217,14 @@ class UserGraphTrainer:
         self.build_potentials()
         fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg, gradient=(self._g_ee, self._g_ed),
                  keep_messages=False)
+        return self._statistics_after_sweep()
+
+    def _statistics_after_sweep(self, gradient_from_messages=False):
+        """Everything of the step behind the sweeps: gradient (when the sweep launch did not produce it: from the
+        messages in memory), the per-instance plane shares, log-posteriors, the batch sums."""
+        fb = self.batch
+        if gradient_from_messages:
+            fb.gradient(self._g_ee, self._g_ed)
         self._patch_gradient()
         _ffi.check(_ffi.lib.mlbp_log_posterior_f64(self._marg.data_ptr(), fb._labels.data_ptr(), fb.B, self.topo.n_vars,
                                                    fb.X, self._lp.data_ptr(), _stream_ptr(self.device)))
@@ -303,7 +311,7 @@ class TiDirTrainer:
 
     def __init__(self, ti_path, en_vocab, de_vocab, phi_pmi, phi_pmi_w1, phi_ed, phi_ped, device='cuda:0', sweeps=3,
                  rank=0, world=1, use_planes=True, adapt=None, domains=None, reg_param_ua_scale=1.0,
-                 use_correct_feat=True, history=True, session_history=True):
+                 use_correct_feat=True, history=True, session_history=True, grouped_sweeps='auto'):
         """use_planes switches the three per-instance feature planes on as a whole; use_correct_feat / history /
         session_history gate them one by one as the reference's options of the same names do (train_mp.py:178, 192,
         206: the 'correct', 'full_history' and 'hit_history' planes).
@@ -314,6 +322,7 @@ class TiDirTrainer:
         if adapt not in (None, 'user', 'experience'):
             raise ValueError("adapt is None, 'user' or 'experience'")
         self.adapt, self.reg_param_ua_scale = adapt, float(reg_param_ua_scale)
+        self.grouped_sweeps = grouped_sweeps
         self.en, self.de = tidir.read_vocab(en_vocab), tidir.read_vocab(de_vocab)
         phi_ee, phi_w1, phi_ed_t = tidir.load_features(phi_pmi, phi_pmi_w1, phi_ed, phi_ped)
         instances = tidir.read_instances(ti_path)
@@ -368,10 +377,31 @@ class TiDirTrainer:
             d2t['en_de', d] = self.theta_dom_en_de[i].cpu().numpy().reshape(1, -1)
         return d2t
 
-    def epoch(self, learning_rate, reg_param):
+    def local_statistics(self):
+        """Sum of the buckets' statistics.  grouped_sweeps: the sweeps of ALL sentence shapes in one launch
+        (batch.sweep_groups -> mlbp_sweep_groups_f64: every bucket its own topology and roots) instead of one
+        launch sequence per bucket -- what a minibatch of many small buckets wants; large buckets are better off on
+        their own shared-table launches (the default 'auto' switches at 1024 instances per bucket on average)."""
         self.stats.zero_()
-        for tr in self.trainers.values():
-            self.stats += tr.local_statistics()
+        trs = list(self.trainers.values())
+        n_inst = sum(tr.batch.B for tr in trs)
+        grouped = self.grouped_sweeps is True or (self.grouped_sweeps == 'auto' and len(trs) > 1 and n_inst < 1024 * len(trs))
+        grouped = grouped and all(tr.topo.P >= 1 and tr.batch.X == 64 for tr in trs)
+        if not grouped:
+            for tr in trs:
+                self.stats += tr.local_statistics()
+            return self.stats
+        from .batch import sweep_groups
+        for tr in trs:
+            tr.build_potentials()
+        sweep_groups([tr.batch for tr in trs], [tr.roots[:tr.n_sweeps_run] for tr in trs], init=True,
+                     marginals=[tr._marg for tr in trs])
+        for tr in trs:
+            self.stats += tr._statistics_after_sweep(gradient_from_messages=True)
+        return self.stats
+
+    def epoch(self, learning_rate, reg_param):
+        self.local_statistics()
         mdist.all_reduce_sum_(self.stats)                   # global and per-domain statistics in ONE reduction
         n, F_ee, F_ed = self.n_stat, len(self.theta_en_en), len(self.theta_en_de)
         apply_update(self.theta_en_en, self.theta_en_de, self.stats[:n], F_ee, F_ed, learning_rate, reg_param)

@@ -399,3 +399,26 @@ def test_tidir_trainer_user_adapt(tmp_path):
     tt.epoch(0.1, 0.2 / 30)
     assert not torch.equal(before, tt.theta_dom_en_de)
     assert float((tt.theta_dom_en_de[0] - tt.theta_dom_en_de[1]).abs().max()) > 0
+
+
+def test_tidir_trainer_sweeps_all_sentence_shapes_in_one_launch(tmp_path):
+    """TiDirTrainer(grouped_sweeps=True): the sweeps of every bucket (its own topology and roots) run as ONE launch of
+    the fast kernel (mlbp_sweep_groups_f64), the gradient then reads the messages from memory.  Same statistics as
+    the per-bucket launch sequences, and training moves theta the same way."""
+    from macaronicusermodeling_amd import _ffi, tidir
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    paths = tidir.synthesize(str(tmp_path), n_instances=40, X=64, Vde=64, sent_len=(4, 7), n_predicted=(2, 3), seed=21)
+    mk = lambda grouped: TiDirTrainer(paths['ti'], paths['end'], paths['ded'], paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'],
+                                      paths['phi_ped'], sweeps=3, grouped_sweeps=grouped)
+    a, b = mk(True), mk(False)
+    assert len(a.buckets) > 2
+    for t in (a, b):                                   # away from theta = 0, where every pot is the all-ones table
+        t.theta_en_en += torch.tensor([0.3, -0.2, 0.1], dtype=torch.float64, device=t.theta_en_en.device)
+        t.theta_en_de += torch.tensor([0.2, 0.1, -0.3, 0.05, 0.0, 0.1], dtype=torch.float64, device=t.theta_en_de.device)
+    sa = a.local_statistics().clone()
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 7       # the lean kernel ran the groups
+    sb = b.local_statistics().clone()
+    np.testing.assert_allclose(sa.cpu().numpy(), sb.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    ha, hb = a.train(epochs=2, reg_param=0.2), b.train(epochs=2, reg_param=0.2)
+    np.testing.assert_allclose(ha, hb, rtol=1e-9)
+    np.testing.assert_allclose(a.theta_en_de.cpu().numpy(), b.theta_en_de.cpu().numpy(), rtol=1e-8, atol=1e-12)

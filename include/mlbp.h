@@ -224,6 +224,12 @@ typedef struct mlbp_sweep_args {
  * the table loads.  The arrays must still be valid: the statement is checked on the device off the critical path,
  * and a graph for which it does not hold is computed by the exact kernel through the arrays. */
 #define MLBP_SWEEP_DENSE_TABLES 8
+/* flags: FactorGraph.use_approx_inference (LBP.py:506-507, 515-516): a pairwise factor->variable update uses only the
+ * MLBP_APPROX_K = 100 largest entries of the incoming message (au.sparse_vec_mat_dot, c_array_utils.pyx:193-205).
+ * Batched: the selection runs on the device inside the sweep launch (rank by value, ties by lower index).
+ * 100 <= X <= 1024; smaller X fails like the reference's argpartition ("kth out of bounds"). */
+#define MLBP_SWEEP_APPROX_INFERENCE 16
+#define MLBP_APPROX_K 100
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
 
@@ -346,6 +352,10 @@ typedef struct mlbp_gradient_args {
  * contracted on the matrix cores ((T (.) phi_k) . r, four contractions per factor).  Groups of 16 graphs for
  * which the claim does not hold are computed one graph at a time inside the same kernel (correct, slower). */
 #define MLBP_GRADIENT_SHARED_PAIR_TABLES 1
+/* flags: FactorGraph.use_approx_beliefs (LBP.py:554-563): a pairwise factor's beliefs live on the block of the
+ * MLBP_APPROX_K largest entries of its two incoming messages (au.sparse_dot, sparse_pointwise_multiply,
+ * sparse_normalize, c_array_utils.pyx:108-129, 23-26).  X >= MLBP_APPROX_K. */
+#define MLBP_GRADIENT_APPROX_BELIEFS 2
 int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream);
 
 /* A unary factor's belief is normalize(table) (LBP.py:540) whatever the messages say, so its expected

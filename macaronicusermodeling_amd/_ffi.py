@@ -52,7 +52,10 @@ SWEEP_SHARED_PAIR_TABLES = 1      # include/mlbp.h MLBP_SWEEP_*
 SWEEP_NO_MESSAGE_WRITEBACK = 2
 SWEEP_PAIR_TABLES_F32 = 4
 SWEEP_DENSE_TABLES = 8
+SWEEP_APPROX_INFERENCE = 16
+APPROX_K = 100
 GRADIENT_SHARED_PAIR_TABLES = 1
+GRADIENT_APPROX_BELIEFS = 2
 
 
 _i32p = C.POINTER(C.c_int32)

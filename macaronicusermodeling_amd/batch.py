@@ -60,7 +60,7 @@ class Program:
 
 
 class FactorGraphBatch:
-    def __init__(self, topo, X, B, device='cuda:0', normalize_messages=True):
+    def __init__(self, topo, X, B, device='cuda:0', normalize_messages=True, use_approx_inference=False, use_approx_beliefs=False):
         if not isinstance(topo, GraphTopology):
             raise TypeError('topo must be a GraphTopology')
         self.topo, self.X, self.B = topo, int(X), int(B)
@@ -68,6 +68,8 @@ class FactorGraphBatch:
         if self.device.type != 'cuda':
             raise ValueError('FactorGraphBatch lives on an MI355X; there is no CPU path')
         self.normalize_messages = bool(normalize_messages)
+        # FactorGraph.use_approx_inference / use_approx_beliefs (LBP.py:52-53): top-100 variants, selected on the device
+        self.use_approx_inference, self.use_approx_beliefs = bool(use_approx_inference), bool(use_approx_beliefs)
         self.msgs = torch.empty(self.B, topo.n_msgs, self.X, dtype=torch.float64, device=self.device)
         self.pair_tables = self.pair_tab = self.unary_tables = self.unary_tab = None
         self._in_off = torch.from_numpy(topo.in_off).to(self.device)
@@ -164,6 +166,8 @@ class FactorGraphBatch:
         a.msgs = self.msgs.data_ptr()
         a.normalize_messages = 1 if self.normalize_messages else 0
         a.init_messages = 1 if init else 0
+        if self.use_approx_inference:
+            a.flags |= _ffi.SWEEP_APPROX_INFERENCE
         if (getattr(self, '_pair_dense', False) or not self.topo.P) and (getattr(self, '_unary_dense', False) or not self.topo.U):
             a.flags |= _ffi.SWEEP_DENSE_TABLES
         if getattr(self, 'pair_tables_shared', False):
@@ -355,7 +359,9 @@ class FactorGraphBatch:
         if getattr(self, 'use_planar', True):
             a.phi_en_en_p, a.phi_en_en_w1_p = (p.data_ptr() for p in self._phi_p)
         a.grad_en_en, a.grad_en_de = out_ee.data_ptr(), out_ed.data_ptr()
-        if getattr(self, 'pair_tables_shared', False) and getattr(self, 'use_shared_gradient', True):
+        if self.use_approx_beliefs:
+            a.flags |= _ffi.GRADIENT_APPROX_BELIEFS
+        if getattr(self, 'pair_tables_shared', False) and getattr(self, 'use_shared_gradient', True) and not self.use_approx_beliefs:
             a.flags |= _ffi.GRADIENT_SHARED_PAIR_TABLES
             if getattr(self, '_pair_row_host', None) is not None:
                 a.pair_tab_host = self._pair_row_host.ctypes.data

@@ -105,6 +105,8 @@ struct SweepDev {
   // messages when fill_uniform is set (FactorGraph.initialize fused)
   const uint8_t* only;
   int32_t fill_uniform;
+  int32_t approx_k;            // > 0: use_approx_inference (LBP.py:506-507, 515-516): only the approx_k largest entries of the
+                               // incoming message enter a pairwise update (au.sparse_vec_mat_dot, c_array_utils.pyx:193-205)
 };
 
 }  // namespace mlbp_dev

@@ -82,6 +82,25 @@ __device__ void pair_gradient(const GradDev& d, int g, int p, double* scratch, d
   const double* phi = a.pair_phi[p] ? a.phi_en_en_w1 : a.phi_en_en;
   const double* c = a.msgs + ((size_t)g * a.n_msgs + a.pair_c_slot[p]) * X;
   const double* r = a.msgs + ((size_t)g * a.n_msgs + a.pair_r_slot[p]) * X;
+  if (a.flags & MLBP_GRADIENT_APPROX_BELIEFS) {
+    // use_approx_beliefs (LBP.py:554-563; au.sparse_dot / sparse_pointwise_multiply / sparse_normalize): beliefs live on
+    // the block of the K largest entries of c times the K largest of r -- the other entries of both vectors are dropped
+    extern __shared__ double kept[];                 // [2][X]
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * X; j += WG) {
+      const double* v = j < X ? c : r;
+      const int jj = j < X ? j : j - X;
+      const double x = v[jj];
+      int rank = 0;
+      for (int i = 0; i < X; ++i) {
+        const double y = v[i];
+        rank += (y > x) || (y == x && i < jj);
+      }
+      kept[j] = rank < MLBP_APPROX_K ? x : 0.0;
+    }
+    __syncthreads();
+    c = kept; r = kept + X;
+  }
   double acc[F + 1];
 #pragma unroll
   for (int k = 0; k <= F; ++k) acc[k] = 0.0;
@@ -506,6 +525,8 @@ int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream) {
   d.skip_pairs = 0;
   if (int e = status_word(&d.status)) return e;
   hipStream_t st = (hipStream_t)stream;
+  if (a->X == 64 && (a->flags & MLBP_GRADIENT_APPROX_BELIEFS))
+    return fail(MLBP_EINVAL, "mlbp_gradient_f64: approximate beliefs keep the %d largest entries; kth(=%d) out of bounds (64)", MLBP_APPROX_K, MLBP_APPROX_K - 1);
   if (a->X == 64) {
     // shared pairwise tables: the pairwise factors of 16 graphs at a time on the matrix cores, after the unary part
     const bool shared = (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->F_ee == 3 && a->P > 0 && a->n_pair_tables <= 32 && a->phi_en_en_p && a->phi_en_en_w1_p;
@@ -519,13 +540,18 @@ int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream) {
     if (shared) return mlbp::launch_shared_pair_gradient(a, d.status, stream);
     return MLBP_OK;
   }
-  // shared pairwise tables at a large state space: pairwise part as DGEMMs over the whole batch (mlbp_gemm.hip)
-  const bool gemm_pairs = (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->pair_tab_host && mlbp::gemm_path_supports(a->X) && a->F_ee == 3 &&
+  const bool approx = (a->flags & MLBP_GRADIENT_APPROX_BELIEFS) != 0;
+  if (approx && a->X < MLBP_APPROX_K)
+    return fail(MLBP_EINVAL, "mlbp_gradient_f64: approximate beliefs keep the %d largest entries; kth(=%d) out of bounds (%d)",
+                MLBP_APPROX_K, MLBP_APPROX_K - 1, a->X);
+  const size_t dyn = approx ? 2 * (size_t)a->X * sizeof(double) : 0;
+  // shared pairwise tables at a large state space: pairwise part as MFMA contractions over the whole batch (mlbp_gemm.hip)
+  const bool gemm_pairs = !approx && (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->pair_tab_host && mlbp::gemm_path_supports(a->X) && a->F_ee == 3 &&
                           a->P > 0 && a->P <= 16 && a->phi_en_en_p && a->phi_en_en_w1_p && mlbp::gemm_path_ready() == MLBP_OK;
   d.skip_pairs = gemm_pairs ? 1 : 0;
-  if (a->F_ee == 3) hipLaunchKernelGGL((gradient_kernel<3, 6>), dim3(a->B), dim3(WG), 0, st, d);
-  else if (a->F_ee == 2) hipLaunchKernelGGL((gradient_kernel<2, 2>), dim3(a->B), dim3(WG), 0, st, d);
-  else hipLaunchKernelGGL((gradient_kernel<1, 1>), dim3(a->B), dim3(WG), 0, st, d);
+  if (a->F_ee == 3) hipLaunchKernelGGL((gradient_kernel<3, 6>), dim3(a->B), dim3(WG), dyn, st, d);
+  else if (a->F_ee == 2) hipLaunchKernelGGL((gradient_kernel<2, 2>), dim3(a->B), dim3(WG), dyn, st, d);
+  else hipLaunchKernelGGL((gradient_kernel<1, 1>), dim3(a->B), dim3(WG), dyn, st, d);
   HIP_TRY(hipGetLastError());
   if (gemm_pairs) return mlbp::launch_gemm_pair_gradient(a, d.status, stream);
   return MLBP_OK;

@@ -725,6 +725,7 @@ static int lean_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* o
   const bool padx = a->X < 64;
   if (padx && prog->P > 4) return MLBP_OK;
   if (a->gradient) return MLBP_OK;                // the fused gradient epilogue lives in the older kernels
+  if (a->flags & MLBP_SWEEP_APPROX_INFERENCE) return MLBP_OK;
   if (a->marginals && !prog->d_lreadout && !padx) return MLBP_OK;
   const int n_ext = 2 + lp.n_cprod;               // uniform, the constant products, ones
   *lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 256) * sizeof(double) + 16 * (size_t)(lp.n_bundles + 1) * sizeof(int32_t);
@@ -743,7 +744,7 @@ static int lean_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* o
   d->n_sweeps = prog->n_sweeps; d->n_msgs = prog->n_msgs; d->P = prog->P; d->U = prog->U; d->X = a->X;
   d->n_pair_tables = a->n_pair_tables; d->n_unary_tables = a->n_unary_tables;
   d->marginals = padx ? nullptr : a->marginals; d->readout = nullptr; d->n_vars = prog->n_vars;
-  d->only = nullptr; d->fill_uniform = 0;
+  d->only = nullptr; d->fill_uniform = 0; d->approx_k = 0;
   f->image = prog->d_limage; f->readout = (a->marginals && !padx) ? prog->d_lreadout : nullptr; f->bail = mp->d_bail;
   f->n_bundles = lp.n_bundles; f->HL = lp.HL; f->n_cprod = lp.n_cprod; f->WL = lp.WL;
   f->n_ext = n_ext; f->init = a->init_messages; f->dense = dense ? 1 : 0;

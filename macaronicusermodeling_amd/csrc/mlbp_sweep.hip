@@ -1180,6 +1180,23 @@ __global__ __launch_bounds__(WG) void sweep_wide_kernel(SweepDev d) {
         const double* m = gm + (size_t)b * X;
         for (int j = t; j < XP; j += WG) vin[j] = j < X ? m[j] : 0.0;
         __syncthreads();
+        if (d.approx_k > 0) {
+          // use_approx_inference: keep the K largest entries of the message (rank by value, ties by index: the rule of
+          // mlbp_topk_f64), zero the rest -- sum over the index set, as au.sparse_vec_mat_dot does
+          double* keep = part;
+          for (int j = t; j < X; j += WG) {
+            const double x = vin[j];
+            int rank = 0;
+            for (int i = 0; i < X; ++i) {
+              const double y = vin[i];
+              rank += (y > x) || (y == x && i < j);
+            }
+            keep[j] = rank < d.approx_k ? x : 0.0;
+          }
+          __syncthreads();
+          for (int j = t; j < X; j += WG) vin[j] = keep[j];
+          __syncthreads();
+        }
         if (kind == MLBP_OP_PAIR_TM) {
           double mj[Q][V];
 #pragma unroll
@@ -1786,6 +1803,12 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   if (prog->U > 0 && (!a->unary_tables || !a->unary_tab || a->n_unary_tables <= 0))
     return fail(MLBP_EINVAL, "mlbp_sweep_f64: program has %d unary factors but no unary tables", prog->U);
   if (a->X > 4096) return fail(MLBP_EUNSUPPORTED, "mlbp_sweep_f64: X=%d > 4096", a->X);
+  const bool approx = (a->flags & MLBP_SWEEP_APPROX_INFERENCE) != 0;
+  if (approx && a->X < MLBP_APPROX_K)      // np.argpartition(-vec, K - 1) in the reference: "kth(=99) out of bounds"
+    return fail(MLBP_EINVAL, "mlbp_sweep_f64: approximate inference keeps the %d largest entries; kth(=%d) out of bounds (%d)",
+                MLBP_APPROX_K, MLBP_APPROX_K - 1, a->X);
+  if (approx && !(a->X > 64 && a->X <= 1024 && a->normalize_messages && !(a->flags & MLBP_SWEEP_PAIR_TABLES_F32)))
+    return fail(MLBP_EUNSUPPORTED, "mlbp_sweep_f64: batched approximate inference needs 100 <= X <= 1024, normalised messages, float64 tables");
   if (int e = check_device()) return e;
   {
     int dev = -1;
@@ -1802,7 +1825,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   d.n_sweeps = prog->n_sweeps; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U; d.X = a->X;
   d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables;
   d.marginals = nullptr; d.readout = prog->d_readout; d.n_vars = prog->n_vars;
-  d.only = nullptr; d.fill_uniform = 0;
+  d.only = nullptr; d.fill_uniform = 0; d.approx_k = 0;
   if (a->marginals && !prog->d_readout)
     return fail(MLBP_EINVAL, "mlbp_sweep_f64: marginals requested but mlbp_program_set_readout was not called");
   hipStream_t st = (hipStream_t)stream;
@@ -1929,7 +1952,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       return MLBP_OK;
     }
   }
-  if ((a->flags & MLBP_SWEEP_SHARED_PAIR_TABLES) && a->pair_tab_host && mlbp::gemm_path_supports(a->X) &&
+  if ((a->flags & MLBP_SWEEP_SHARED_PAIR_TABLES) && a->pair_tab_host && mlbp::gemm_path_supports(a->X) && !approx &&
       prog->P >= 1 && prog->P <= 16 && (variant == 1 || variant == 2 || variant == 30)) {
     // shared tables at a large state space: every contraction is one MFMA launch over the whole batch
     if ((a->flags & MLBP_SWEEP_PAIR_TABLES_F32) && a->gradient)
@@ -1952,6 +1975,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     return fail(MLBP_EUNSUPPORTED, "mlbp_sweep_f64: no gradient with float32 pairwise tables");
   // large state spaces: the wide kernel for X = 128 / 256 / 512 exactly, and (normalised messages, float64 tables) for
   // any X in (64, 1024] with the last pieces of each row masked
+  d.approx_k = approx ? MLBP_APPROX_K : 0;
   const bool wide_exact = a->X == 128 || a->X == 256 || a->X == 512;
   const bool wide_padded = !wide_exact && !f32_tables && norm && a->X > 64 && a->X <= 1024;
   if ((wide_exact || wide_padded) && (variant != 0 || f32_tables)) {

@@ -422,3 +422,63 @@ def test_tidir_trainer_sweeps_all_sentence_shapes_in_one_launch(tmp_path):
     ha, hb = a.train(epochs=2, reg_param=0.2), b.train(epochs=2, reg_param=0.2)
     np.testing.assert_allclose(ha, hb, rtol=1e-9)
     np.testing.assert_allclose(a.theta_en_de.cpu().numpy(), b.theta_en_de.cpu().numpy(), rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.parametrize('case', C.approx_cases(), ids=lambda c: c['name'])
+def test_batched_approximate_inference_and_beliefs(case):
+    """use_approx_inference / use_approx_beliefs batched (FactorGraphBatch(use_approx_*=True)): the top-100 selection
+    runs on the device inside the sweep launch (one launch for all sweeps) and inside the gradient kernel -- no
+    per-update round trip as in the object API.  Graph 0 against the fixture the reference itself produced with both
+    switches on (messages, marginals, gradient: the selected index SETS must be the reference's for these to agree),
+    the other graphs against the oracle in approximate mode."""
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.batch import FactorGraphBatch
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = case['spec']
+    gold = load_golden(case['name'])
+    topo = GraphTopology.from_spec(spec)
+    nb = 4
+    inputs = case_inputs(case, nb)
+    has_phi = 'phi_en_en' in inputs[0]
+    if has_phi:
+        for i in inputs[1:]:
+            for k in ('phi_en_en', 'phi_en_en_w1', 'phi_en_de'):
+                i[k] = inputs[0][k]
+    pair, unary = batch_tables(spec, topo, inputs)
+    fb = FactorGraphBatch(topo, spec['X'], nb, use_approx_inference=True, use_approx_beliefs=True)
+    fb.set_pair_tables(pair)
+    fb.set_unary_tables(unary)
+    roots = case['roots'][:max(case['snaps'])]
+    marg = torch.empty(nb, topo.n_vars, spec['X'], dtype=torch.float64, device=fb.device)
+    prog = fb.sweep(roots, init=True, marginals=marg)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 4 and prog.status() == 0        # the wide kernel, selection fused in
+    got = fb.msgs.cpu().numpy()
+    np.testing.assert_allclose(got[0], gold['msgs_s%d' % max(case['snaps'])], rtol=1e-10, atol=1e-300)
+    np.testing.assert_allclose(marg[0].cpu().numpy(), gold['marginals'], rtol=1e-10, atol=1e-300)
+    g = O.Graph(spec)
+    for b in range(1, nb):
+        msgs = O.init_messages(g)
+        for r in roots:
+            O.sweep(g, inputs[b], msgs, r, True)
+        want = np.stack([msgs[k] for k in C.msg_keys(spec)]).reshape(got[b].shape)
+        np.testing.assert_allclose(got[b], want, rtol=1e-10, atol=1e-300)
+    if has_phi:
+        pair_phi, kinds, obs, labels = _meta(spec, topo)
+        fb.set_features(inputs[0]['phi_en_en'], inputs[0]['phi_en_en_w1'], inputs[0]['phi_en_de'], pair_phi, kinds)
+        fb.set_observations(np.tile(labels, (nb, 1)), np.tile(obs, (nb, 1)))
+        g_ee, g_ed = fb.gradient()
+        assert _ffi.lib.mlbp_gradient_status() == 0
+        np.testing.assert_allclose(g_ee[0].cpu().numpy(), gold['grad_unreg_en_en'].reshape(-1), rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(g_ed[0].cpu().numpy(), gold['grad_unreg_en_de'].reshape(-1), rtol=1e-8, atol=1e-11)
+        for b in range(1, nb):
+            msgs = O.init_messages(g)
+            for r in roots:
+                O.sweep(g, inputs[b], msgs, r, True)
+            ee, ed = O.unregularized_gradient(g, inputs[b], msgs, True)
+            np.testing.assert_allclose(g_ee[b].cpu().numpy(), ee.reshape(-1), rtol=1e-8, atol=1e-11)
+            np.testing.assert_allclose(g_ed[b].cpu().numpy(), ed.reshape(-1), rtol=1e-8, atol=1e-11)
+    # too few states for a top-100: the reference's argpartition raises; so does the batched switch
+    small = FactorGraphBatch(GraphTopology.from_spec(C.ring_spec(4, 64)), 64, 2, use_approx_inference=True)
+    small.set_pair_tables(np.ones((8, 64, 64))); small.set_unary_tables(np.ones((8, 64)))
+    with pytest.raises(_ffi.MlbpError, match='out of bounds'):
+        small.sweep([0], init=True)

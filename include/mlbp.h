@@ -194,7 +194,7 @@ typedef struct mlbp_sweep_args {
   const int32_t* pair_tab_host;
                               /* HOST int32 [P] or NULL: with MLBP_SWEEP_SHARED_PAIR_TABLES, the pair_tab row
                                  every graph has.  Needed for X >= 128, where the sweeps then run op by op
-                                 over the whole batch with one DGEMM (rocBLAS) per factor->variable update;
+                                 over the whole batch with one hand-written MFMA contraction launch per factor->variable update;
                                  the statement is checked on the device, a false one raises
                                  mlbp_program_status to 2                                            */
   const float* pair_tables_f32;
@@ -342,7 +342,7 @@ typedef struct mlbp_gradient_args {
   double* grad_en_de;           /* out [B][F_ed]                                                    */
   int32_t flags;                /* MLBP_GRADIENT_* bits                                              */
   const int32_t* pair_tab_host; /* HOST int32 [P] or NULL: with MLBP_GRADIENT_SHARED_PAIR_TABLES and X >= 128 the
-                                   pairwise factors become four DGEMMs each over the whole batch         */
+                                   pairwise factors become four MFMA contractions each over the whole batch         */
   const double* unary_expect;   /* optional [n_unary_tables][8] from mlbp_unary_expectations_f64: with
                                    MLBP_GRADIENT_SHARED_PAIR_TABLES the unary factors then cost one
                                    gather per factor instead of a reduction over the states           */

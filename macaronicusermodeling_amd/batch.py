@@ -172,7 +172,7 @@ class FactorGraphBatch:
             a.flags |= _ffi.SWEEP_DENSE_TABLES
         if getattr(self, 'pair_tables_shared', False):
             a.flags |= _ffi.SWEEP_SHARED_PAIR_TABLES
-            if getattr(self, '_pair_row_host', None) is not None:       # X >= 128: op-by-op DGEMM path needs the row on the host
+            if getattr(self, '_pair_row_host', None) is not None:       # X >= 128: the update-by-update contraction path needs the row on the host
                 a.pair_tab_host = self._pair_row_host.ctypes.data
             if not keep_messages and (marginals is not None or gradient is not None):
                 a.flags |= _ffi.SWEEP_NO_MESSAGE_WRITEBACK

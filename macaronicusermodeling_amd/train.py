@@ -95,7 +95,7 @@ class UserGraphTrainer:
         ptab = np.tile(np.array(pair_phi or [0], dtype=np.int64), (B, 1)) + 2 * self._dom_host[:, None]
         fb.pair_tab = torch.from_numpy(ptab.astype(np.int32)).to(dev)
         fb.pair_tables_shared = bool(topo.P)      # every instance reads the two pots: the MFMA kernels apply
-        # one row for every instance (no per-domain pots): at X >= 128 the sweeps can run as batched DGEMMs
+        # one row for every instance (no per-domain pots): at X >= 128 the sweeps can run as batched MFMA contractions
         fb._pair_row_host = np.ascontiguousarray(ptab[0], dtype=np.int32) if (topo.P and not self.n_dom) else None
         obs = obs_np
         base = np.array([0, X, 2 * X], dtype=np.int64)[np.array(unary_kind, dtype=np.int64)] if topo.U else np.zeros(0)

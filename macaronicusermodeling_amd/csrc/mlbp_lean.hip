@@ -542,6 +542,8 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
 
 int ensure_lds(const void* fn, size_t bytes) {
   static std::vector<std::pair<const void*, size_t>> granted;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
   for (auto& g : granted)
     if (g.first == fn && g.second >= bytes) return MLBP_OK;
   HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));

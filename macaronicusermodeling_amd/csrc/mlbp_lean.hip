@@ -116,8 +116,18 @@ __device__ __forceinline__ void mul2(double2& a, const double2 b) { a.x *= b.x; 
 
 // One table (T[r][k] = rows 4R + r, column pair k ^ b3) against one input vector; u = the micro-op's 8 words (scalars).
 // u0 = flags (wave-uniform scalar); s1..s4, vf = source / store byte offsets (same in every lane, kept in VGPRs).
-template <bool MT>
-__device__ __forceinline__ void contract(const double2 (&T)[4][2], char* wb, int u0, int s1, int s2, int s3, int s4, int vf,
+// A table held in registers, or -- the (NT+1)-th table of a 7-table graph -- in LDS as [r * 2 + k][thread] double2.
+struct RegTable {
+  const double2 (&T)[4][2];
+  __device__ __forceinline__ double2 operator()(int r, int k) const { return T[r][k]; }
+};
+struct LdsTable {
+  const double2* base;                      // this thread's column of the image
+  __device__ __forceinline__ double2 operator()(int r, int k) const { return base[(r * 2 + k) * WG]; }
+};
+
+template <bool MT, typename TB>
+__device__ __forceinline__ void contract(const TB T, char* wb, int u0, int s1, int s2, int s3, int s4, int vf,
                                          const LaneGeo& G, char* redA) {
   const int nsrc = (u0 >> UOP_NSRC_SHIFT) & 15;
   const bool has_vf = (u0 & UOP_STORE_VF) != 0;
@@ -136,10 +146,11 @@ __device__ __forceinline__ void contract(const double2 (&T)[4][2], char* wb, int
       *reinterpret_cast<double2*>(wb + vf + G.mt) = ma;
       *reinterpret_cast<double2*>(wb + vf + G.mt + 16) = mb;
     }
-    double a00 = ma.x * T[0][0].x, a01 = ma.x * T[0][0].y, a10 = ma.x * T[0][1].x, a11 = ma.x * T[0][1].y;
-    a00 += ma.y * T[1][0].x; a01 += ma.y * T[1][0].y; a10 += ma.y * T[1][1].x; a11 += ma.y * T[1][1].y;
-    a00 += mb.x * T[2][0].x; a01 += mb.x * T[2][0].y; a10 += mb.x * T[2][1].x; a11 += mb.x * T[2][1].y;
-    a00 += mb.y * T[3][0].x; a01 += mb.y * T[3][0].y; a10 += mb.y * T[3][1].x; a11 += mb.y * T[3][1].y;
+    double a00, a01, a10, a11;
+    { const double2 t0 = T(0, 0), t1 = T(0, 1); a00 = ma.x * t0.x; a01 = ma.x * t0.y; a10 = ma.x * t1.x; a11 = ma.x * t1.y; }
+    { const double2 t0 = T(1, 0), t1 = T(1, 1); a00 += ma.y * t0.x; a01 += ma.y * t0.y; a10 += ma.y * t1.x; a11 += ma.y * t1.y; }
+    { const double2 t0 = T(2, 0), t1 = T(2, 1); a00 += mb.x * t0.x; a01 += mb.x * t0.y; a10 += mb.x * t1.x; a11 += mb.x * t1.y; }
+    { const double2 t0 = T(3, 0), t1 = T(3, 1); a00 += mb.y * t0.x; a01 += mb.y * t0.y; a10 += mb.y * t1.x; a11 += mb.y * t1.y; }
     // rows: lane bit 3 (partner l ^ 8 keeps the other column pair in its register 0), lane bit 5, then the waves
     a00 += dpp_mov<0x128>(a10);
     a01 += dpp_mov<0x128>(a11);
@@ -162,10 +173,11 @@ __device__ __forceinline__ void contract(const double2 (&T)[4][2], char* wb, int
     double v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      v[r] = T[r][0].x * m0.x;
-      v[r] += T[r][0].y * m0.y;
-      v[r] += T[r][1].x * m1.x;
-      v[r] += T[r][1].y * m1.y;
+      const double2 t0 = T(r, 0), t1 = T(r, 1);
+      v[r] = t0.x * m0.x;
+      v[r] += t0.y * m0.y;
+      v[r] += t1.x * m1.x;
+      v[r] += t1.y * m1.y;
     }
     // columns: lane bit 4 (rows of 16 lanes exchange registers), lane bit 2 (select), lane bits 1 and 0 (plain)
     const double u0 = swapadd16(v[0], v[2]), u1 = swapadd16(v[1], v[3]);
@@ -177,16 +189,21 @@ __device__ __forceinline__ void contract(const double2 (&T)[4][2], char* wb, int
   }
 }
 
-template <int NT>
-__device__ __forceinline__ void front(const double2 (&tab)[NT][4][2], char* wb, int u0, const int4& lo, const int4& hi, const LaneGeo& G,
-                                      char* redA) {
+template <int NT, int NL>
+__device__ __forceinline__ void front(const double2 (&tab)[NT][4][2], const double2* tl, char* wb, int u0, const int4& lo, const int4& hi,
+                                      const LaneGeo& G, char* redA) {
   const int pslot = (u0 >> UOP_PSLOT_SHIFT) & 7;
 #pragma unroll
   for (int p = 0; p < NT; ++p) {
     if (p == pslot) {
-      if (u0 & UOP_MT) contract<true>(tab[p], wb, u0, lo.y, lo.z, lo.w, hi.x, hi.y, G, redA);
-      else contract<false>(tab[p], wb, u0, lo.y, lo.z, lo.w, hi.x, hi.y, G, redA);
+      if (u0 & UOP_MT) contract<true>(RegTable{tab[p]}, wb, u0, lo.y, lo.z, lo.w, hi.x, hi.y, G, redA);
+      else contract<false>(RegTable{tab[p]}, wb, u0, lo.y, lo.z, lo.w, hi.x, hi.y, G, redA);
     }
+  }
+  if (NL > 0 && pslot >= NT) {
+    const LdsTable T = {tl + (size_t)(pslot - NT) * 8 * WG};
+    if (u0 & UOP_MT) contract<true>(T, wb, u0, lo.y, lo.z, lo.w, hi.x, hi.y, G, redA);
+    else contract<false>(T, wb, u0, lo.y, lo.z, lo.w, hi.x, hi.y, G, redA);
   }
 }
 
@@ -209,8 +226,10 @@ __device__ __forceinline__ double rescale(double r, int& bad) {
 // messages -- described by a device table; the workgroup looks its group up and from then on runs as if launched for
 // that group alone.  This is what lets a minibatch of mixed sentence shapes, each with its own roots (LBP.py:223-225,
 // train_mp.py:257-299), sweep in one launch.
-template <int NT, bool PADX, bool MULTI>
-__global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x64_lean_kernel(SweepDev d, LeanDev f, const int32_t* groups,
+// NL: tables NT .. NT+NL-1 of the graph live in LDS instead of registers (a 7-table chain then fits 242 VGPRs + 70 KB, so two
+// workgroups share a CU, where 8 register-resident tables allow one).
+template <int NT, bool PADX, bool MULTI, int NL>
+__global__ __launch_bounds__(WG, (NT >= 7 ? 1 : (NT >= 4 ? 2 : 3))) void sweep_x64_lean_kernel(SweepDev d, LeanDev f, const int32_t* groups,
                                                                                              int n_groups) {
   int g = blockIdx.x;
   if (MULTI) {
@@ -237,6 +256,7 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
   double* work = lds;                                        // [n_msgs + n_ext][64] scaled messages
   double* red = lds + (size_t)(d.n_msgs + f.n_ext) * 64;     // [2 parities][2 bundle slots][4][64]
   int32_t* limg = reinterpret_cast<int32_t*>(red + 4 * 256);      // [n_bundles + 1][16] micro-ops
+  double2* tl = reinterpret_cast<double2*>(limg + 16 * (f.n_bundles + 1));      // [NL][8][256] tables kept in LDS
 
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int X = PADX ? d.X : 64;
@@ -310,6 +330,25 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
             tab[p][r][k].y = (row < X && col + 1 < X) ? T[(size_t)row * X + col + 1] : 0.0;
           }
       }
+    }
+  }
+  // tables NT .. NT+NL-1: straight into LDS (LDS-DMA: no registers; lane l of a wave-instruction lands at base + 16 l, which
+  // is exactly the [r * 2 + k][thread] image), waited for with the register tables before the sweeps start
+#pragma unroll
+  for (int p = NT; p < NT + NL; ++p) {
+    if (p < d.P && !PADX) {
+      const int ti = f.dense ? g * d.P + p : as_const(d.pair_tab)[(size_t)g * d.P + p];
+      if ((unsigned)ti >= (unsigned)d.n_pair_tables) { ok = false; continue; }
+      const double* T = d.pair_tables + (size_t)ti * 4096 + (size_t)(4 * R_) * 64 + 2 * c_;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          typedef __attribute__((address_space(3))) void* lds_ptr;
+          typedef const __attribute__((address_space(1))) void* glb_ptr;
+          double2* dst = tl + ((p - NT) * 8 + r * 2 + k) * WG + wave * 64;          // wave-uniform
+          __builtin_amdgcn_global_load_lds((glb_ptr)(T + r * 64 + 32 * (k ? 1 - b3_ : b3_)), (lds_ptr)dst, 16, 0, 0);
+        }
     }
   }
   // MLBP_SWEEP_DENSE_TABLES is a statement about the index arrays; it is checked off the critical path (the loads
@@ -411,6 +450,7 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
 
   // ---- main loop: identical in all four waves; one barrier per bundle.  The micro-ops sit in LDS; a bundle's 16 words
   //      are read (broadcast) one bundle ahead ----
+  if (NL > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA tables have landed (the barrier below publishes them)
 #pragma unroll
   for (int q = 0; q < PW; ++q)
     if (t + q * WG < 16 * (f.n_bundles + 1)) limg[t + q * WG] = pre[q];
@@ -433,9 +473,9 @@ __global__ __launch_bounds__(WG, (NT >= 5 ? 1 : (NT == 4 ? 2 : 3))) void sweep_x
       work[(A1.y >> 3) + lane] = m;
     } else {
       char* redP = reinterpret_cast<char*>(red) + parity * 4096;
-      front<NT>(tab, wb, fA, A0, A1, G, redP);
+      front<NT, NL>(tab, tl + t, wb, fA, A0, A1, G, redP);
       const bool two = !(fB & UOP_NOP);
-      if (two) front<NT>(tab, wb, fB, B0, B1, G, redP + 2048);
+      if (two) front<NT, NL>(tab, tl + t, wb, fB, B0, B1, G, redP + 2048);
       lds_barrier();
       const double* rd = reinterpret_cast<const double*>(redP);
       double rA = rd[lane];
@@ -731,7 +771,8 @@ static int lean_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* o
   if (a->marginals && !prog->d_lreadout && !padx) return MLBP_OK;
   const int n_ext = 2 + lp.n_cprod;               // uniform, the constant products, ones
   *lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 256) * sizeof(double) + 16 * (size_t)(lp.n_bundles + 1) * sizeof(int32_t);
-  if (*lds > 64 * 1024) return MLBP_OK;           // large graphs: the older kernels' rules apply
+  if (prog->P == 7 && !padx) *lds += 32 * 1024;   // the seventh table lives in LDS
+  if (*lds > 80 * 1024) return MLBP_OK;           // large graphs: the older kernels' rules apply
   const bool dense = (a->flags & MLBP_SWEEP_DENSE_TABLES) != 0;
   if (dense && ((int64_t)a->B * prog->P > a->n_pair_tables || (int64_t)a->B * prog->U > a->n_unary_tables))
     return fail(MLBP_EINVAL, "mlbp_sweep_f64: MLBP_SWEEP_DENSE_TABLES needs B*P pair tables and B*U unary columns");
@@ -760,19 +801,20 @@ template <bool MULTI>
 static void (*pick_lean(int P, bool padx))(SweepDev, LeanDev, const int32_t*, int) {
   if (padx) {
     switch (P) {
-      case 1: return sweep_x64_lean_kernel<1, true, MULTI>;
-      case 2: return sweep_x64_lean_kernel<2, true, MULTI>;
-      case 3: return sweep_x64_lean_kernel<3, true, MULTI>;
-      default: return sweep_x64_lean_kernel<4, true, MULTI>;
+      case 1: return sweep_x64_lean_kernel<1, true, MULTI, 0>;
+      case 2: return sweep_x64_lean_kernel<2, true, MULTI, 0>;
+      case 3: return sweep_x64_lean_kernel<3, true, MULTI, 0>;
+      default: return sweep_x64_lean_kernel<4, true, MULTI, 0>;
     }
   }
   switch (P) {
-    case 1: return sweep_x64_lean_kernel<1, false, MULTI>;
-    case 2: return sweep_x64_lean_kernel<2, false, MULTI>;
-    case 3: return sweep_x64_lean_kernel<3, false, MULTI>;
-    case 4: return sweep_x64_lean_kernel<4, false, MULTI>;
-    case 5: case 6: return sweep_x64_lean_kernel<6, false, MULTI>;
-    default: return sweep_x64_lean_kernel<8, false, MULTI>;       // 7, 8: part of the tables lives in the accumulator registers
+    case 1: return sweep_x64_lean_kernel<1, false, MULTI, 0>;
+    case 2: return sweep_x64_lean_kernel<2, false, MULTI, 0>;
+    case 3: return sweep_x64_lean_kernel<3, false, MULTI, 0>;
+    case 4: return sweep_x64_lean_kernel<4, false, MULTI, 0>;
+    case 5: case 6: return sweep_x64_lean_kernel<6, false, MULTI, 0>;
+    case 7: return sweep_x64_lean_kernel<6, false, MULTI, 1>;     // six tables in registers, the seventh in LDS: two workgroups per CU
+    default: return sweep_x64_lean_kernel<8, false, MULTI, 0>;    // part of the tables lives in the accumulator registers
   }
 }
 
@@ -815,7 +857,7 @@ int launch_lean_groups(const mlbp_program* const* progs, const mlbp_sweep_args* 
     if (!ok) return MLBP_OK;
     if (k == 0) { d0 = d; f0 = f; }
     else if (f.init != f0.init || f.keep != f0.keep || (f.readout != nullptr) != (f0.readout != nullptr)) return MLBP_OK;
-    lds_max = std::max(lds_max, lds);
+    lds_max = std::max(lds_max, lds + (progs[k]->P < 7 ? 32 * 1024 : 0));      // (a 7-table group may sit beside it: its LDS table)
     p_max = std::max(p_max, (int)progs[k]->P);
     int32_t* w = &table[(size_t)k * GROUP_WORDS];
     auto put = [&](int at, const void* p) { const uintptr_t v = (uintptr_t)p; w[at] = (int32_t)(uint32_t)v; w[at + 1] = (int32_t)(uint32_t)(v >> 32); };

@@ -10,7 +10,9 @@
 //   prologue   the input message of N_T = 16 or 32 graphs is formed and parked in LDS: either a stored slot, or --
 //              fused -- the variable->factor product of VariableNode.update_message_to (LBP.py:377-389: uniform x the
 //              listed incoming messages, nan_to_num after each product, renormalised), which is also stored;
-//   main loop  v_mfma_f64_16x16x4_f64: wave w owns the row tiles w, w+4, ...; its A fragments (table rows) come straight
+//   main loop  four v_mfma_f64_4x4x4_f64 per 16 x 16 x 4 product (this GPU sustains 70 TFLOP/s on that form, 48 on the
+//              single v_mfma_f64_16x16x4_f64; tools/mfma_peak.hip): wave w owns the row tiles w, w+4, ...; its A
+//              fragments (table rows) come straight
 //              from L2 as one coalesced 16-byte load per lane and two k-steps, out of a copy of the table laid out in
 //              fragment order once per call (table_frag_kernel), with a register double buffer; the B fragments
 //              (messages) are 8-byte LDS reads out of a [graph][state + 2] image (conflict-free);
@@ -219,9 +221,16 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
   for (int s0 = 0; s0 < DIST; ++s0) load_a(a[s0], s0);
   static_assert(KB % 4 == 0 && (DEPTH == 2 || DEPTH == 4), "");
   if constexpr (sizeof(TT) == 8) {
+    // The 16 x 16 x 4 product as FOUR v_mfma_f64_4x4x4 (4 blocks of 4 x 4 x 4): measured on this GPU the 16x16x4 form sustains
+    // 47-49 TFLOP/s, the 4x4x4 form 70-71 (tools/mfma_peak.hip, profiles/r02k_mfma_peak.txt).  Operand lanes (probed,
+    // profiles/r02k_mfma_f64_4x4x4_layout.txt): A_blk[i][k] at lane i + 4 blk + 16 k -- the 16x16x4 A fragment as it is,
+    // block = rows 4 blk .. 4 blk + 3; B_blk[k][j] at lane j + 4 blk + 16 k -- four graphs 4 q + j per instruction, the
+    // same in every block (LDS broadcast); D_blk[i][j] at lane j + 4 blk + 16 i, i.e. accumulator q of a lane holds
+    // (row 4 ((lane >> 2) & 3) + (lane >> 4), graph 4 q + (lane & 3)).
     auto step = [&](const avec (&af)[RT], int kb) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
+#ifdef MLBP_CONTRACT_16X16          // A/B build: the single-instruction form
         double bf[NCT];
 #pragma unroll
         for (int c = 0; c < NCT; ++c) bf[c] = Mt[(16 * c + gcol) * XP + 8 * kb + 4 * e + krow];
@@ -230,6 +239,20 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
 #pragma unroll
           for (int c = 0; c < NCT; ++c)
             acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(e ? af[r].y : af[r].x, bf[c], acc[r][c], 0, 0, 0);
+#else
+        double bf[NCT][4];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bf[c][q] = Mt[(16 * c + 4 * q + (lane & 3)) * XP + 8 * kb + 4 * e + krow];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc[r][c][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(e ? af[r].y : af[r].x, bf[c][q], acc[r][c][q], 0, 0, 0);
+#endif
       }
     };
 #pragma unroll 1
@@ -278,14 +301,20 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
   }
   __syncthreads();                       // every wave has read its last message fragment: the image becomes the output
   // ---- epilogue: accumulators -> LDS transposed ([graph][state], float64), renormalise, store whole rows ----
-  // result element (row, col) of a 16 x 16 tile: col = lane & 15 (graph); float64 MFMA: row = (lane >> 4) + 4 i;
-  // float32 MFMA: row = 4 (lane >> 4) + i
+  // result element (row, col) of a 16 x 16 tile: float64 (four 4x4x4 MFMAs): see the main loop; float32 MFMA:
+  // col = lane & 15 (graph), row = 4 (lane >> 4) + i
 #pragma unroll
   for (int r = 0; r < RT; ++r)
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+#ifndef MLBP_CONTRACT_16X16
+        if (sizeof(TT) == 8) {
+          Ot[(16 * c + 4 * i + (lane & 3)) * XP + 16 * (wave + 4 * r) + 4 * ((lane >> 2) & 3) + krow] = acc[r][c][i];
+          continue;
+        }
+#endif
         const int row = sizeof(TT) == 8 ? krow + 4 * i : 4 * krow + i;
         Ot[(16 * c + gcol) * XP + 16 * (wave + 4 * r) + row] = acc[r][c][i];
       }

@@ -14,9 +14,10 @@ os.makedirs(OUT, exist_ok=True)
 lib = os.path.join(OUT, 'libmlbp_noloop.so')
 csrc = os.path.join(ROOT, 'macaronicusermodeling_amd', 'csrc')
 from macaronicusermodeling_amd import build as B_  # noqa: E402
-if '--noloop' in sys.argv:
+extra = [a for a in sys.argv[1:] if a.startswith('-D')]
+if '--noloop' in sys.argv or extra:
     subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fno-fast-math',
-                           '-DMLBP_CONTRACT_NOLOOP', '-shared', '-x', 'hip'] + [os.path.join(csrc, f) for f in B_.SOURCES] + ['-o', lib])
+                           *((['-DMLBP_CONTRACT_NOLOOP'] if '--noloop' in sys.argv else []) + extra), '-shared', '-x', 'hip'] + [os.path.join(csrc, f) for f in B_.SOURCES] + ['-o', lib])
     import macaronicusermodeling_amd._ffi as ffi  # noqa: E402
     ffi.LIB_PATH = lib
     ffi.lib = ffi._load()

@@ -148,6 +148,8 @@ int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_
  * program handed from the scale-free kernel to the exact kernel (degenerate inputs: zero-sum
  * messages, negative or non-finite entries).  Diagnostic; results are exact either way. */
 int mlbp_program_exact_count(const mlbp_program* p, int32_t B);
+/* The number of updates of the program's root sequence that MLBP_SWEEP_SKIP_UNCHANGED drops (0: the flag changes nothing). */
+int mlbp_program_skippable_updates(const mlbp_program* p);
 
 /* Synchronising read-and-reset of the program's device status word: 0 = clean; 1 = a kernel skipped
  * a graph because one of its table indices lay outside [0, n_*_tables) (instead of reading out of
@@ -230,6 +232,15 @@ typedef struct mlbp_sweep_args {
  * 100 <= X <= 1024; smaller X fails like the reference's argpartition ("kth out of bounds"). */
 #define MLBP_SWEEP_APPROX_INFERENCE 16
 #define MLBP_APPROX_K 100
+/* flags: run the program WITHOUT the updates whose inputs are bit for bit what they were when their destination was
+ * last computed (mlbp_program_skippable_updates of them).  A root sequence (LBP.py:223-233) recomputes such messages
+ * -- all of a tree's after its first sweep, the ones upstream of the first changed message when the root of a loopy
+ * graph moves -- and gets the same values again.  On the default X <= 64 kernel (MLBP_KERNEL_LEAN) dropping them changes
+ * no output bit (tests/test_gpu_sweep.py compares bitwise); the other kernels fuse a variable->factor product into the
+ * contraction that follows it when the two are adjacent in the list, so a shorter list can move their results by a
+ * rounding error (1e-12 in the tests).  Off by default: the default executes every update of the reference's schedule.
+ * Ignored together with a fused gradient. */
+#define MLBP_SWEEP_SKIP_UNCHANGED 32
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);
 

@@ -53,6 +53,7 @@ SWEEP_NO_MESSAGE_WRITEBACK = 2
 SWEEP_PAIR_TABLES_F32 = 4
 SWEEP_DENSE_TABLES = 8
 SWEEP_APPROX_INFERENCE = 16
+SWEEP_SKIP_UNCHANGED = 32
 APPROX_K = 100
 GRADIENT_SHARED_PAIR_TABLES = 1
 GRADIENT_APPROX_BELIEFS = 2
@@ -80,6 +81,7 @@ SIGNATURES = {
     'mlbp_program_reserve': (C.c_int, [_vp, _i32]),
     'mlbp_program_set_readout': (C.c_int, [_vp, _i32, _i32p, _i32p]),
     'mlbp_program_exact_count': (C.c_int, [_vp, _i32]),
+    'mlbp_program_skippable_updates': (C.c_int, [_vp]),
     'mlbp_program_status': (C.c_int, [_vp]),
     'mlbp_set_sweep_variant': (C.c_int, [_i32]),
     'mlbp_sweep_f64': (C.c_int, [_vp, C.POINTER(SweepArgs), _vp]),

@@ -51,6 +51,10 @@ class Program:
         """Graphs of the last launch that needed the exact kernel (mlbp_program_exact_count)."""
         return _ffi.check(_ffi.lib.mlbp_program_exact_count(self.handle, B))
 
+    def skippable_updates(self):
+        """Updates of the root sequence that skip_unchanged drops (mlbp_program_skippable_updates)."""
+        return _ffi.check(_ffi.lib.mlbp_program_skippable_updates(self.handle))
+
     def __del__(self):
         h = getattr(self, 'handle', None)
         lib = getattr(_ffi, 'lib', None) if _ffi is not None else None      # module may be gone at interpreter exit
@@ -70,6 +74,7 @@ class FactorGraphBatch:
         self.normalize_messages = bool(normalize_messages)
         # FactorGraph.use_approx_inference / use_approx_beliefs (LBP.py:52-53): top-100 variants, selected on the device
         self.use_approx_inference, self.use_approx_beliefs = bool(use_approx_inference), bool(use_approx_beliefs)
+        self.skip_unchanged = False       # MLBP_SWEEP_SKIP_UNCHANGED on every sweep (same output bits, fewer updates)
         self.msgs = torch.empty(self.B, topo.n_msgs, self.X, dtype=torch.float64, device=self.device)
         self.pair_tables = self.pair_tab = self.unary_tables = self.unary_tab = None
         self._in_off = torch.from_numpy(topo.in_off).to(self.device)
@@ -136,7 +141,7 @@ class FactorGraphBatch:
             self._programs[key] = Program(self.topo, key, max_graphs=self.B)
         return self._programs[key]
 
-    def sweep(self, roots, init=False, marginals=None, gradient=None, keep_messages=True, _collect=None):
+    def sweep(self, roots, init=False, marginals=None, gradient=None, keep_messages=True, skip_unchanged=None, _collect=None):
         """Runs len(roots) sweeps, sweep s rooted at variable id roots[s], on every graph, in one
         launch.  init=True starts from uniform messages (initialize() fused into the launch);
         marginals: optional [B][n_vars][X] device tensor that receives every variable's marginal
@@ -144,7 +149,9 @@ class FactorGraphBatch:
         (out_ee [B][F_ee], out_ed [B][F_ed]) device tensors that receive the per-graph gradients
         (set_features / set_observations first), fused into the launch when the kernel allows;
         keep_messages=False lets a shared-table launch with a fused read-out skip the write-back of
-        self.msgs (their contents are then undefined)."""
+        self.msgs (their contents are then undefined); skip_unchanged (default: self.skip_unchanged, False) drops the
+        updates of the root sequence that would recompute a message from unchanged inputs (MLBP_SWEEP_SKIP_UNCHANGED:
+        same output bits, fewer updates)."""
         prog = self.program(roots)
         a = _ffi.SweepArgs()
         a.B, a.X = self.B, self.X
@@ -168,6 +175,8 @@ class FactorGraphBatch:
         a.init_messages = 1 if init else 0
         if self.use_approx_inference:
             a.flags |= _ffi.SWEEP_APPROX_INFERENCE
+        if getattr(self, 'skip_unchanged', False) if skip_unchanged is None else skip_unchanged:
+            a.flags |= _ffi.SWEEP_SKIP_UNCHANGED
         if (getattr(self, '_pair_dense', False) or not self.topo.P) and (getattr(self, '_unary_dense', False) or not self.topo.U):
             a.flags |= _ffi.SWEEP_DENSE_TABLES
         if getattr(self, 'pair_tables_shared', False):

@@ -95,6 +95,10 @@ struct mlbp_program {
   int device;
   mlbp::FusedProgram fused;      // host copy (the update-by-update contraction path walks it)
   mlbp::LeanProgram lean;
+  mlbp_program* pruned = nullptr;   // the same program without the updates MLBP_SWEEP_SKIP_UNCHANGED drops, or NULL (none to drop)
+  int32_t n_dropped = 0;
+  bool is_twin = false;             // this IS some program's pruned twin
+  bool last_was_pruned = false;     // the last sweep call ran the twin (mlbp_program_exact_count reads its flags)
   int32_t* d_limage = nullptr;   // LeanProgram::image
   int32_t* d_lreadout = nullptr; // build_lean_readout
   // shared-table form (mlbp_shared.hip)

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <utility>
+#include <map>
 #include <vector>
 
 #include "mlbp_internal.h"
@@ -1708,9 +1709,60 @@ int mlbp_program_plan(const int32_t* ops, int32_t n_ops, const int32_t* srcs, in
   return MLBP_OK;
 }
 
+// MLBP_SWEEP_SKIP_UNCHANGED: the op list with every update dropped whose inputs -- and therefore whose result, bit for
+// bit -- are what they were when the destination slot was last computed.  Value numbering over the whole call: a slot's
+// value is named by (kind, table / factor, names of the source values); what the call starts from is opaque.  A root
+// sequence re-walks messages that the previous sweep left final (the whole of a tree after its first sweep; the part of a
+// loopy graph upstream of the first changed message), LBP.py:223-233 recomputes them, this list does not.  Returns the
+// number of updates dropped; sweeps_out are ranges into ops_out (no sharing between equal roots any more).
+static int drop_unchanged_updates(const int32_t* ops, const int32_t* srcs, const int32_t* sweeps, int n_sweeps, int n_msgs,
+                                  std::vector<int32_t>& ops_out, std::vector<int32_t>& sweeps_out) {
+  std::map<std::vector<int64_t>, int64_t> names;
+  std::vector<int64_t> val(n_msgs);
+  for (int c = 0; c < n_msgs; ++c) val[c] = -(int64_t)c - 1;
+  int dropped = 0;
+  std::vector<int64_t> key;
+  for (int s = 0; s < n_sweeps; ++s) {
+    const int first = sweeps[2 * s], cnt = sweeps[2 * s + 1];
+    const int start = (int)ops_out.size() / 4;
+    for (int o = first; o < first + cnt; ++o) {
+      const int kind = ops[4 * o], a = ops[4 * o + 1], b = ops[4 * o + 2], c = ops[4 * o + 3];
+      key.clear();
+      key.push_back(kind);
+      if (kind == MLBP_OP_VAR) {
+        for (int q = a; q < a + b; ++q) key.push_back(val[srcs[q]]);
+      } else if (kind == MLBP_OP_UNARY) {
+        key.push_back(a);
+      } else {
+        key.push_back(a);
+        key.push_back(val[b]);
+      }
+      auto it = names.find(key);
+      const int64_t name = it != names.end() ? it->second : (int64_t)names.size();
+      if (it == names.end()) names.emplace(key, name);
+      if (val[c] == name) { ++dropped; continue; }
+      val[c] = name;
+      ops_out.insert(ops_out.end(), ops + 4 * o, ops + 4 * o + 4);
+    }
+    sweeps_out.push_back(start);
+    sweeps_out.push_back((int)ops_out.size() / 4 - start);
+  }
+  return dropped;
+}
+
+static int create_program(const int32_t* ops, int32_t n_ops, const int32_t* srcs, int32_t n_srcs,
+                          const int32_t* sweeps, int32_t n_sweeps, int32_t n_msgs, int32_t P, int32_t U,
+                          mlbp_program** out, bool with_pruned);
+
 int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, int32_t n_srcs,
                         const int32_t* sweeps, int32_t n_sweeps, int32_t n_msgs, int32_t P, int32_t U,
                         mlbp_program** out) {
+  return create_program(ops, n_ops, srcs, n_srcs, sweeps, n_sweeps, n_msgs, P, U, out, true);
+}
+
+static int create_program(const int32_t* ops, int32_t n_ops, const int32_t* srcs, int32_t n_srcs,
+                          const int32_t* sweeps, int32_t n_sweeps, int32_t n_msgs, int32_t P, int32_t U,
+                          mlbp_program** out, bool with_pruned) {
   if (!out) return fail(MLBP_EINVAL, "out is NULL");
   *out = nullptr;
   int max_srcs = 0;
@@ -1779,12 +1831,32 @@ int mlbp_program_create(const int32_t* ops, int32_t n_ops, const int32_t* srcs, 
     mlbp_program_destroy(p);
     return fail(MLBP_EHIP, "mlbp_program_create: device upload failed: %s", hipGetErrorString(e));
   }
+  if (with_pruned) {
+    std::vector<int32_t> ops2, sweeps2;
+    p->n_dropped = drop_unchanged_updates(ops, srcs, sweeps, n_sweeps, n_msgs, ops2, sweeps2);
+    if (p->n_dropped > 0) {
+      if (int rc = create_program(ops2.data(), (int)ops2.size() / 4, srcs, n_srcs, sweeps2.data(), n_sweeps, n_msgs, P, U, &p->pruned, false)) {
+        mlbp_program_destroy(p);
+        return rc;
+      }
+      p->pruned->is_twin = true;
+    }
+  }
   *out = p;
   return MLBP_OK;
 }
 
+// the program a call runs: the pruned twin under MLBP_SWEEP_SKIP_UNCHANGED (not with a fused gradient: its epilogue is
+// laid out for the full update sequence)
+static const mlbp_program* effective_program(const mlbp_program* p, const mlbp_sweep_args* a) {
+  const bool pruned = p && a && (a->flags & MLBP_SWEEP_SKIP_UNCHANGED) && !a->gradient && p->pruned;
+  if (p && a && !p->is_twin) const_cast<mlbp_program*>(p)->last_was_pruned = pruned;
+  return pruned ? p->pruned : p;
+}
+
 int mlbp_program_destroy(mlbp_program* p) {
   if (!p) return MLBP_OK;
+  if (p->pruned) (void)mlbp_program_destroy(p->pruned);
   (void)hipFree(p->d_ops); (void)hipFree(p->d_srcs); (void)hipFree(p->d_sweeps);
   (void)hipFree(p->d_pairseq); (void)hipFree(p->d_status);
   (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq); (void)hipFree(p->d_bail); (void)hipFree(p->d_readout);
@@ -1795,6 +1867,7 @@ int mlbp_program_destroy(mlbp_program* p) {
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream) {
   if (!prog || !a) return fail(MLBP_EINVAL, "mlbp_sweep_f64: NULL program or args");
+  prog = effective_program(prog, a);
   if (a->B <= 0 || a->X <= 0) return fail(MLBP_EINVAL, "mlbp_sweep_f64: B=%d X=%d", a->B, a->X);
   if (!a->msgs) return fail(MLBP_EINVAL, "mlbp_sweep_f64: msgs is NULL");
   if (prog->P > 0 && (!((a->flags & MLBP_SWEEP_PAIR_TABLES_F32) ? (const void*)a->pair_tables_f32 : (const void*)a->pair_tables) ||
@@ -2043,6 +2116,12 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
 int mlbp_sweep_groups_f64(const mlbp_program* const* progs, const mlbp_sweep_args* args, int32_t n_groups, void* stream) {
   if (!progs || !args || n_groups < 1) return fail(MLBP_EINVAL, "mlbp_sweep_groups_f64: bad arguments");
   bool one_launch = false;
+  std::vector<const mlbp_program*> eff(n_groups);
+  for (int k = 0; k < n_groups; ++k) {
+    if (!progs[k]) return fail(MLBP_EINVAL, "mlbp_sweep_groups_f64: NULL program");
+    eff[k] = effective_program(progs[k], &args[k]);
+  }
+  progs = eff.data();
   if (sweep_variant() == 1)
     if (int e = mlbp::launch_lean_groups(progs, args, n_groups, stream, &one_launch)) return e;
   // the fast kernel has run every group (one_launch): what is left per group is the fix-up pass over the graphs it
@@ -2071,6 +2150,8 @@ int mlbp_debug_set_stamp_buffer(void* dev_ptr) {
 
 int mlbp_program_reserve(mlbp_program* p, int32_t max_graphs) {
   if (!p || max_graphs <= 0) return fail(MLBP_EINVAL, "mlbp_program_reserve: bad arguments");
+  if (p->pruned)
+    if (int e = mlbp_program_reserve(p->pruned, max_graphs)) return e;
   if (p->bail_cap >= max_graphs) return MLBP_OK;
   (void)hipFree(p->d_bail);
   p->d_bail = nullptr;
@@ -2089,6 +2170,8 @@ int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_
   const int n_in = in_off[n_vars];
   for (int q = 0; q < n_in; ++q)
     if (in_slots[q] < 0 || in_slots[q] >= p->n_msgs) return fail(MLBP_EINVAL, "in_slots[%d] = %d out of [0,%d)", q, in_slots[q], p->n_msgs);
+  if (p->pruned)
+    if (int e = mlbp_program_set_readout(p->pruned, n_vars, in_off, in_slots)) return e;
   std::vector<int32_t> img(in_off, in_off + n_vars + 1);
   img.insert(img.end(), in_slots, in_slots + n_in);
   img.push_back(0);
@@ -2130,6 +2213,7 @@ int mlbp_program_exact_count(const mlbp_program* prog, int32_t B) {
   // Synchronising: how many of the first B graphs of the last default-variant launch were handed
   // to the exact kernel (0 when the scale-free kernel was not used).
   if (!prog || B < 0) return fail(MLBP_EINVAL, "mlbp_program_exact_count: bad arguments");
+  if (prog->last_was_pruned && prog->pruned) prog = prog->pruned;
   if (!prog->d_bail || B == 0) return 0;
   if (B > prog->bail_cap) B = prog->bail_cap;
   std::vector<unsigned char> h((size_t)B);
@@ -2147,7 +2231,17 @@ int mlbp_program_status(const mlbp_program* prog) {
   int32_t v = 0, zero = 0;
   HIP_TRY(hipMemcpy(&v, prog->d_status, sizeof(v), hipMemcpyDeviceToHost));
   if (v) HIP_TRY(hipMemcpy(prog->d_status, &zero, sizeof(zero), hipMemcpyHostToDevice));
+  if (prog->pruned) {
+    const int w = mlbp_program_status(prog->pruned);
+    if (w < 0) return w;
+    v |= w;
+  }
   return v;
+}
+
+int mlbp_program_skippable_updates(const mlbp_program* prog) {
+  if (!prog) return fail(MLBP_EINVAL, "NULL program");
+  return prog->n_dropped;
 }
 
 int mlbp_init_messages_f64(double* msgs, int64_t n_rows, int32_t X, void* stream) {

@@ -11,7 +11,7 @@ export MLBP_BENCH_SPINUP_STEPS=0     # counters are per dispatch: no need for st
 out=gpurun_out/pmc_${tag}_${wl}_b${batch}
 mkdir -p $out profiles
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 bench.py --workload $wl --batch $batch --steps 5 --warmup 1 --no-cpu-baseline "$@" > $out/$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/$c -- python3 bench.py --workload $wl --batch $batch --steps 5 --warmup 1 --no-cpu-baseline --no-skip-unchanged "$@" > $out/$c.log 2>&1
 done
 f=$(find $out/FETCH_SIZE -name '*counter_collection.csv' | head -1)
 w=$(find $out/WRITE_SIZE -name '*counter_collection.csv' | head -1)

@@ -190,3 +190,27 @@ def test_to_string_and_to_dist_formats(L):
     assert len(strings) == 10            # one line per sentence position (3 predicted + 7 given)
     toks = [s for s in strings if s.startswith('w1 ')][0].split()
     assert len(toks) == 3 + 2 * 50
+
+
+def test_prediction_and_dist_text_equal_the_reference_output(L):
+    """SURVEY 8 row f4, pinned: tests/golden/user_k3_x64_text.json holds the text the reference's own to_string /
+    to_dist (LBP.py:109-143) and the '*SENT_ID:' block (train_mp.py:337) produce for the user_k3_x64 case after three
+    sweeps (make_text_golden.py runs the reference).  The drop-in must emit the same characters: labels, the top-50
+    vocabulary in the same order, '%0.4f' / '%0.6f' log-marginals."""
+    import json
+    import os
+    from macaronicusermodeling_amd import tidir
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'user_k3_x64_text.json'), encoding='utf8'))
+    case = [c for c in C.inference_cases() if c['name'] == gold['case']][0]
+    spec = case['spec']
+    roots = Roots(L)
+    fg = C.build_graph(L, spec, C.make_inputs(spec, case['seed']))
+    for f in fg.factors:
+        f.word_label = 'w%d' % (f.position or 0)
+    roots.queue = [gold['roots'][0]]
+    fg.initialize()
+    roots.queue = list(gold['roots'])
+    fg.treelike_inference(3)
+    assert fg.to_string() == gold['to_string']
+    assert fg.to_dist() == gold['to_dist']
+    assert tidir.prediction_block(17, fg) == gold['prediction_block']

@@ -482,3 +482,40 @@ def test_batched_approximate_inference_and_beliefs(case):
     small.set_pair_tables(np.ones((8, 64, 64))); small.set_unary_tables(np.ones((8, 64)))
     with pytest.raises(_ffi.MlbpError, match='out of bounds'):
         small.sweep([0], init=True)
+
+
+def test_ti_dir_to_posterior_equals_the_reference_pipeline(tmp_path):
+    """SURVEY 8 rows f1 + f3 end to end, pinned: tests/golden/tidir_reference.json holds, for 12 synthetic instances
+    (X = 16, all three feature planes on, seeded theta), the marginals and log-posteriors the REFERENCE computes with its own
+    TrainingInstance.from_dict -> create_factor_graph (train_mp.py:105-306: potentials from phi . theta with the per-instance
+    planes written into phi_en_de, factor creation) -> initialize -> three sweeps -> get_posterior_probs
+    (make_tidir_golden.py).  TiDirTrainer must reach the same numbers from the same files."""
+    import json
+    import os
+    from macaronicusermodeling_amd import tidir
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tidir_reference.json'), encoding='utf8'))
+    d = str(tmp_path)
+    paths = {k: os.path.join(d, k) for k in ('ti', 'vocab.en', 'vocab.de', 'phi.pmi', 'phi.pmi_w1', 'phi.ed', 'phi.ped')}
+    open(paths['ti'], 'w', encoding='utf8').write('\n'.join(gold['instances']) + '\n')
+    open(paths['vocab.en'], 'w', encoding='utf8').write('\n'.join(gold['vocab_en']) + '\n')
+    open(paths['vocab.de'], 'w', encoding='utf8').write('\n'.join(gold['vocab_de']) + '\n')
+    for k, name in (('phi.pmi', 'phi_pmi'), ('phi.pmi_w1', 'phi_pmi_w1'), ('phi.ed', 'phi_ed'), ('phi.ped', 'phi_ped')):
+        np.savetxt(paths[k], np.array(gold[name]))
+    assert gold['ee_names'] == tidir.EE_NAMES and gold['ed_names'] == tidir.ED_NAMES
+    tt = TiDirTrainer(paths['ti'], paths['vocab.en'], paths['vocab.de'], paths['phi.pmi'], paths['phi.pmi_w1'], paths['phi.ed'],
+                      paths['phi.ped'], sweeps=3, use_correct_feat=True, history=True, session_history=True)
+    tt.theta_en_en.copy_(torch.tensor(gold['theta_en_en'], dtype=torch.float64).reshape(-1))
+    tt.theta_en_de.copy_(torch.tensor(gold['theta_en_de'], dtype=torch.float64).reshape(-1))
+    by_sent = {json.loads(l)['current_sent'][0]['sent_id']: r for l, r in zip(gold['instances'], gold['reference'])}
+    seen = 0
+    for key, tr in tt.trainers.items():
+        assert list(tr.roots) == by_sent[tt.buckets[key]['rows'][0]['sent_id']]['roots']
+        lp, _, _, _ = tr.predict(top=min(16, tr.batch.X))
+        marg = tr._marg.cpu().numpy()
+        for i, row in enumerate(tt.buckets[key]['rows']):
+            ref = by_sent[row['sent_id']]
+            np.testing.assert_allclose(marg[i], np.array(ref['marginals']), rtol=1e-9, atol=1e-300)
+            np.testing.assert_allclose(lp[i], ref['log_posterior'], rtol=1e-9)
+            seen += 1
+    assert seen == len(gold['reference']) == 12

@@ -84,3 +84,86 @@ def test_params_file_round_trip(tmp_path):
     np.testing.assert_allclose(eet, ee, atol=1e-6); np.testing.assert_allclose(edt, ed, atol=1e-6)
     np.testing.assert_allclose(got['en_en', 'u1'], ee * 2, atol=1e-6)
     np.testing.assert_allclose(got['en_de', 'u1'], ed * 3, atol=1e-6)
+
+
+def test_params_file_matches_the_reference_functions(tmp_path):
+    """SURVEY 8 row f4, pinned: tests/golden/params_reference.txt is what the reference's OWN save_params
+    (train_mp.py:80-102) wrote for seeded thetas and three adapted domains (one name longer than the 15-column pad, one
+    non-ASCII), params_reference.npz what its read_params (train_mp.py:49-77) read back (make_params_golden.py runs the
+    two functions out of the reference's file).  Our writer must produce the same bytes, our reader the same arrays."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    ref_bytes = open(os.path.join(here, 'params_reference.txt'), 'rb').read()
+    z = np.load(os.path.join(here, 'params_reference.npz'))
+    keys = [tuple(k.split('\t')) for k in z['in_keys']]
+    ee_rows = iter(z['in_vals_ee']); ed_rows = iter(z['in_vals_ed'])
+    d2t = {}
+    for k in keys:                                          # the insertion order the reference iterated in
+        d2t[k] = next(ee_rows) if k[0] == 'en_en' else next(ed_rows)
+    p = os.path.join(str(tmp_path), 'params')
+    tidir.save_params(p, z['ee'], z['ed'], ee_names=list(z['een']), ed_names=list(z['edn']), d2t=d2t)
+    assert open(p, 'rb').read() == ref_bytes
+    een, eet, edn, edt, got = tidir.read_params(os.path.join(here, 'params_reference.txt'))
+    assert een == list(z['een']) and edn == list(z['edn'])
+    assert np.array_equal(eet, z['eet']) and np.array_equal(edt, z['edt'])
+    out_keys = [tuple(k.split('\t')) for k in z['out_keys']]
+    assert sorted(got) == out_keys
+    ee_rows = iter(z['out_vals_ee']); ed_rows = iter(z['out_vals_ed'])
+    for k in out_keys:
+        want = next(ee_rows) if k[0] == 'en_en' else next(ed_rows)
+        assert got[k].shape == (1, want.shape[-1]) and np.array_equal(got[k], want)
+
+
+def _tidir_gold():
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    return json.load(open(os.path.join(here, 'tidir_reference.json'), encoding='utf8'))
+
+
+def test_normalisation_rules_equal_the_reference_classes():
+    """SURVEY 8 row f3, pinned: Guess.__init__ / SimpleNode.__init__ of training_classes.py, run by
+    make_tidir_golden.py on a list of spellings (blank, reserved words in any case, phrasal guesses, trailing '*',
+    apostrophes, non-ASCII)."""
+    g = _tidir_gold()['normalisation']
+    for raw, want in g['guesses']:
+        assert tidir.normalize_guess(raw) == want, repr(raw)
+    for d, (sent_id, nid, l2, l1, pos, lang) in g['nodes']:
+        n = tidir.parse_node(d)
+        assert (n['sent_id'], list(n['id']), n['l2_word'], n['l1_parent'], n['position'], n['lang']) == (sent_id, nid, l2, l1, pos, lang)
+
+
+def test_reader_and_shape_compiler_equal_the_reference_graph_builder():
+    """SURVEY 8 row f3, pinned: for the 12 instances of tests/golden/tidir_reference.json the reference's own
+    TrainingInstance.from_dict and create_factor_graph (train_mp.py:105-306, run by make_tidir_golden.py against the
+    reference's LBP.py) give the normalised guesses and nodes, the variables that enter the graph and the factor list in
+    creation order; parse_instance / instance_shape / shape_spec / bucket_instances must give the same."""
+    gold = _tidir_gold()
+    en, de = gold['vocab_en'], gold['vocab_de']
+    en2id = {w: i for i, w in enumerate(en)}
+    de2id = {w: i for i, w in enumerate(de)}
+    n_checked = 0
+    for line, ref in zip(gold['instances'], gold['reference']):
+        ti = tidir.parse_instance(line)
+        for fld, want in ref['guesses'].items():
+            got = [[list(g['id']), g['guess'], bool(g['revealed']), g['l2_word'], g['reference']] for g in ti[fld]]
+            assert got == want, fld
+        assert [[n['sent_id'], list(n['id']), n['l2_word'], n['l1_parent'], n['position'], n['lang']] for n in ti['current_sent']] == ref['nodes']
+        key, rec = tidir.instance_shape(ti, en2id, de2id)
+        sent = sorted(ti['current_sent'], key=lambda n: n['position'])
+        # variables of the graph = the predicted words, id = index in position order (train_mp.py:108-133)
+        assert [v[0] for v in ref['variables']] == list(key[1])
+        for vid, var_type, label, truth in ref['variables']:
+            assert var_type == 'var_type_predicted' and en[rec['label'][vid]] == label and sent[vid]['l1_parent'] == truth
+        b = tidir.bucket_instances([ti], en, de)[key]
+        spec = b['spec']
+        unary = [f for f in sorted(spec['factors'], key=lambda f: f['id']) if len(f['vars']) == 1]
+        obs = {f['id']: int(b['unary_obs'][0][u]) for u, f in enumerate(unary)}
+        assert len(spec['factors']) == len(ref['factors'])
+        for f, (fid, ftype, fvars, observed, gap, position, word_label) in zip(sorted(spec['factors'], key=lambda f: f['id']), ref['factors']):
+            assert (f['id'], f['factor_type'], f['vars'], f['gap'], f['position']) == (fid, ftype, fvars, gap, position)
+            assert (obs[fid] if len(fvars) == 1 else None) == observed
+            if ftype == 'en_de':
+                assert de[obs[fid]] == word_label
+            elif len(fvars) == 1:
+                assert en[obs[fid]] == word_label
+            n_checked += 1
+    assert n_checked > 60

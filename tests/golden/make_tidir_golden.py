@@ -6,7 +6,7 @@
 `training_classes.py` imports `enchant` (absent) and `train_mp.py` imports `training_classes`, so neither module can be
 imported; both are Python 2.  What the path needs from them uses neither enchant nor the edit-distance helper:
 the dict-classes TrainingInstance / Guess / SimpleNode (training_classes.py:8-39, 94-183) and find_guess /
-get_var_node_pair / create_factor_graph (train_mp.py:41-47, 105-306).  This script reads the two files as text, passes them
+get_var_node_pair / create_factor_graph / apply_regularization / batch_sgd (train_mp.py:34-47, 105-306, 360-398).  This script reads the two files as text, passes them
 through the stdlib `lib2to3` fixers IN MEMORY (as make_golden.py does for LBP.py), takes exactly those definitions out of the
 syntax trees and executes them against the reference's own LBP.py (loaded by make_golden.load_reference), with the
 module-level names the functions read (`options`, `N`, `de_domain`, PRED2PRED / PRED2GIVEN -- set from the command line in
@@ -17,7 +17,9 @@ normalisation rules act (phrasal guess, trailing '*', apostrophe, capitals), see
 planes on.  Saved in tidir_reference.json: the TI_DIR itself (instances, vocabularies, the four feature matrices), theta,
 and per instance what the reference built and computed -- normalised guesses and nodes, variables (type, label, truth),
 factors in creation order (type, variables, observed index, gap, position, word label), the root sequence used, marginals
-after initialize + three sweeps, get_posterior_probs.  Plus `normalisation`: raw -> Guess.guess / SimpleNode fields for
+after initialize + three sweeps, get_posterior_probs, and the instance's step `return_gradient()` (learning rate 0.1,
+regularisation options.reg_param / N as train_mp.py:160 sets it; what batch_sgd returns and batch_sgd_accumulate adds to theta).  Plus `user_adapt`: the same instances through batch_sgd (train_mp.py:360-398) with --user_adapt on and seeded per-user
+thetas: log-posterior, global step and per-domain step of every instance.  Plus `normalisation`: raw -> Guess.guess / SimpleNode fields for
 a list of spellings.  Needs /root/reference; never run on the GPU box."""
 import argparse
 import ast
@@ -114,10 +116,42 @@ def main():
                              for f in sorted(fg.factors, key=lambda f: f.id)],
                     roots=seq,
                     marginals=[fg.variables[v].get_marginal().m.reshape(-1).tolist() for v in vids],
+                    # batch_sgd's result (train_mp.py:398): the learning-rate-scaled regularised step of this instance
+                    step=[np.asarray(g, dtype=np.float64).reshape(-1).tolist() for g in fg.return_gradient()],
                     log_posterior=float(np.sum(fg.get_posterior_probs())), log_posterior_terms=np.asarray(fg.get_posterior_probs(), dtype=np.float64).reshape(-1).tolist())
                 out_inst.append(rec)
         finally:
             sys.stderr = err
+        # ---- --user_adapt (train_mp.py:162-171, 226-247, 382-394): potentials from the user's theta INSTEAD of the global one,
+        #      batch_sgd returns the global step and the per-domain step (regularisation scaled by reg_param_ua_scale) ----
+        users = sorted({json.loads(l)['user_id'] for l in lines})
+        d2t = {}
+        for u in users:
+            d2t['en_en', u] = rs.randn(1, 3) * 0.7
+            d2t['en_de', u] = rs.randn(1, 6) * 0.7
+        ns['options'].user_adapt = True
+        ns['options'].reg_param_ua_scale = '0.5'
+        ns['domain2theta'] = d2t
+        ns['json'] = json
+        ns['TrainingInstance'] = tc['TrainingInstance']
+        exec(definitions(os.path.join(a.reference, 'train_mp.py'), ['apply_regularization', 'batch_sgd']), ns)
+        theta_dom0 = {u: [d2t['en_en', u].reshape(-1).tolist(), d2t['en_de', u].reshape(-1).tolist()] for u in users}
+        adapt_inst = []
+        sys.stderr = open(os.devnull, 'w')
+        try:
+            for line, rec in zip(lines, out_inst):
+                vids = [v[0] for v in rec['variables']]
+                roots.queue = [vids[0]] + [vids[i % len(vids)] for i in range(3)]       # has_loops' start, then the sweeps' roots
+                phi = L.PhiWrapper(phi_ee.copy(), phi_w1.copy(), phi_ed.copy())
+                sent_id, p, g_ee, g_ed, ag = ns['batch_sgd'](line, ee_names, ed_names, theta_ee.copy(), theta_ed.copy(), phi, 0.1, en, de2id, en2id,
+                                                              {k: v.copy() for k, v in d2t.items()})
+                (u,) = {d for _, d in ag}
+                adapt_inst.append(dict(sent_id=sent_id, user=u, log_posterior=float(np.sum(p)),
+                                       step=[np.asarray(g_ee).reshape(-1).tolist(), np.asarray(g_ed).reshape(-1).tolist()],
+                                       step_domain=[np.asarray(ag['en_en', u]).reshape(-1).tolist(), np.asarray(ag['en_de', u]).reshape(-1).tolist()]))
+        finally:
+            sys.stderr = err
+            roots.queue = []
         raw_guesses = ['', '   ', '__BLANK__', '__blank__', '__Unk__', '__copy__', 'House', "don't", 'the big house', 'big* house', 'star*', '*',
                        ' x ', 'Ab Cd*', "o'neil's*", 'aa bb', 'bb aa', 'ünï Code']
         norm_g = [[r, tc['Guess'](id=(0, 0), guess=r, revealed=False, l2_word='w').guess] for r in raw_guesses]
@@ -131,8 +165,9 @@ def main():
                    phi_pmi=np.loadtxt(paths['phi_pmi']).tolist(), phi_pmi_w1=np.loadtxt(paths['phi_pmi_w1']).tolist(),
                    phi_ed=np.loadtxt(paths['phi_ed']).tolist(), phi_ped=np.loadtxt(paths['phi_ped']).tolist(),
                    theta_en_en=theta_ee.tolist(), theta_en_de=theta_ed.tolist(), ee_names=ee_names, ed_names=ed_names,
-                   options=dict(use_correct_feat=True, history=True, session_history=True, sweeps=3),
-                   reference=out_inst, normalisation=dict(guesses=norm_g, nodes=norm_n))
+                   options=dict(use_correct_feat=True, history=True, session_history=True, sweeps=3, learning_rate=0.1, reg_param=0.1),
+                   reference=out_inst, normalisation=dict(guesses=norm_g, nodes=norm_n),
+                   user_adapt=dict(users=users, theta_dom=theta_dom0, reg_param_ua_scale=0.5, instances=adapt_inst))
         json.dump(out, open(os.path.join(HERE, 'tidir_reference.json'), 'w'), ensure_ascii=False)
         man_path = os.path.join(HERE, 'MANIFEST.json')
         man = json.load(open(man_path)) if os.path.exists(man_path) else {}

@@ -489,7 +489,8 @@ def test_ti_dir_to_posterior_equals_the_reference_pipeline(tmp_path):
     (X = 16, all three feature planes on, seeded theta), the marginals and log-posteriors the REFERENCE computes with its own
     TrainingInstance.from_dict -> create_factor_graph (train_mp.py:105-306: potentials from phi . theta with the per-instance
     planes written into phi_en_de, factor creation) -> initialize -> three sweeps -> get_posterior_probs
-    (make_tidir_golden.py).  TiDirTrainer must reach the same numbers from the same files."""
+    (make_tidir_golden.py), and each instance's step `return_gradient()`.  TiDirTrainer must reach the same numbers from the
+    same files, and one epoch must move theta by the sum of those steps."""
     import json
     import os
     from macaronicusermodeling_amd import tidir
@@ -519,3 +520,52 @@ def test_ti_dir_to_posterior_equals_the_reference_pipeline(tmp_path):
             np.testing.assert_allclose(lp[i], ref['log_posterior'], rtol=1e-9)
             seen += 1
     assert seen == len(gold['reference']) == 12
+    # one epoch = theta + the sum of the instances' steps at that theta (batch_sgd -> batch_sgd_accumulate,
+    # train_mp.py:360-424; the gradient includes the three per-instance feature planes)
+    o = gold['options']
+    mean_lp = tt.epoch(o['learning_rate'], o['reg_param'] / len(gold['reference']))
+    want_ee = np.array(gold['theta_en_en']).reshape(-1) + sum(np.array(r['step'][0]) for r in gold['reference'])
+    want_ed = np.array(gold['theta_en_de']).reshape(-1) + sum(np.array(r['step'][1]) for r in gold['reference'])
+    np.testing.assert_allclose(tt.theta_en_en.cpu().numpy(), want_ee, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(tt.theta_en_de.cpu().numpy(), want_ed, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(mean_lp, np.mean([r['log_posterior'] for r in gold['reference']]), rtol=1e-9)
+
+
+def test_ti_dir_user_adapt_epoch_equals_the_reference_batch_sgd(tmp_path):
+    """--user_adapt, pinned: tidir_reference.json['user_adapt'] holds what the reference's own batch_sgd (train_mp.py:360-398,
+    run by make_tidir_golden.py) returns per instance with seeded per-user thetas: potentials from the user's theta INSTEAD of
+    the global one, the global step, and the per-domain step regularised with reg_param_ua_scale = 0.5.  One epoch of
+    TiDirTrainer(adapt='user') must add exactly the sums (batch_sgd_accumulate, train_mp.py:405-416)."""
+    import json
+    import os
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tidir_reference.json'), encoding='utf8'))
+    ua = gold['user_adapt']
+    d = str(tmp_path)
+    paths = {k: os.path.join(d, k) for k in ('ti', 'vocab.en', 'vocab.de', 'phi.pmi', 'phi.pmi_w1', 'phi.ed', 'phi.ped')}
+    open(paths['ti'], 'w', encoding='utf8').write('\n'.join(gold['instances']) + '\n')
+    open(paths['vocab.en'], 'w', encoding='utf8').write('\n'.join(gold['vocab_en']) + '\n')
+    open(paths['vocab.de'], 'w', encoding='utf8').write('\n'.join(gold['vocab_de']) + '\n')
+    for k, name in (('phi.pmi', 'phi_pmi'), ('phi.pmi_w1', 'phi_pmi_w1'), ('phi.ed', 'phi_ed'), ('phi.ped', 'phi_ped')):
+        np.savetxt(paths[k], np.array(gold[name]))
+    tt = TiDirTrainer(paths['ti'], paths['vocab.en'], paths['vocab.de'], paths['phi.pmi'], paths['phi.pmi_w1'], paths['phi.ed'],
+                      paths['phi.ped'], sweeps=3, adapt='user', domains=ua['users'], reg_param_ua_scale=ua['reg_param_ua_scale'])
+    tt.theta_en_en.copy_(torch.tensor(gold['theta_en_en'], dtype=torch.float64).reshape(-1))
+    tt.theta_en_de.copy_(torch.tensor(gold['theta_en_de'], dtype=torch.float64).reshape(-1))
+    for i, u in enumerate(ua['users']):
+        tt.theta_dom_en_en[i].copy_(torch.tensor(ua['theta_dom'][u][0], dtype=torch.float64))
+        tt.theta_dom_en_de[i].copy_(torch.tensor(ua['theta_dom'][u][1], dtype=torch.float64))
+    o = gold['options']
+    mean_lp = tt.epoch(o['learning_rate'], o['reg_param'] / len(gold['instances']))
+    inst = ua['instances']
+    np.testing.assert_allclose(mean_lp, np.mean([r['log_posterior'] for r in inst]), rtol=1e-9)
+    np.testing.assert_allclose(tt.theta_en_en.cpu().numpy(), np.array(gold['theta_en_en']).reshape(-1) + sum(np.array(r['step'][0]) for r in inst),
+                               rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(tt.theta_en_de.cpu().numpy(), np.array(gold['theta_en_de']).reshape(-1) + sum(np.array(r['step'][1]) for r in inst),
+                               rtol=1e-9, atol=1e-12)
+    for i, u in enumerate(ua['users']):
+        mine = [r for r in inst if r['user'] == u]
+        np.testing.assert_allclose(tt.theta_dom_en_en[i].cpu().numpy(), np.array(ua['theta_dom'][u][0]) + sum(np.array(r['step_domain'][0]) for r in mine),
+                                   rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(tt.theta_dom_en_de[i].cpu().numpy(), np.array(ua['theta_dom'][u][1]) + sum(np.array(r['step_domain'][1]) for r in mine),
+                                   rtol=1e-9, atol=1e-12)

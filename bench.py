@@ -541,6 +541,7 @@ def main():
             out['parity'] = parity_sample(spec, topo, roots, fb, marg)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()          # rank 0 is still busy with the secondary figures and the parity sample: leave together
         dist.destroy_process_group()
 
 

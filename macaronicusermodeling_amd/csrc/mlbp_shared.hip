@@ -297,8 +297,13 @@ __device__ int g_sh_ablate = 0;
 #define ABL_DECL const int abl_ = __builtin_amdgcn_readfirstlane(g_sh_ablate);
 #define STAMP_DECL unsigned long long _t0 = 0, _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t0) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#ifdef MLBP_STAMPS_LIGHT      // only the workgroup's lifetime (start -> last stamp): the shader clock the kernel runs at, undisturbed
+#define STAMPV(i) if ((i) == 6) { unsigned long long _t1; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t1) :: "memory"); _ph[6] += _t1 - _t0; _t0 = _t1; }
+#define STAMP(i)
+#else
 #define STAMPV(i) { unsigned long long _t1; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t1) :: "memory"); __builtin_amdgcn_sched_barrier(0); _ph[i] += _t1 - _t0; _t0 = _t1; }
 #define STAMP(i) { unsigned long long _t1; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t1) :: "memory"); __builtin_amdgcn_sched_barrier(0); _ph[i] += _t1 - _t0; _t0 = _t1; }
+#endif
 #define STAMP_FLUSH if (g_sh_stamp && blockIdx.x < 64 && threadIdx.x == 0) { for (int _i = 0; _i < 8; ++_i) g_sh_stamp[blockIdx.x * 8 + _i] = _ph[_i]; }
 #else
 #define STAMP_DECL
@@ -455,7 +460,9 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
     const int E = d.n_cpw / 4;
     const int cpg = (E + HB - 1) / HB, nb = 4 * cpg;             // batches per graph, batches of this wave
     double cur = 1.0;
-    bool bad = false;
+    unsigned key = 0;                                            // largest high word met in the running product's rows
+    // high word of 1e280: a row entry above it as an unsigned integer is negative, not finite, or too large to multiply on
+    constexpr unsigned KEY_LIMIT = 0x7A11A0FCu;
     int fj = 0, fe = 0, pj = 0, pe = 0;                          // fetch / process cursors: graph 4w + j, first entry
     // entry e of the list lives in lane e: the per-row scalars come from v_readlane instead of a chain of
     // dependent LDS reads per row (three round trips per row were most of this phase)
@@ -477,18 +484,20 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
         if (pe + j < E) {
           // The scale of a unary message cancels in everything downstream (only its normalised form is ever
           // stored, by unary_writeback_kernel), so the raw columns are multiplied and the PRODUCT is
-          // normalised once.  A column Message.renormalize would replace by the uniform vector (total <= 0,
-          // LBP.py:655-657) or that is not a finite non-negative vector sends the graph to the exact kernel.
+          // normalised once (hardware reciprocal: only the magnitude matters).  A column Message.renormalize
+          // would replace by the uniform vector (total <= 0, LBP.py:655-657) zeroes the product, and an entry that
+          // is negative, not finite or huge shows in the high words: either sends the graph to the exact kernel,
+          // decided once per product instead of once per row.
           const int flags = __builtin_amdgcn_readlane(ent_flags, pe + j);
-          if (flags & 1) { cur = 1.0; bad = false; }
+          if (flags & 1) { cur = 1.0; key = 0; }
           const double r = row[j];
-          bad |= !(r >= 0.0 && r <= 1e280) || !__any(r > 0.0);
+          key = max(key, (unsigned)__double2hiint(r));
           cur *= r;
           if (flags & 2) {
             const double s = ABL(2) ? 64.0 : wave_sum(cur);
-            bad |= !total_ok(s);
-            if (!ABL(1)) TP(__builtin_amdgcn_readlane(ent_tile, pe + j))[lane * G + gg] = cur * (1.0 / s);
-            if (__any(bad)) gflag[gg] = 1;
+            const bool bad = !total_ok(s) || __any(key > KEY_LIMIT);
+            if (!ABL(1)) TP(__builtin_amdgcn_readlane(ent_tile, pe + j))[lane * G + gg] = cur * __builtin_amdgcn_rcp(s);
+            if (bad) gflag[gg] = 1;
           }
         }
       }

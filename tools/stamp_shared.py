@@ -15,7 +15,7 @@ os.makedirs(OUT, exist_ok=True)
 lib = os.path.join(OUT, 'libmlbp_stamps.so')
 csrc = os.path.join(ROOT, 'macaronicusermodeling_amd', 'csrc')
 subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-fno-fast-math',
-                       '-DMLBP_STAMPS', '-shared', '-x', 'hip'] +
+                       '-DMLBP_STAMPS', *(['-DMLBP_STAMPS_LIGHT'] if '--light' in sys.argv else []), '-shared', '-x', 'hip'] +
                       [os.path.join(csrc, f) for f in ('mlbp_host.cpp', 'mlbp_sweep.hip', 'mlbp_lean.hip', 'mlbp_shared.hip', 'mlbp_gemm.hip', 'mlbp_prims.hip',
                                                        'mlbp_grad.hip')] + ['-o', lib])
 import macaronicusermodeling_amd._ffi as ffi  # noqa: E402
@@ -45,17 +45,18 @@ names = ['A: indices/image/init', 'B: table fragment loads issued', 'C: unary ->
          'loop: mfma + store', 'loop: barrier', 'epilogue', 'loop: column sum + v->f stores']
 ABL = ['unary write-back stores', 'transposed tile writes', 'wave_sum', 'unary loads', 'v->f stores', 'column_sum', 'mfma',
        'second source tiles']
+KEEP = '--no-writeback' not in sys.argv
 masks = [0] + [1 << i for i in range(8)] if '--ablate' in sys.argv else [0]
 for mask in masks:
     buf = torch.zeros(64 * 8, dtype=torch.int64, device=dev)
     assert ffi.lib.mlbp_debug_set_shared_stamp_buffer(buf.data_ptr(), mask) == 0
     for _ in range(3):
-        fb.sweep(roots, init=True, marginals=marg)
+        fb.sweep(roots, init=True, marginals=marg, keep_messages=KEEP)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(5):
-        fb.sweep(roots, init=True, marginals=marg)
+        fb.sweep(roots, init=True, marginals=marg, keep_messages=KEEP)
     e.record(); torch.cuda.synchronize()
     assert ffi.lib.mlbp_last_sweep_kernel() == 3
     if mask == 0:
@@ -63,5 +64,6 @@ for mask in masks:
     t = buf.cpu().numpy().reshape(64, 8).astype(float)
     tot = t.sum(1).mean()
     what = 'nothing removed' if mask == 0 else 'WITHOUT ' + ABL[mask.bit_length() - 1]
-    print('B=%d %s: %.1f us per launch (stamped build); ticks per workgroup %.0f' % (B, what, s.elapsed_time(e) / 5 * 1e3, tot))
+    us = s.elapsed_time(e) / 5 * 1e3
+    print('B=%d %s: %.1f us per launch (stamped build); ticks per workgroup %.0f (min %.0f, max %.0f) = %.2f ticks per ns of the launch' % (B, what, us, tot, t.sum(1).min(), t.sum(1).max(), tot / (us * 1e3)))
     print('   ' + '  '.join('%s %.0f' % (n.split(':')[0] if i < 3 else n[6:], t[:, i].mean()) for i, n in enumerate(names)))

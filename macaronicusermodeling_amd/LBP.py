@@ -72,7 +72,7 @@ class _Engine:
             [(f.id, [v.id for v in f.varset], [f.potential_table.var_id2dim[v.id] for v in f.varset]) for f in factors],
             var_ids=list(fg.variables.keys()),
             facsets={vid: [f.id for f in v.facset] for vid, v in fg.variables.items()})
-        self.batch = FactorGraphBatch(self.topo, self.X, 1, device=_device())
+        self.batch = FactorGraphBatch(self.topo, self.X, 1, device=_device(), share_programs=True)
         self.keys = self.topo.slot_keys()
         self.slot = {k: i for i, k in enumerate(self.keys)}
         self.host = np.full((self.topo.n_msgs, self.X), 1.0 / self.X)
@@ -173,6 +173,8 @@ class _MessageStore:
         self._e = engine
 
     def __getitem__(self, key):
+        """A COPY of the message (the values live on the device): unlike the reference's dict, editing `messages[k].m` in
+        place changes nothing -- assign the Message back (`messages[k] = msg`) to write it."""
         i = self._e.slot[key]                         # KeyError like a dict
         return Message(self._e.to_host()[i].copy())
 

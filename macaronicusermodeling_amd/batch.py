@@ -12,6 +12,7 @@ HBM layout (all float64, the reference dtype):
     msgs         [B][n_msgs][X]          slot order = GraphTopology.slot_keys()
 """
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -63,8 +64,22 @@ class Program:
             self.handle = None
 
 
+# Programs shared between the one-graph batches of the object API (LBP.py drop-in): every TrainingInstance of one sentence
+# shape builds the same topology and draws its roots from the same few variables, and creating a Program costs a dozen
+# synchronous allocations and copies.  Per thread (a program's scratch buffers belong to one stream at a time,
+# include/mlbp.h), keyed by the topology's integer description, the device and the root sequence; bounded.
+_shared_programs = threading.local()
+_SHARED_PROGRAMS_MAX = 512
+
+
+def _topology_signature(topo):
+    return (topo.n_vars, tuple(topo.var_ids), topo.fac_nvars.tobytes(), topo.fac_var.tobytes(), topo.fac_dim.tobytes(),
+            tuple(tuple(f) for f in topo.facsets))
+
+
 class FactorGraphBatch:
-    def __init__(self, topo, X, B, device='cuda:0', normalize_messages=True, use_approx_inference=False, use_approx_beliefs=False):
+    def __init__(self, topo, X, B, device='cuda:0', normalize_messages=True, use_approx_inference=False, use_approx_beliefs=False,
+                 share_programs=False):
         if not isinstance(topo, GraphTopology):
             raise TypeError('topo must be a GraphTopology')
         self.topo, self.X, self.B = topo, int(X), int(B)
@@ -80,6 +95,7 @@ class FactorGraphBatch:
         self._in_off = torch.from_numpy(topo.in_off).to(self.device)
         self._in_slots = torch.from_numpy(topo.in_slots).to(self.device)
         self._programs = {}
+        self._share_programs = bool(share_programs)     # the object API: Programs come from the per-thread shared cache
         self.is_loopy = None
 
     # ---- tables -------------------------------------------------------------------------------
@@ -138,7 +154,21 @@ class FactorGraphBatch:
     def program(self, roots):
         key = tuple(int(r) for r in roots)
         if key not in self._programs:
-            self._programs[key] = Program(self.topo, key, max_graphs=self.B)
+            if self._share_programs:
+                cache = getattr(_shared_programs, 'by_key', None)
+                if cache is None:
+                    cache = _shared_programs.by_key = {}
+                if not hasattr(self, '_topo_sig'):
+                    self._topo_sig = (_topology_signature(self.topo), self.device.index)
+                full = (self._topo_sig, key)
+                prog = cache.get(full)
+                if prog is None:
+                    if len(cache) >= _SHARED_PROGRAMS_MAX:
+                        cache.clear()             # programs still referenced by a batch's own dict live on
+                    prog = cache[full] = Program(self.topo, key, max_graphs=self.B)
+                self._programs[key] = prog
+            else:
+                self._programs[key] = Program(self.topo, key, max_graphs=self.B)
         return self._programs[key]
 
     def sweep(self, roots, init=False, marginals=None, gradient=None, keep_messages=True, skip_unchanged=None, _collect=None):

@@ -19,7 +19,8 @@ and per instance what the reference built and computed -- normalised guesses and
 factors in creation order (type, variables, observed index, gap, position, word label), the root sequence used, marginals
 after initialize + three sweeps, get_posterior_probs, and the instance's step `return_gradient()` (learning rate 0.1,
 regularisation options.reg_param / N as train_mp.py:160 sets it; what batch_sgd returns and batch_sgd_accumulate adds to theta).  Plus `user_adapt`: the same instances through batch_sgd (train_mp.py:360-398) with --user_adapt on and seeded per-user
-thetas: log-posterior, global step and per-domain step of every instance.  Plus `normalisation`: raw -> Guess.guess / SimpleNode fields for
+thetas: log-posterior, global step and per-domain step of every instance; `experience_adapt`: the same with --experience_adapt
+(domain = number of sentences seen).  Plus `normalisation`: raw -> Guess.guess / SimpleNode fields for
 a list of spellings.  Needs /root/reference; never run on the GPU box."""
 import argparse
 import ast
@@ -68,7 +69,8 @@ def main():
         recs = [json.loads(l) for l in lines]
         respell = [lambda g: 'a ' + g.upper() + '*', lambda g: g[:2] + "'" + g[2:], lambda g: ' ' + g.capitalize() + ' ', lambda g: g + '*']
         k = 0
-        for r in recs:
+        for idx, r in enumerate(recs):
+            r['past_sentences_seen'] = list(range(idx % 3))          # --experience_adapt: domain = how many sentences were seen
             for fld in ('current_guesses', 'current_revealed_guesses', 'past_correct_guesses', 'past_guesses_for_current_sent'):
                 for g in r[fld]:
                     if k % 3 == 0:
@@ -152,6 +154,33 @@ def main():
         finally:
             sys.stderr = err
             roots.queue = []
+        # ---- --experience_adapt (train_mp.py:167-171): the same with domain = len(ti.past_sentences_seen) ----
+        seen = sorted({len(json.loads(l)['past_sentences_seen']) for l in lines})
+        d2t_e = {}
+        for d in seen:
+            d2t_e['en_en', d] = rs.randn(1, 3) * 0.7
+            d2t_e['en_de', d] = rs.randn(1, 6) * 0.7
+        ns['options'].user_adapt = False
+        ns['options'].experience_adapt = True
+        ns['options'].reg_param_ua_scale = '2.0'
+        ns['domain2theta'] = d2t_e
+        theta_exp0 = {str(d): [d2t_e['en_en', d].reshape(-1).tolist(), d2t_e['en_de', d].reshape(-1).tolist()] for d in seen}
+        exp_inst = []
+        sys.stderr = open(os.devnull, 'w')
+        try:
+            for line, rec in zip(lines, out_inst):
+                vids = [v[0] for v in rec['variables']]
+                roots.queue = [vids[0]] + [vids[i % len(vids)] for i in range(3)]
+                phi = L.PhiWrapper(phi_ee.copy(), phi_w1.copy(), phi_ed.copy())
+                sent_id, p, g_ee, g_ed, ag = ns['batch_sgd'](line, ee_names, ed_names, theta_ee.copy(), theta_ed.copy(), phi, 0.1, en, de2id, en2id,
+                                                              {k: v.copy() for k, v in d2t_e.items()})
+                (d,) = {d for _, d in ag}
+                exp_inst.append(dict(sent_id=sent_id, domain=str(d), log_posterior=float(np.sum(p)),
+                                     step=[np.asarray(g_ee).reshape(-1).tolist(), np.asarray(g_ed).reshape(-1).tolist()],
+                                     step_domain=[np.asarray(ag['en_en', d]).reshape(-1).tolist(), np.asarray(ag['en_de', d]).reshape(-1).tolist()]))
+        finally:
+            sys.stderr = err
+            roots.queue = []
         raw_guesses = ['', '   ', '__BLANK__', '__blank__', '__Unk__', '__copy__', 'House', "don't", 'the big house', 'big* house', 'star*', '*',
                        ' x ', 'Ab Cd*', "o'neil's*", 'aa bb', 'bb aa', 'ünï Code']
         norm_g = [[r, tc['Guess'](id=(0, 0), guess=r, revealed=False, l2_word='w').guess] for r in raw_guesses]
@@ -167,7 +196,8 @@ def main():
                    theta_en_en=theta_ee.tolist(), theta_en_de=theta_ed.tolist(), ee_names=ee_names, ed_names=ed_names,
                    options=dict(use_correct_feat=True, history=True, session_history=True, sweeps=3, learning_rate=0.1, reg_param=0.1),
                    reference=out_inst, normalisation=dict(guesses=norm_g, nodes=norm_n),
-                   user_adapt=dict(users=users, theta_dom=theta_dom0, reg_param_ua_scale=0.5, instances=adapt_inst))
+                   user_adapt=dict(users=users, theta_dom=theta_dom0, reg_param_ua_scale=0.5, instances=adapt_inst),
+                   experience_adapt=dict(domains=[str(d) for d in seen], theta_dom=theta_exp0, reg_param_ua_scale=2.0, instances=exp_inst))
         json.dump(out, open(os.path.join(HERE, 'tidir_reference.json'), 'w'), ensure_ascii=False)
         man_path = os.path.join(HERE, 'MANIFEST.json')
         man = json.load(open(man_path)) if os.path.exists(man_path) else {}

@@ -214,3 +214,30 @@ def test_prediction_and_dist_text_equal_the_reference_output(L):
     assert fg.to_string() == gold['to_string']
     assert fg.to_dist() == gold['to_dist']
     assert tidir.prediction_block(17, fg) == gold['prediction_block']
+
+
+def test_graphs_of_one_shape_share_their_programs_and_messages_are_copies(L):
+    """Two FactorGraph objects of the same shape reuse one device program per root sequence (per-thread cache in
+    batch.py), and `messages[k]` hands out copies: an in-place edit is not seen, an assignment is."""
+    case = [c for c in C.inference_cases() if c['name'] == 'user_k3_x64'][0]
+    spec = case['spec']
+    roots = Roots(L)
+    graphs = []
+    for seed in (case['seed'], case['seed'] + 1):
+        fg = C.build_graph(L, spec, C.make_inputs(spec, seed))
+        roots.queue = [1]
+        fg.initialize()
+        roots.queue = [1, 4, 7]
+        fg.treelike_inference(3)
+        graphs.append(fg)
+    e0, e1 = graphs[0]._engine, graphs[1]._engine
+    assert e0.batch.program((1, 4, 7)) is e1.batch.program((1, 4, 7))
+    assert not np.array_equal(_stack(graphs[0], e0.keys), _stack(graphs[1], e1.keys))      # different tables, own messages
+    k = e0.keys[3]
+    m = graphs[0].messages[k]
+    before = m.m.copy()
+    m.m[:] = 0.5                                         # a copy: nothing changes on the graph
+    np.testing.assert_array_equal(graphs[0].messages[k].m, before)
+    m2 = L.Message(np.full_like(before, 0.25))
+    graphs[0].messages[k] = m2
+    np.testing.assert_array_equal(graphs[0].messages[k].m.reshape(-1), np.full(before.size, 0.25))

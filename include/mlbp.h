@@ -239,7 +239,7 @@ typedef struct mlbp_sweep_args {
  * no output bit (tests/test_gpu_sweep.py compares bitwise); the other kernels fuse a variable->factor product into the
  * contraction that follows it when the two are adjacent in the list, so a shorter list can move their results by a
  * rounding error (1e-12 in the tests).  Off by default: the default executes every update of the reference's schedule.
- * Ignored together with a fused gradient. */
+ * A gradient fused into the call reads the final messages and follows either list. */
 #define MLBP_SWEEP_SKIP_UNCHANGED 32
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream);

@@ -1846,10 +1846,10 @@ static int create_program(const int32_t* ops, int32_t n_ops, const int32_t* srcs
   return MLBP_OK;
 }
 
-// the program a call runs: the pruned twin under MLBP_SWEEP_SKIP_UNCHANGED (not with a fused gradient: its epilogue is
-// laid out for the full update sequence)
+// the program a call runs: the pruned twin under MLBP_SWEEP_SKIP_UNCHANGED (a fused gradient reads the final messages and
+// the resident tables only, so it follows either list)
 static const mlbp_program* effective_program(const mlbp_program* p, const mlbp_sweep_args* a) {
-  const bool pruned = p && a && (a->flags & MLBP_SWEEP_SKIP_UNCHANGED) && !a->gradient && p->pruned;
+  const bool pruned = p && a && (a->flags & MLBP_SWEEP_SKIP_UNCHANGED) && p->pruned;
   if (p && a && !p->is_twin) const_cast<mlbp_program*>(p)->last_was_pruned = pruned;
   return pruned ? p->pruned : p;
 }

@@ -30,7 +30,7 @@ from .topology import GraphTopology
 class UserGraphTrainer:
     def __init__(self, spec, var_labels, unary_obs, phi_en_en, phi_en_en_w1, phi_en_de, theta_en_en, theta_en_de,
                  device='cuda:0', sweeps=3, roots=None, planes=None, domains=None, theta_dom_en_en=None,
-                 theta_dom_en_de=None):
+                 theta_dom_en_de=None, skip_unchanged=True):
         """spec: a 'trainmp'-style spec (tests/golden/cases.py: factors carry factor_type / gap);
         var_labels [B][n_vars], unary_obs [B][U]: this rank's shard of instances.
         planes: optional per-instance sparse feature planes, a list (one entry per instance) of
@@ -39,7 +39,10 @@ class UserGraphTrainer:
         domains [B] + theta_dom_en_en [D][F_ee] + theta_dom_en_de [D][F_ed]: --user_adapt / --experience_adapt
         (train_mp.py:162-171, 226-247): instance i builds its potentials from theta_dom[domains[i]] INSTEAD of the
         global theta; the global theta still receives every instance's step.  Instances of one domain should be
-        contiguous (groups of 16 consecutive graphs that share their tables run on the matrix cores)."""
+        contiguous (groups of 16 consecutive graphs that share their tables run on the matrix cores).
+        skip_unchanged (default on): the sweeps drop the updates of the root sequence that would recompute a message from
+        unchanged inputs (MLBP_SWEEP_SKIP_UNCHANGED, include/mlbp.h) -- a third of a three-root user graph's contractions;
+        statistics equal the full schedule's to rounding (tests/test_gpu_gradient.py)."""
         self.spec = spec
         self.topo = topo = GraphTopology.from_spec(spec)
         by_id = {f['id']: f for f in spec['factors']}
@@ -47,6 +50,7 @@ class UserGraphTrainer:
         self.device = torch.device(device)
         B = int(np.asarray(var_labels).shape[0])
         self.batch = fb = FactorGraphBatch(topo, X, B, device=self.device)
+        fb.skip_unchanged = bool(skip_unchanged)
         pair_phi, unary_kind = [], []
         for j in topo.pair_factors:
             f = by_id[topo.factor_ids[j]]
@@ -311,7 +315,7 @@ class TiDirTrainer:
 
     def __init__(self, ti_path, en_vocab, de_vocab, phi_pmi, phi_pmi_w1, phi_ed, phi_ped, device='cuda:0', sweeps=3,
                  rank=0, world=1, use_planes=True, adapt=None, domains=None, reg_param_ua_scale=1.0,
-                 use_correct_feat=True, history=True, session_history=True, grouped_sweeps='auto'):
+                 use_correct_feat=True, history=True, session_history=True, grouped_sweeps='auto', skip_unchanged=True):
         """use_planes switches the three per-instance feature planes on as a whole; use_correct_feat / history /
         session_history gate them one by one as the reference's options of the same names do (train_mp.py:178, 192,
         206: the 'correct', 'full_history' and 'hit_history' planes).
@@ -365,7 +369,7 @@ class TiDirTrainer:
                     planes.append(cells)
             self.trainers[key] = UserGraphTrainer(b['spec'], b['var_labels'], b['unary_obs'], phi_ee, phi_w1, phi_ed_t,
                                                   self.theta_en_en, self.theta_en_de, device=device, sweeps=sweeps, roots=roots,
-                                                  planes=planes, **extra)
+                                                  planes=planes, skip_unchanged=skip_unchanged, **extra)
         self.n_stat = len(tidir.EE_NAMES) + len(tidir.ED_NAMES) + 2
         self.stats = torch.zeros(self.n_stat * (1 + len(self.domains)), dtype=torch.float64, device=dev)
 

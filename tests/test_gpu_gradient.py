@@ -573,3 +573,27 @@ def test_ti_dir_adapt_epoch_equals_the_reference_batch_sgd(tmp_path, mode):
                                    rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(tt.theta_dom_en_de[i].cpu().numpy(), np.array(ua['theta_dom'][u][1]) + sum(np.array(r['step_domain'][1]) for r in mine),
                                    rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('shared', [False, True])
+def test_gradient_fused_into_a_sweep_that_skips_unchanged_updates(shared):
+    """MLBP_SWEEP_SKIP_UNCHANGED with the gradient in the same call: the fused gradient reads the final messages and the
+    resident tables, so it must equal the full schedule's (to rounding: these kernels fuse adjacent updates), with
+    per-graph tables (the scale-free kernel's epilogue) and with shared pots (separate gradient kernel after the MFMA sweep)."""
+    from macaronicusermodeling_amd.train import UserGraphTrainer
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = C.user_spec(10, [1, 4, 7], 64, 48, seed=1)
+    topo = GraphTopology.from_spec(spec)
+    inputs = C.make_inputs(spec, 77)
+    B, roots = 40, [4, 1, 7]
+    labels, obs = _instances(spec, topo, B, 5)
+    outs = []
+    for skip in (False, True):
+        tr = UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],
+                              inputs['theta_en_en'], inputs['theta_en_de'], roots=roots)
+        tr.batch.skip_unchanged = skip
+        tr.batch.pair_tables_shared = shared
+        stats = tr.local_statistics().clone()
+        assert tr.batch.program(tr.roots[:tr.n_sweeps_run]).skippable_updates() > 0
+        outs.append(stats.cpu().numpy())
+    np.testing.assert_allclose(outs[1], outs[0], rtol=1e-11, atol=1e-13)

@@ -28,7 +28,9 @@ rs = np.random.RandomState(0)
 labels = rs.randint(0, X, size=(B, topo.n_vars)); obs = rs.randint(0, 64, size=(B, topo.U))
 tr = UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],
                       inputs['theta_en_en'], inputs['theta_en_de'])
-print('shared pots:  full local_statistics %.3f ms' % timed(tr.local_statistics))
+for skip in (False, True):
+    tr.batch.skip_unchanged = skip
+    print('shared pots:  full local_statistics %.3f ms (skip_unchanged=%s)' % (timed(tr.local_statistics), skip))
 eager = tr.local_statistics().clone()
 tr.capture()
 print('shared pots:  full local_statistics as one HIP graph replay %.3f ms' % timed(tr.local_statistics))
@@ -52,6 +54,7 @@ gee = torch.empty(B, 3, dtype=torch.float64, device=dev); ged = torch.empty(B, 6
 for planar in (True, False, True, False):
   fb.use_planar = planar
   print('planar' if planar else 'interleaved', end=' ')
-  print('unique tables: sweep+marginals %.3f ms   gradient alone %.3f ms   sweep+marginals+fused gradient %.3f ms' % (
+  print('unique tables: sweep+marginals %.3f ms   gradient alone %.3f ms   sweep+marginals+fused gradient %.3f ms (skip_unchanged: %.3f ms)' % (
       timed(lambda: fb.sweep([1, 4, 7], init=True, marginals=marg)), timed(lambda: fb.gradient()),
-      timed(lambda: fb.sweep([1, 4, 7], init=True, marginals=marg, gradient=(gee, ged)))))
+      timed(lambda: fb.sweep([1, 4, 7], init=True, marginals=marg, gradient=(gee, ged))),
+      timed(lambda: fb.sweep([1, 4, 7], init=True, marginals=marg, gradient=(gee, ged), skip_unchanged=True))))

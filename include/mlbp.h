@@ -477,6 +477,22 @@ int mlbp_sparse_normalize_f64(double* m, int32_t n_cols, const int32_t* cidx, in
 int mlbp_potentials_f64(const double* phi, const double* theta, int32_t rows, int32_t cols, int32_t F, double* pot,
                         double* pot_t, void* stream);
 
+/* The same for up to MLBP_POTENTIALS_MAX_JOBS feature sets and n_rep parameter vectors in ONE launch: what
+ * create_factor_graph does per instance with (phi_en_en, phi_en_en_w1, phi_en_de) and the instance's theta -- the global
+ * one, or under --user_adapt / --experience_adapt the domain's (train_mp.py:220-255).  Job j, repetition r:
+ * theta = jobs[j].theta + r * theta_stride, outputs at pot + r * pot_stride and pot_t + r * pot_t_stride (strides in
+ * doubles; pot / pot_t may be NULL).  `jobs` is a HOST array (copied by value into the launch). */
+#define MLBP_POTENTIALS_MAX_JOBS 4
+typedef struct mlbp_potentials_job {
+  const double* phi;       /* [rows][cols][F] */
+  const double* theta;     /* [n_rep] vectors of F, theta_stride apart */
+  double* pot;             /* [n_rep] x [rows][cols], or NULL */
+  double* pot_t;           /* [n_rep] x [cols][rows], or NULL */
+  int64_t theta_stride, pot_stride, pot_t_stride;
+  int32_t rows, cols, F, reserved;
+} mlbp_potentials_job;
+int mlbp_potentials_multi_f64(const mlbp_potentials_job* jobs, int32_t n_jobs, int32_t n_rep, void* stream);
+
 /* Elementwise natural log (np.log at LBP.py:139, 252, 408, 411: log-marginal read-outs). */
 int mlbp_log_f64(const double* in, double* out, int64_t n, void* stream);
 

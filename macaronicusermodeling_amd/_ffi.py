@@ -40,6 +40,12 @@ class GradientArgs(C.Structure):
                 ('grad_en_en', C.c_void_p), ('grad_en_de', C.c_void_p), ('flags', C.c_int32), ('pair_tab_host', C.c_void_p), ('unary_expect', C.c_void_p)]
 
 
+class PotentialsJob(C.Structure):
+    _fields_ = [('phi', C.c_void_p), ('theta', C.c_void_p), ('pot', C.c_void_p), ('pot_t', C.c_void_p),
+                ('theta_stride', C.c_int64), ('pot_stride', C.c_int64), ('pot_t_stride', C.c_int64),
+                ('rows', C.c_int32), ('cols', C.c_int32), ('F', C.c_int32), ('reserved', C.c_int32)]
+
+
 class SweepArgs(C.Structure):
     _fields_ = [('B', C.c_int32), ('X', C.c_int32), ('n_pair_tables', C.c_int32),
                 ('n_unary_tables', C.c_int32), ('pair_tables', C.c_void_p), ('pair_tab', C.c_void_p),
@@ -110,6 +116,7 @@ SIGNATURES = {
     'mlbp_sparse_pointwise_multiply_f64': (C.c_int, [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _vp]),
     'mlbp_sparse_normalize_f64': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp]),
     'mlbp_potentials_f64': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'mlbp_potentials_multi_f64': (C.c_int, [_vp, _i32, _i32, _vp]),
     'mlbp_log_f64': (C.c_int, [_vp, _vp, _i64, _vp]),
     'mlbp_observed_minus_f64': (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
 }

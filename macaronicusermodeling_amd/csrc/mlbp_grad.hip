@@ -382,27 +382,43 @@ __device__ unsigned g_sum_done = 0;
 struct SumCat { const double* in[3]; int cols[3]; };       // up to three [rows][cols_i] arrays read as one [rows][sum cols] matrix
 
 __global__ __launch_bounds__(WG) void sum_rows_kernel(SumCat cat, int64_t rows, int append_count, double* out) {
-  __shared__ double part[WG];
+  // every thread sums ALL columns of its rows (fixed order), the columns then meet once: lanes by DPP, waves through
+  // LDS -- one barrier per launch instead of nine per column
+  __shared__ double part[WG / 64][64];
   __shared__ bool last;
   const int64_t per = (rows + SUM_PARTS - 1) / SUM_PARTS;
   const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int jout = 0;
   for (int a = 0; a < 3; ++a) {
     const double* in = cat.in[a];
     const int cols = cat.cols[a];
-    for (int j = 0; j < cols; ++j, ++jout) {
-      double acc = 0.0;
-      for (int64_t b = r0 + threadIdx.x; b < r1; b += WG) acc += in[b * cols + j];
-      part[threadIdx.x] = acc;
-      __syncthreads();
-      for (int s = WG / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
-        __syncthreads();
+    for (int j0 = 0; j0 < cols; j0 += 8) {                 // eight columns at a time in registers
+      const int nj = cols - j0 < 8 ? cols - j0 : 8;
+      double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      for (int64_t b = r0 + threadIdx.x; b < r1; b += WG) {
+        const double* row = in + b * cols + j0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nj) acc[j] += row[j];
       }
-      if (threadIdx.x == 0) g_sum_partials[blockIdx.x * 64 + jout] = part[0];
-      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < nj) {
+          const double v = wave_sum(acc[j]);
+          if (lane == 0) part[wave][jout + j] = v;
+        }
+      jout += nj;
     }
   }
+  __syncthreads();
+  if (threadIdx.x < jout) {
+    double v = part[0][threadIdx.x];
+    for (int w = 1; w < WG / 64; ++w) v += part[w][threadIdx.x];
+    g_sum_partials[blockIdx.x * 64 + threadIdx.x] = v;
+    __threadfence();                                         // visible device-wide before this workgroup counts itself done
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     __threadfence();
     last = atomicAdd(&g_sum_done, 1u) == SUM_PARTS - 1;

@@ -2,6 +2,7 @@
 // These back the drop-in `au.*` functions one call at a time (the fused sweep in mlbp_sweep.hip is
 // the performance path); they are written for correctness on arbitrary strides first.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include <cfloat>
 
@@ -189,6 +190,26 @@ __global__ void potentials_kernel(const double* phi, const double* theta, int ro
   }
 }
 
+struct PotentialsJobs { mlbp_potentials_job j[MLBP_POTENTIALS_MAX_JOBS]; };
+// blockIdx.y = job, blockIdx.z = repetition (parameter vector); the arithmetic of potentials_kernel
+__global__ void potentials_multi_kernel(PotentialsJobs js) {
+  const mlbp_potentials_job& J = js.j[blockIdx.y];
+  const int64_t n = (int64_t)J.rows * J.cols;
+  const double* theta = J.theta + (int64_t)blockIdx.z * J.theta_stride;
+  double* pot = J.pot ? J.pot + (int64_t)blockIdx.z * J.pot_stride : nullptr;
+  double* pot_t = J.pot_t ? J.pot_t + (int64_t)blockIdx.z * J.pot_t_stride : nullptr;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    double acc = 0.0;
+    for (int k = 0; k < J.F; ++k) acc += J.phi[e * J.F + k] * theta[k];
+    const double v = exp(acc);
+    if (pot) pot[e] = v;
+    if (pot_t) {
+      const int64_t i = e / J.cols, j = e - i * J.cols;
+      pot_t[j * J.rows + i] = v;
+    }
+  }
+}
+
 __global__ void log_kernel(const double* in, double* out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     out[i] = log(in[i]);
@@ -325,6 +346,26 @@ int mlbp_sparse_normalize_f64(double* m, int32_t n_cols, const int32_t* cidx, in
   hipLaunchKernelGGL(block_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, m, n_cols, cidx, Kc, ridx, Kr, scratch1);
   HIP_TRY(hipGetLastError());
   return launch_block_op(2, m, nullptr, scratch1, n_cols, cidx, Kc, ridx, Kr, m, stream);
+}
+
+int mlbp_potentials_multi_f64(const mlbp_potentials_job* jobs, int32_t n_jobs, int32_t n_rep, void* stream) {
+  if (!jobs || n_jobs < 1 || n_jobs > MLBP_POTENTIALS_MAX_JOBS || n_rep < 1 || n_rep > 65535)
+    return fail(MLBP_EINVAL, "mlbp_potentials_multi_f64: 1..%d jobs, 1..65535 repetitions", MLBP_POTENTIALS_MAX_JOBS);
+  PotentialsJobs js;
+  int64_t n_max = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const mlbp_potentials_job& J = jobs[j];
+    if (!J.phi || !J.theta || J.rows <= 0 || J.cols <= 0 || J.F <= 0 || (!J.pot && !J.pot_t))
+      return fail(MLBP_EINVAL, "mlbp_potentials_multi_f64: bad job %d", j);
+    js.j[j] = J;
+    n_max = std::max<int64_t>(n_max, (int64_t)J.rows * J.cols);
+  }
+  for (int j = n_jobs; j < MLBP_POTENTIALS_MAX_JOBS; ++j) js.j[j] = jobs[0];
+  if (int e = need_device()) return e;
+  const int blocks = (int)std::min<int64_t>((n_max + 255) / 256, 4096);
+  hipLaunchKernelGGL(potentials_multi_kernel, dim3(blocks, n_jobs, n_rep), dim3(256), 0, (hipStream_t)stream, js);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
 }
 
 int mlbp_potentials_f64(const double* phi, const double* theta, int32_t rows, int32_t cols, int32_t F, double* pot,

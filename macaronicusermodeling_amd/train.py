@@ -182,16 +182,22 @@ class UserGraphTrainer:
 
     def build_potentials(self):
         fb, X, st = self.batch, self.spec['X'], _stream_ptr(self.device)
-        for d in range(max(self.n_dom, 1)):             # per domain: its theta REPLACES the global one (train_mp.py:226-247)
-            t_ee = self.theta_dom_en_en[d] if self.n_dom else self.theta_en_en
-            t_ed = self.theta_dom_en_de[d] if self.n_dom else self.theta_en_de
-            ut = self.unary_tables[d * self.rows_per_dom:]
-            _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_en.data_ptr(), t_ee.data_ptr(), X, X, self.F_ee,
-                                                    self.pair_tables[2 * d].data_ptr(), ut[0:X].data_ptr(), st))
-            _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_en_w1.data_ptr(), t_ee.data_ptr(), X, X, self.F_ee,
-                                                    self.pair_tables[2 * d + 1].data_ptr(), ut[X:2 * X].data_ptr(), st))
-            _ffi.check(_ffi.lib.mlbp_potentials_f64(fb.phi_en_de.data_ptr(), t_ed.data_ptr(), X, self.Vde,
-                                                    self.F_ed, None, ut[2 * X:].data_ptr(), st))
+        # all three pots, for the global theta or for every domain's (its theta REPLACES the global one,
+        # train_mp.py:226-247), in ONE launch: pot_en_en / pot_en_en_w1 as pairwise tables and transposed rows, pot_en_de
+        # as transposed rows only
+        nd = max(self.n_dom, 1)
+        t_ee = self.theta_dom_en_en if self.n_dom else self.theta_en_en
+        t_ed = self.theta_dom_en_de if self.n_dom else self.theta_en_de
+        ut, pt = self.unary_tables, self.pair_tables
+        jobs = (_ffi.PotentialsJob * 3)()
+        for j, (phi, th, F, cols, pot, pot_t) in enumerate((
+                (fb.phi_en_en, t_ee, self.F_ee, X, pt[0].data_ptr(), ut[0:X].data_ptr()),
+                (fb.phi_en_en_w1, t_ee, self.F_ee, X, pt[1].data_ptr(), ut[X:2 * X].data_ptr()),
+                (fb.phi_en_de, t_ed, self.F_ed, self.Vde, None, ut[2 * X:].data_ptr()))):
+            jobs[j].phi, jobs[j].theta, jobs[j].pot, jobs[j].pot_t = phi.data_ptr(), th.data_ptr(), pot, pot_t
+            jobs[j].theta_stride, jobs[j].pot_stride, jobs[j].pot_t_stride = F, 2 * X * X, self.rows_per_dom * X
+            jobs[j].rows, jobs[j].cols, jobs[j].F = X, cols, F
+        _ffi.check(_ffi.lib.mlbp_potentials_multi_f64(jobs, 3, nd, st))
         self._patch_tables()
 
     def capture(self):

@@ -106,9 +106,11 @@ template <> struct Frag<float> {
 };
 
 // X = 64 * RT states; N_T = 16 * NCT graphs per workgroup.
-template <typename TT, int RT, int NCT, int DEPTH>
-__global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
+template <typename TT, int RT, int NCT, int DEPTH, int NW>
+__global__ __launch_bounds__(64 * NW) void contract_kernel(ContractDev d) {
   constexpr int X = 64 * RT, NT_G = 16 * NCT, XP = X + 2;
+  constexpr int RTW = 4 * RT / NW;                               // 16-row tiles per wave (wave w owns tiles w, w + NW, ...)
+  static_assert((4 * RT) % NW == 0 && NT_G % NW == 0, "");
   constexpr int KS = Frag<TT>::KSTEPS, KB = X / (4 * KS);       // 16-byte fragment blocks along k
   typedef typename Frag<TT>::vec avec;
   typedef typename Frag<TT>::lds_t mt_t;
@@ -121,37 +123,38 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
 
   // ---- prologue: the input messages of this workgroup's graphs -> LDS.  A wave takes NT_G / 4 consecutive graphs, four
   //      at a time, so that one round of memory latency covers four graphs; lane l holds states 2l, 2l+1 (+128 j) ----
-  constexpr int GPW = NT_G / 4, H = RT / 2 + (RT & 1);        // graphs per wave; double2 pieces per lane (odd RT: last half-used)
+  constexpr int GPW = NT_G / NW, GU = GPW < 4 ? GPW : 4;        // graphs per wave, and how many of them go through together
+  constexpr int H = RT / 2 + (RT & 1);                         // double2 pieces per lane (odd RT: last half-used)
   static_assert(RT % 2 == 0, "X must be a multiple of 128 here");
-  for (int g4 = 0; g4 < GPW; g4 += 4) {
-    double2 v[4][H];
-    const double* gin[4];
-    bool live[4];
+  for (int g4 = 0; g4 < GPW; g4 += GU) {
+    double2 v[GU][H];
+    const double* gin[GU];
+    bool live[GU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GU; ++u) {
       const int b = b0 + wave * GPW + g4 + u;
       live[u] = b < d.B;
       gin[u] = d.in + (size_t)(live[u] ? b : 0) * d.in_ld;
     }
     if (d.n_src == 0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < GU; ++u)
 #pragma unroll
         for (int j = 0; j < H; ++j) v[u][j] = reinterpret_cast<const double2*>(gin[u] + (size_t)d.in_slot * X)[lane + 64 * j];
     } else {
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < GU; ++u)
 #pragma unroll
         for (int j = 0; j < H; ++j) v[u][j] = make_double2(uniform, uniform);
       for (int q = 0; q < d.n_src; ++q) {
         const size_t so = (size_t)d.src[q] * X;
-        double2 m[4][H];
+        double2 m[GU][H];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < GU; ++u)
 #pragma unroll
           for (int j = 0; j < H; ++j) m[u][j] = reinterpret_cast<const double2*>(gin[u] + so)[lane + 64 * j];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < GU; ++u)
 #pragma unroll
           for (int j = 0; j < H; ++j) {
             double px = m[u][j].x * v[u][j].x, py = m[u][j].y * v[u][j].y;
@@ -160,23 +163,23 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
           }
       }
       if (d.normalize) {
-        double tot[4];
+        double tot[GU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < GU; ++u) {
           double part = 0.0;
 #pragma unroll
           for (int j = 0; j < H; ++j) part += v[u][j].x + v[u][j].y;
           tot[u] = wave_sum64(part);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < GU; ++u)
 #pragma unroll
           for (int j = 0; j < H; ++j)
             v[u][j] = tot[u] > 0.0 ? make_double2(v[u][j].x / tot[u], v[u][j].y / tot[u]) : make_double2(uniform, uniform);
       }
       if (d.vf_slot >= 0) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < GU; ++u)
           if (live[u]) {
             double2* o = reinterpret_cast<double2*>(d.out + (size_t)(b0 + wave * GPW + g4 + u) * d.out_ld + (size_t)d.vf_slot * X);
 #pragma unroll
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GU; ++u) {
       mt_t* row = Mt + (wave * GPW + g4 + u) * XP;
 #pragma unroll
       for (int j = 0; j < H; ++j) {
@@ -199,9 +202,9 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
   // ---- main loop ----
   const avec* Af = reinterpret_cast<const avec*>(d.frag);
   const int gcol = lane & 15, krow = lane >> 4;
-  double4_t acc[RT][NCT];
+  double4_t acc[RTW][NCT];
 #pragma unroll
-  for (int r = 0; r < RT; ++r)
+  for (int r = 0; r < RTW; ++r)
 #pragma unroll
     for (int c = 0; c < NCT; ++c) acc[r][c] = double4_t{0.0, 0.0, 0.0, 0.0};
   // DEPTH register sets of A fragments in rotation, each requested DEPTH / 2 whole steps before it is used (the loop is
@@ -212,10 +215,10 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
 #else
   constexpr int KB_RUN = KB;
 #endif
-  avec a[DEPTH][RT];
-  auto load_a = [&](avec (&dst)[RT], int kb) {
+  avec a[DEPTH][RTW];
+  auto load_a = [&](avec (&dst)[RTW], int kb) {
 #pragma unroll
-    for (int r = 0; r < RT; ++r) dst[r] = Af[((size_t)(wave + 4 * r) * KB + kb) * 64 + lane];
+    for (int r = 0; r < RTW; ++r) dst[r] = Af[((size_t)(wave + NW * r) * KB + kb) * 64 + lane];
   };
 #pragma unroll
   for (int s0 = 0; s0 < DIST; ++s0) load_a(a[s0], s0);
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
     // block = rows 4 blk .. 4 blk + 3; B_blk[k][j] at lane j + 4 blk + 16 k -- four graphs 4 q + j per instruction, the
     // same in every block (LDS broadcast); D_blk[i][j] at lane j + 4 blk + 16 i, i.e. accumulator q of a lane holds
     // (row 4 ((lane >> 2) & 3) + (lane >> 4), graph 4 q + (lane & 3)).
-    auto step = [&](const avec (&af)[RT], int kb) {
+    auto step = [&](const avec (&af)[RTW], int kb) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
 #ifdef MLBP_CONTRACT_16X16          // A/B build: the single-instruction form
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
 #pragma unroll
         for (int c = 0; c < NCT; ++c) bf[c] = Mt[(16 * c + gcol) * XP + 8 * kb + 4 * e + krow];
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
+        for (int r = 0; r < RTW; ++r)
 #pragma unroll
           for (int c = 0; c < NCT; ++c)
             acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(e ? af[r].y : af[r].x, bf[c], acc[r][c], 0, 0, 0);
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) bf[c][q] = Mt[(16 * c + 4 * q + (lane & 3)) * XP + 8 * kb + 4 * e + krow];
 #pragma unroll
-        for (int r = 0; r < RT; ++r)
+        for (int r = 0; r < RTW; ++r)
 #pragma unroll
           for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -265,15 +268,15 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
     }
   } else {
     // float32 products, summed in float32 over 64 states (4 fragment blocks) at a time, then added in float64
-    float4_t part[RT][NCT];
-    auto step = [&](const avec (&af4)[RT], int kb) {
+    float4_t part[RTW][NCT];
+    auto step = [&](const avec (&af4)[RTW], int kb) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float bf[NCT];
 #pragma unroll
         for (int c = 0; c < NCT; ++c) bf[c] = Mt[(16 * c + gcol) * XP + 16 * kb + 4 * e + krow];
 #pragma unroll
-        for (int r = 0; r < RT; ++r) {
+        for (int r = 0; r < RTW; ++r) {
           const float af = e == 0 ? af4[r].x : (e == 1 ? af4[r].y : (e == 2 ? af4[r].z : af4[r].w));
 #pragma unroll
           for (int c = 0; c < NCT; ++c) part[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[c], part[r][c], 0, 0, 0);
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
 #pragma unroll 1
     for (int kb = 0; kb < KB_RUN; kb += 4) {
 #pragma unroll
-      for (int r = 0; r < RT; ++r)
+      for (int r = 0; r < RTW; ++r)
 #pragma unroll
         for (int c = 0; c < NCT; ++c) part[r][c] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
         step(a[s0 % DEPTH], kb + s0);
       }
 #pragma unroll
-      for (int r = 0; r < RT; ++r)
+      for (int r = 0; r < RTW; ++r)
 #pragma unroll
         for (int c = 0; c < NCT; ++c)
 #pragma unroll
@@ -304,26 +307,26 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
   // result element (row, col) of a 16 x 16 tile: float64 (four 4x4x4 MFMAs): see the main loop; float32 MFMA:
   // col = lane & 15 (graph), row = 4 (lane >> 4) + i
 #pragma unroll
-  for (int r = 0; r < RT; ++r)
+  for (int r = 0; r < RTW; ++r)
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #ifndef MLBP_CONTRACT_16X16
         if (sizeof(TT) == 8) {
-          Ot[(16 * c + 4 * i + (lane & 3)) * XP + 16 * (wave + 4 * r) + 4 * ((lane >> 2) & 3) + krow] = acc[r][c][i];
+          Ot[(16 * c + 4 * i + (lane & 3)) * XP + 16 * (wave + NW * r) + 4 * ((lane >> 2) & 3) + krow] = acc[r][c][i];
           continue;
         }
 #endif
         const int row = sizeof(TT) == 8 ? krow + 4 * i : 4 * krow + i;
-        Ot[(16 * c + gcol) * XP + 16 * (wave + 4 * r) + row] = acc[r][c][i];
+        Ot[(16 * c + gcol) * XP + 16 * (wave + NW * r) + row] = acc[r][c][i];
       }
   __syncthreads();
-  for (int g4 = 0; g4 < GPW; g4 += 4) {
-    double2 v[4][H];
-    double tot[4];
+  for (int g4 = 0; g4 < GPW; g4 += GU) {
+    double2 v[GU][H];
+    double tot[GU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GU; ++u) {
       const double* row = Ot + (wave * GPW + g4 + u) * XP;
       double part = 0.0;
 #pragma unroll
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(WG) void contract_kernel(ContractDev d) {
       tot[u] = d.normalize ? wave_sum64(part) : 1.0;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GU; ++u) {
       const int b = b0 + wave * GPW + g4 + u;
       if (b < d.B) {
         double2* o = reinterpret_cast<double2*>(d.out + (size_t)b * d.out_ld + (size_t)d.dst_slot * X);
@@ -361,7 +364,12 @@ int launch_contract_rt(const ContractDev& d, int nct, hipStream_t st) {
   const int ntg = 16 * nct;
   const size_t lds = contract_lds_bytes<TT>(X, nct);
   // 32 graphs per workgroup: one workgroup per CU, deep fragment prefetch; 16: two per CU hide each other's stalls
-  void (*k)(ContractDev) = nct == 2 ? contract_kernel<TT, RT, 2, 4> : (sizeof(TT) == 8 ? contract_kernel<TT, RT, 1, 2> : contract_kernel<TT, RT, 1, 4>);
+  // 16 graphs per workgroup: 8 waves (two workgroups = 4 waves per SIMD hide each other's stalls; measured 3-5 % over 4 waves)
+  static const int nw = getenv("MLBP_CONTRACT_WAVES") ? atoi(getenv("MLBP_CONTRACT_WAVES")) : 8;       // A/B measurements
+  void (*k)(ContractDev) = nct == 2 ? contract_kernel<TT, RT, 2, 4, 4>
+                                    : (sizeof(TT) == 8 ? (nw == 8 ? contract_kernel<TT, RT, 1, 2, 8> : contract_kernel<TT, RT, 1, 2, 4>)
+                                                       : (nw == 8 ? contract_kernel<TT, RT, 1, 4, 8> : contract_kernel<TT, RT, 1, 4, 4>));
+  const int threads = (nct == 2 || nw != 8) ? WG : 512;
   static std::mutex mu;
   static std::vector<const void*> granted;
   {
@@ -374,7 +382,7 @@ int launch_contract_rt(const ContractDev& d, int nct, hipStream_t st) {
       granted.push_back((const void*)k);
     }
   }
-  hipLaunchKernelGGL(k, dim3((d.B + ntg - 1) / ntg), dim3(WG), lds, st, d);
+  hipLaunchKernelGGL(k, dim3((d.B + ntg - 1) / ntg), dim3(threads), lds, st, d);
   return MLBP_OK;
 }
 

@@ -30,6 +30,11 @@ from macaronicusermodeling_amd.topology import GraphTopology  # noqa: E402
 f32 = '--f32' in sys.argv
 spec, roots, sweeps, seed = bench.workload_spec('ring8_x512_shared')
 X, B = spec['X'], 8192
+for a_ in sys.argv[1:]:
+    if a_.startswith('--X='):
+        X = int(a_[4:])          # other table sizes of the same ring (128, 256, 384, 512)
+    if a_.startswith('--B='):
+        B = int(a_[4:])
 topo = GraphTopology.from_spec(spec)
 dev = torch.device('cuda:0')
 fb = FactorGraphBatch(topo, X, B, device=dev)
@@ -42,4 +47,4 @@ for rnd in range(4):
     s.record(); fb.sweep(roots, init=True); e.record(); torch.cuda.synchronize()
     ts.append(s.elapsed_time(e))
 n_upd = 16 * len(roots)
-print('%s%s: %.3f ms per %d-sweep call = %.1f us per update' % ('noloop ' if '--noloop' in sys.argv else 'full ', 'f32' if f32 else 'f64', min(ts), len(roots), 1e3 * min(ts) / n_upd))
+print('X=%d B=%d %s%s: %.3f ms per %d-sweep call = %.1f us per update = %.1f TFLOP/s' % (X, B, 'noloop ' if '--noloop' in sys.argv else 'full ', 'f32' if f32 else 'f64', min(ts), len(roots), 1e3 * min(ts) / n_upd, 2.0 * X * X * B * n_upd / (min(ts) * 1e-3) / 1e12))

@@ -1,6 +1,6 @@
 set -e
 export TMPDIR=/tmp
-T=${1:-r02l}
+T=${1:-r02m}
 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench_user_k3_b8192.json 2> gpurun_out/${T}.err
 MLBP_BENCH_SPINUP_STEPS=300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_prof_user_k3 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-skip-unchanged > /dev/null 2>&1
 cp $(find gpurun_out/${T}_prof_user_k3 -name "*kernel_stats.csv" | head -1) gpurun_out/${T}_kernel_stats_user_k3_b8192.csv

@@ -101,6 +101,9 @@ struct mlbp_program {
   bool last_was_pruned = false;     // the last sweep call ran the twin (mlbp_program_exact_count reads its flags)
   int32_t* d_limage = nullptr;   // LeanProgram::image
   int32_t* d_lreadout = nullptr; // build_lean_readout
+  int32_t* d_gtable = nullptr;   // group table of mlbp_sweep_groups_f64 calls that name this program first (launch_lean_groups)
+  size_t gtable_cap = 0;         // in words
+  std::vector<int32_t> h_gtable; // what d_gtable holds (a call uploads only when its table differs)
   // shared-table form (mlbp_shared.hip)
   mlbp::SharedProgram shared;
   int32_t* d_simage;      // SharedProgram::image

@@ -46,6 +46,8 @@ constexpr int UOP_PSLOT_SHIFT = 2;  // bits 2-4: pair slot (register-resident ta
 constexpr int UOP_NOP = 32;         // bit 5: empty second slot of a bundle
 constexpr int UOP_STORE_VF = 64;    // bit 6: the variable->factor message is stored (word 5)
 constexpr int UOP_NSRC_SHIFT = 8;   // bits 8-11: number of sources (1..4)
+constexpr int UOP_CARRY_IN = 0x1000;   // a link of a long variable product: starts from the running product in registers
+constexpr int UOP_CARRY_OUT = 0x2000;  // ... and hands it on instead of storing it
 constexpr int GROUP_WORDS = 48;     // one group descriptor of a MULTI launch (see launch_lean_groups)
 // micro-op words: 0 flags | 1-4 source byte offsets | 5 byte offset of the variable->factor message to store, or -1 |
 // 6 destination byte offset | 7 unused.  A bundle = two micro-ops = 16 words = one s_load_dwordx16.
@@ -416,6 +418,10 @@ __global__ __launch_bounds__(WG, (NT >= 7 ? 1 : (NT >= 4 ? 2 : 3))) void sweep_x
   }
   if (!__syncthreads_and(ok ? 1 : 0)) {       // an out-of-range table index: skip the graph, raise the status word
     if (t == 0) atomicExch(d.status, 1);
+    // "skipped" means untouched -- except that a call which was asked to initialise leaves the graph initialised
+    // (FactorGraph.initialize, LBP.py:211-216), not holding whatever the caller's buffer held
+    if (f.init)
+      for (int i = t; i < d.n_msgs * X; i += WG) gm[i] = uniform;
     return;
   }
   PSTAMP          // 2: unary messages normalised
@@ -458,6 +464,7 @@ __global__ __launch_bounds__(WG, (NT >= 7 ? 1 : (NT >= 4 ? 2 : 3))) void sweep_x
   lds_barrier();
   char* wb = reinterpret_cast<char*>(work);
   int parity = 0, bad = 0;
+  double carry = 1.0;
   const int4* li = reinterpret_cast<const int4*>(limg);
   int4 A0 = li[0], A1 = li[1], B0 = li[2], B1 = li[3];
   for (int k = 0; k < f.n_bundles && !PROBED(0); ++k) {
@@ -465,12 +472,17 @@ __global__ __launch_bounds__(WG, (NT >= 7 ? 1 : (NT >= 4 ? 2 : 3))) void sweep_x
     const int fA = __builtin_amdgcn_readfirstlane(A0.x), fB = __builtin_amdgcn_readfirstlane(B0.x);
     if (fA & UOP_VAR) {
       // a lone variable update: the product, lane = state, the same in every wave; no contraction, no barrier
+      // a product of more than four sources is a chain of links; the running product stays in a register between
+      // them and only the last link stores (every wave stores the same value once: no read-modify-write of a slot
+      // that another wave may still be writing)
       const int nsrc = (fA >> UOP_NSRC_SHIFT) & 15;
       double m = work[(A0.y >> 3) + lane];
+      if (fA & UOP_CARRY_IN) m *= carry;
       if (nsrc > 1) m *= work[(A0.z >> 3) + lane];
       if (nsrc > 2) m *= work[(A0.w >> 3) + lane];
       if (nsrc > 3) m *= work[(A1.x >> 3) + lane];
-      work[(A1.y >> 3) + lane] = m;
+      if (fA & UOP_CARRY_OUT) carry = m;
+      else work[(A1.y >> 3) + lane] = m;
     } else {
       char* redP = reinterpret_cast<char*>(red) + parity * 4096;
       front<NT, NL>(tab, tl + t, wb, fA, A0, A1, G, redP);
@@ -596,7 +608,8 @@ int ensure_lds(const void* fn, size_t bytes) {
 namespace mlbp {
 
 // FusedProgram -> micro-ops.  Every operand becomes an LDS byte offset (slot * 512); a variable product with more
-// than four sources is split into a chain of variable-only micro-ops that accumulate in its destination slot.
+// than four sources is split into a chain of variable-only micro-ops ("links") that hand the running product on in a
+// register (UOP_CARRY_OUT / UOP_CARRY_IN); only the last link stores.
 // Image: bundles [n_bundles][16] | per-wave hoist lists [4][HL][2] | constant-product lists [n_cprod][16] |
 // per-wave written-slot lists [4][WL] | one bundle of padding (the loop prefetches one bundle past the end).
 void build_lean_program(const FusedProgram& fp, int n_msgs, LeanProgram& out) {
@@ -606,18 +619,16 @@ void build_lean_program(const FusedProgram& fp, int n_msgs, LeanProgram& out) {
   std::vector<char> second;                          // micro-op i is the second member of a bundle
   auto emit_var = [&](const int32_t* src, int n, int c) {      // work[c] = prod(src[0..n))
     int done = 0;
-    bool first = true;
-    while (done < n || first) {
+    do {
       int32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       int k = 0;
-      if (!first) w[1 + k++] = c * 512;
+      const bool first = done == 0;
       while (k < 4 && done < n) w[1 + k++] = src[done++] * 512;
-      w[0] = UOP_VAR | (k << UOP_NSRC_SHIFT);
+      w[0] = UOP_VAR | (k << UOP_NSRC_SHIFT) | (first ? 0 : UOP_CARRY_IN) | (done < n ? UOP_CARRY_OUT : 0);
       w[5] = c * 512;
       U.insert(U.end(), w, w + 8);
       second.push_back(0);
-      first = false;
-    }
+    } while (done < n);
   };
   const int n_fops = (int)fp.fops.size() / 8;
   for (int i = 0; i < n_fops; ++i) {
@@ -835,8 +846,10 @@ int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* 
 }
 
 // Several (program, arguments) groups in ONE launch of the lean kernel.  *launched stays false when some group does not
-// qualify (the caller then runs the groups one by one).  The group table lives in a process-wide device buffer that
-// is rewritten, stream-ordered, by every call: calls on different streams must not overlap.
+// qualify (the caller then runs the groups one by one).  The group table lives in a device buffer owned by the FIRST
+// program of the call (like its redo flags: one stream at a time per program) and is uploaded only when its contents
+// differ from the last call's, so a repeated call -- the trainer's every step -- is enqueue-only and can be captured
+// into a HIP graph after one warm-up call.
 int launch_lean_groups(const mlbp_program* const* progs, const mlbp_sweep_args* args, int n_groups, void* stream, bool* launched) {
   *launched = false;
   if (n_groups < 1) return MLBP_OK;
@@ -868,21 +881,22 @@ int launch_lean_groups(const mlbp_program* const* progs, const mlbp_sweep_args* 
     w[30] = d.n_vars; w[31] = d.n_pair_tables; w[32] = d.n_unary_tables; w[33] = f.dense;
     total += args[k].B;
   }
-  static int32_t* d_table = nullptr;
-  static size_t cap = 0;
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
-  if (table.size() > cap) {
-    if (d_table) (void)hipFree(d_table);
-    d_table = nullptr; cap = 0;
-    HIP_TRY(hipMalloc(&d_table, table.size() * sizeof(int32_t)));
-    cap = table.size();
+  mlbp_program* owner = const_cast<mlbp_program*>(progs[0]);
+  if (table.size() > owner->gtable_cap) {
+    (void)hipFree(owner->d_gtable);
+    owner->d_gtable = nullptr; owner->gtable_cap = 0; owner->h_gtable.clear();
+    HIP_TRY(hipMalloc(&owner->d_gtable, table.size() * sizeof(int32_t)));
+    owner->gtable_cap = table.size();
   }
-  HIP_TRY(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
-  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));        // the host vector is about to go away (pageable copy: already staged; belt and braces)
+  if (owner->h_gtable != table) {
+    // stream-ordered behind any launch still reading the old table; the source is the program's own host copy, which
+    // lives until the next change
+    owner->h_gtable = table;
+    HIP_TRY(hipMemcpyAsync(owner->d_gtable, owner->h_gtable.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+  }
   void (*k)(SweepDev, LeanDev, const int32_t*, int) = pick_lean<true>(p_max, false);
   if (int e = ensure_lds((const void*)k, lds_max)) return e;
-  hipLaunchKernelGGL(k, dim3(total), dim3(WG), lds_max, (hipStream_t)stream, d0, f0, d_table, n_groups);
+  hipLaunchKernelGGL(k, dim3(total), dim3(WG), lds_max, (hipStream_t)stream, d0, f0, owner->d_gtable, n_groups);
   HIP_TRY(hipGetLastError());
   *launched = true;
   return MLBP_OK;

@@ -47,9 +47,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
-KERNEL_NAMES = {0: 'sweep_x64_kernel (first generation)',
-                1: 'scale-free X=64 kernel (include/mlbp.h MLBP_KERNEL_SCALE_FREE) + the ~5 us fix-up pass of sweep_x64_fused_kernel, timed together',
-                2: 'sweep_x64_fused_kernel (exact)',
+KERNEL_NAMES = {2: 'sweep_x64_fused_kernel (exact)',
                 3: 'sweep_x64_shared_kernel (v_mfma_f64_16x16x4_f64; timed region also holds the flag memset and the fix-up pass)',
                 4: 'sweep_wide_kernel', 5: 'sweep_generic_kernel',
                 7: 'sweep_x64_lean_kernel (scale-free, micro-op form) + the ~5 us fix-up pass of sweep_x64_fused_kernel, timed together',
@@ -462,6 +460,48 @@ def main():
         else:
             skip = {'updates_in_schedule': n_all, 'updates_dropped': 0}
 
+    # SURVEY.md 8(d) config 3 reads "3 sweeps, then gradient" (LBP.py:301-327): the optimisation step of train_mp.py:381-400
+    # on the same batch -- initialize + sweeps + per-graph gradient + log-posterior + the batch sums of batch_sgd_accumulate --
+    # timed after the windows (HIP events, rank 0), never `value`.
+    train = None
+    if rank == 0 and spec['style'] == 'trainmp' and X == 64:
+        by_id = {f['id']: f for f in spec['factors']}
+        pair_phi = [0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1 for j in topo.pair_factors]
+        ukind = [2 if by_id[topo.factor_ids[j]]['factor_type'] == 'en_de' else (0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1)
+                 for j in topo.unary_factors]
+        rs = np.random.RandomState(seed + 5)
+        Vde = spec['Vde']
+        fb.set_features(rs.rand(X, X, 3), rs.rand(X, X, 3), rs.rand(X, Vde, 6), pair_phi, ukind)
+        obs = np.stack([rs.randint(0, Vde if k == 2 else X, size=B) for k in ukind], axis=1)
+        if a.workload.endswith('_trainlayout'):
+            obs = unary_tab - np.array(ukind)[None, :] * 64           # the observed word IS the row a factor reads
+        fb.set_observations(labels, obs)
+        g_ee = torch.empty(B, 3, dtype=torch.float64, device=dev)
+        g_ed = torch.empty(B, 6, dtype=torch.float64, device=dev)
+        tstat = torch.zeros(16, dtype=torch.float64, device=dev)
+
+        def train_step():
+            fb.sweep(roots, init=True, marginals=marg, gradient=(g_ee, g_ed), keep_messages=False)
+            _ffi.check(_ffi.lib.mlbp_log_posterior_f64(marg.data_ptr(), labels_d.data_ptr(), B, topo.n_vars, X, lp.data_ptr(), _stream_ptr(dev)))
+            _ffi.check(_ffi.lib.mlbp_sum_rows_cat_f64(g_ee.data_ptr(), 3, g_ed.data_ptr(), 6, lp.data_ptr(), 1, B, 1, tstat.data_ptr(), _stream_ptr(dev)))
+        for _ in range(5):
+            train_step()
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_ev.record()
+        for _ in range(a.steps):
+            train_step()
+        e_ev.record()
+        torch.cuda.synchronize()
+        t_kernel = _ffi.lib.mlbp_last_sweep_kernel()
+        fused = (g_ee.clone(), g_ed.clone())
+        fb.sweep(roots, init=True, marginals=marg)                       # second opinion: the standalone gradient kernel on the
+        sep = fb.gradient()                                              # messages this sweep leaves in memory
+        train = {'ms': s_ev.elapsed_time(e_ev) / a.steps, 'kernel': KERNEL_NAMES.get(t_kernel, str(t_kernel)),
+                 'contents': 'initialize + %d sweeps + get_unregularized_gradeint of every graph (LBP.py:301-320; fused into the sweep '
+                             'launch when the kernel keeps the tables on chip) + get_posterior_probs + batch sums; messages not written back' % sweeps,
+                 'max_abs_difference_to_standalone_gradient_kernel': float(max((fused[0] - sep[0]).abs().max().item(), (fused[1] - sep[1]).abs().max().item())),
+                 'gradient_status': int(_ffi.lib.mlbp_gradient_status()), 'flagged_graphs': int(fb.program(roots).exact_count(B))}
+
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         iters_per_s = world * (B / 8192.0) * sweeps * a.steps / elapsed
@@ -536,6 +576,7 @@ def main():
             'roofline': roof,
             'cpu_baseline': cpu,
             'skip_unchanged': skip,
+            'train_step': train,
         }
         if cpu is not None:
             out['parity'] = parity_sample(spec, topo, roots, fb, marg)

@@ -30,9 +30,11 @@
  *     on one stream, or be ordered by the caller;
  *   - calls with DIFFERENT programs may run on different streams concurrently, with two exceptions that share
  *     process-wide scratch and must not overlap across streams: the shared-table path at X >= 128 (sweeps and gradient;
- *     its fragment and product buffers) and mlbp_log_posterior_sum_f64 (its block partials);
- *   - scratch buffers (redo flags, fragment copies, spill areas) are allocated at the first call that needs them -- that
- *     call is not enqueue-only; mlbp_program_reserve and one eager step before stream capture move all of it up front;
+ *     its fragment and product buffers) and mlbp_log_posterior_sum_f64 (its block partials); a mlbp_sweep_groups_f64 call
+ *     counts as a use of EVERY program it names (its group table lives with the first one);
+ *   - scratch buffers (redo flags, fragment copies, spill areas, group tables) are allocated -- and a group table
+ *     uploaded -- at the first call that needs them or changes them: that call is not enqueue-only;
+ *     mlbp_program_reserve and one eager step with the same arguments before stream capture move all of it up front;
  *   - mlbp_set_sweep_variant and the status words behind mlbp_gradient_status are process-wide.
  */
 #ifndef MLBP_H
@@ -252,33 +254,26 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
  * ALL groups in a single launch, followed by one small fix-up launch per group.  progs / args are HOST arrays. */
 int mlbp_sweep_groups_f64(const mlbp_program* const* progs, const mlbp_sweep_args* args, int32_t n_groups, void* stream);
 
-/* Kernel-variant selector for A/B measurement (not needed in normal use; also settable through the
- * MLBP_SWEEP_VARIANT environment variable):
- *   1     default: for X = 64 the scale-free kernel (messages carried with an exact power-of-two
- *         scale, true normalisation deferred to the end of the call, one barrier per update) in its
- *         micro-op form (mlbp_lean.hip) followed by the exact fused kernel on the graphs it flagged as
- *         degenerate;
- *   2     as 1 with the first form of the scale-free kernel (sweep_x64_sf_kernel);
- *   3     exact fused kernel only (normalises after every update like the reference);
- *   0     first-generation kernel;   10+N  exact fused kernel with N register-resident tables
- *         (N = 0 streams);           20+N  scale-free kernel with N resident tables (N = 1..4);
- *   30    as 1 (kept distinct for A/B scripts): shared-table MFMA kernel when the launch qualifies.
- * Variants other than 1 and 30 never use the shared-table kernel.
- * All variants compute every update from the same inputs as the reference's order does (the X = 64
- * program form may reorder independent updates and skips updates whose result is overwritten unread);
- * exact variants agree bitwise, the scale-free and shared-table ones to rounding. */
+/* Kernel selector for the parity tests (process-wide; not needed in normal use):
+ *   1     default: the fast kernels -- for X <= 64 the lean scale-free kernel (messages carried with an exact
+ *         power-of-two scale, true normalisation deferred to the end of the call, mlbp_lean.hip), for shared tables the
+ *         matrix-core kernels -- each followed by the exact kernel on the graphs it flagged as degenerate;
+ *   3     the exact kernel (normalises after every update like the reference) and the per-graph streaming kernels on
+ *         every graph: the tests' second opinion on the same inputs.
+ * Both compute every update from the same inputs as the reference's order does (the X = 64 program form may reorder
+ * independent updates and skips updates whose result is overwritten unread); they agree to rounding.  Other values
+ * (the kernel generations retired in round 3) return MLBP_EINVAL. */
 int mlbp_set_sweep_variant(int32_t variant);
 
 /* Diagnostic: which kernel family the calling thread's last mlbp_sweep_f64 enqueued first (the exact
- * kernel may follow it for flagged graphs); -1 before the first call. */
-#define MLBP_KERNEL_FIRST_GEN 0
-#define MLBP_KERNEL_SCALE_FREE 1
+ * kernel may follow it for flagged graphs); -1 before the first call.  (0 and 1 were the first-generation and the first
+ * scale-free kernel, retired.) */
 #define MLBP_KERNEL_EXACT 2
 #define MLBP_KERNEL_SHARED_MFMA 3
 #define MLBP_KERNEL_WIDE 4
 #define MLBP_KERNEL_GENERIC 5
 #define MLBP_KERNEL_SHARED_GEMM 6
-#define MLBP_KERNEL_LEAN 7            /* scale-free X = 64 kernel, micro-op form (mlbp_lean.hip): the default */
+#define MLBP_KERNEL_LEAN 7            /* scale-free X <= 64 kernel, micro-op form (mlbp_lean.hip): the default */
 int mlbp_last_sweep_kernel(void);
 
 /* Fills msgs[B][n_msgs][X] with 1/X: FactorGraph.initialize (LBP.py:211-216). */

@@ -178,7 +178,7 @@ class FactorGraphBatch:
         after the last sweep, read out of the on-chip messages in the same launch; gradient: optional
         (out_ee [B][F_ee], out_ed [B][F_ed]) device tensors that receive the per-graph gradients
         (set_features / set_observations first), fused into the launch when the kernel allows;
-        keep_messages=False lets a shared-table launch with a fused read-out skip the write-back of
+        keep_messages=False lets a launch whose read-outs (marginals, gradient) are fused skip the write-back of
         self.msgs (their contents are then undefined); skip_unchanged (default: self.skip_unchanged, False) drops the
         updates of the root sequence that would recompute a message from unchanged inputs (MLBP_SWEEP_SKIP_UNCHANGED:
         same output bits, fewer updates)."""
@@ -213,8 +213,8 @@ class FactorGraphBatch:
             a.flags |= _ffi.SWEEP_SHARED_PAIR_TABLES
             if getattr(self, '_pair_row_host', None) is not None:       # X >= 128: the update-by-update contraction path needs the row on the host
                 a.pair_tab_host = self._pair_row_host.ctypes.data
-            if not keep_messages and (marginals is not None or gradient is not None):
-                a.flags |= _ffi.SWEEP_NO_MESSAGE_WRITEBACK
+        if not keep_messages and (marginals is not None or gradient is not None):
+            a.flags |= _ffi.SWEEP_NO_MESSAGE_WRITEBACK      # honoured by the kernels whose read-outs are fused (lean, shared)
         if marginals is not None:
             if tuple(marginals.shape) != (self.B, self.topo.n_vars, self.X) or marginals.dtype != torch.float64:
                 raise ValueError('marginals must be float64 [B][n_vars][X]')

@@ -68,6 +68,11 @@ __device__ __forceinline__ const_i32p as_const(const int32_t* p) {
   return (const_i32p)(uintptr_t)p;
 }
 
+typedef const double __attribute__((address_space(4))) * const_f64p;
+__device__ __forceinline__ const_f64p as_const_f64(const double* p) {
+  return (const_f64p)(uintptr_t)p;
+}
+
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true));
   v = max(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true));
@@ -107,6 +112,17 @@ struct SweepDev {
   int32_t fill_uniform;
   int32_t approx_k;            // > 0: use_approx_inference (LBP.py:506-507, 515-516): only the approx_k largest entries of the
                                // incoming message enter a pairwise update (au.sparse_vec_mat_dot, c_array_utils.pyx:193-205)
+};
+
+// Gradient fused into a sweep launch (X = 64, F = (3, 6), tables still on chip): what FactorGraph.get_unregularized_gradeint
+// (LBP.py:301-320) needs besides the messages and tables the workgroup already holds.
+struct GradFusedDev {
+  const int32_t* pair_c_slot; const int32_t* pair_r_slot; const int32_t* pair_phi; const int32_t* pair_label;
+  const int32_t* unary_kind; const int32_t* unary_obs; const int32_t* unary_label;
+  const double* phi_en_en; const double* phi_en_en_w1;
+  const double* phi_en_en_t; const double* phi_en_en_w1_t; const double* phi_en_de_t;
+  double* grad_en_en; double* grad_en_de;
+  int32_t Vde, enabled;
 };
 
 }  // namespace mlbp_dev

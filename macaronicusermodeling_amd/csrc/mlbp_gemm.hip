@@ -365,7 +365,7 @@ int launch_contract_rt(const ContractDev& d, int nct, hipStream_t st) {
   const size_t lds = contract_lds_bytes<TT>(X, nct);
   // 32 graphs per workgroup: one workgroup per CU, deep fragment prefetch; 16: two per CU hide each other's stalls
   // 16 graphs per workgroup: 8 waves (two workgroups = 4 waves per SIMD hide each other's stalls; measured 3-5 % over 4 waves)
-  static const int nw = getenv("MLBP_CONTRACT_WAVES") ? atoi(getenv("MLBP_CONTRACT_WAVES")) : 8;       // A/B measurements
+  constexpr int nw = 8;
   void (*k)(ContractDev) = nct == 2 ? contract_kernel<TT, RT, 2, 4, 4>
                                     : (sizeof(TT) == 8 ? (nw == 8 ? contract_kernel<TT, RT, 1, 2, 8> : contract_kernel<TT, RT, 1, 2, 4>)
                                                        : (nw == 8 ? contract_kernel<TT, RT, 1, 4, 8> : contract_kernel<TT, RT, 1, 4, 4>));
@@ -391,7 +391,6 @@ template <typename TT>
 int launch_contract(const ContractDev& d, int X, hipStream_t st) {
   const bool f32 = sizeof(TT) == 4;
   int nct = (!f32 && X <= 256 && d.B >= 32 * 512) ? 2 : 1;     // small tables: fewer passes over the table per graph
-  if (const char* e = getenv("MLBP_CONTRACT_NCT")) nct = atoi(e) == 2 && !f32 ? 2 : 1;       // A/B measurements
   switch (X) {
     case 128: return launch_contract_rt<TT, 2>(d, nct, st);
     case 256: return launch_contract_rt<TT, 4>(d, nct, st);

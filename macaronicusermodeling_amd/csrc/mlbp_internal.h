@@ -7,6 +7,8 @@
 
 #include "../../include/mlbp.h"
 
+namespace mlbp_dev { struct GradFusedDev; }
+
 struct mlbp_program;
 
 namespace mlbp {
@@ -35,7 +37,8 @@ void build_lean_program(const FusedProgram& fp, int n_msgs, LeanProgram& out);
 bool build_lean_readout(const LeanProgram& lp, int n_msgs, int n_vars, const int32_t* in_off, const int32_t* in_slots,
                         std::vector<int32_t>& image);
 // Enqueues the lean scale-free kernel when it applies (sets *launched); flagged graphs are left in prog->d_bail.
-int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched);
+// gf != NULL: the call's gradient runs as the kernel's epilogue (P <= 3, every unary message hoisted, F = (3, 6)).
+int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, const mlbp_dev::GradFusedDev* gf, void* stream, bool* launched);
 // The same for several (program, arguments) groups in one launch; *launched false = some group does not qualify.
 int launch_lean_groups(const mlbp_program* const* progs, const mlbp_sweep_args* args, int n_groups, void* stream, bool* launched);
 

@@ -209,6 +209,145 @@ __device__ __forceinline__ void front(const double2 (&tab)[NT][4][2], const doub
   }
 }
 
+// FactorGraph.get_unregularized_gradeint (LBP.py:301-320) for one graph, from what the workgroup still holds after its
+// sweeps: tables in registers (4 x 4 blocks), messages in LDS.  Pairwise factor (LBP.py:543-569, 592-619): beliefs =
+// normalize((c r^T) (.) T), gradient = phi[label cell] - sum_ij beliefs_ij phi_ij -- the scale of c and r cancels, so the
+// scaled messages serve as they are, and the 64 x 64 belief matrix is never formed: each thread folds its 16 cells into
+// Z and three feature sums.  Unary factor (LBP.py:535-541, 600-603): beliefs = au.normalize(table), which IS the factor's
+// hoisted message whenever the table's total is positive (else zero); its expected features are accumulated per lane over
+// the wave's factors and reduced once.  gst: [U] message slot, [U] total positive, [U] kind, [U] observed column, [U] label.
+template <int NT>
+__device__ __forceinline__ void gradient_epilogue(const SweepDev& d, const GradFusedDev& gf, const double2 (&tab)[NT][4][2],
+                                                  const char* wb, const int32_t* gst, double* scratch, const LaneGeo& G, int g,
+                                                  int R_, int c_, int b3_) {
+  constexpr int FEE = 3, FED = 6;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  double pacc[NT][FEE + 1];
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+#pragma unroll
+    for (int q = 0; q <= FEE; ++q) pacc[p][q] = 0.0;
+    if (p < d.P) {
+      const int cs = as_const(gf.pair_c_slot)[p], rs = as_const(gf.pair_r_slot)[p];
+      const double* phi = as_const(gf.pair_phi)[p] ? gf.phi_en_en_w1 : gf.phi_en_en;        // interleaved [64][64][3]
+      const double2 ca = lds2(wb + cs * 512 + G.mt), cb = lds2(wb + cs * 512 + G.mt + 16);
+      const double2 r0 = lds2(wb + rs * 512 + G.tm0), r1 = lds2(wb + rs * 512 + G.tm1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double ci = r == 0 ? ca.x : (r == 1 ? ca.y : (r == 2 ? cb.x : cb.y));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const double2 rj = k ? r1 : r0, T = tab[p][r][k];
+          const double w0 = (ci * rj.x) * T.x, w1 = (ci * rj.y) * T.y;
+          const int col = 32 * (k ? 1 - b3_ : b3_) + 2 * c_;
+          const double2* ph = reinterpret_cast<const double2*>(phi + ((size_t)(4 * R_ + r) * 64 + col) * FEE);   // 48 bytes, 16-aligned
+          const double2 f01 = ph[0], f2g0 = ph[1], g12 = ph[2];          // cell (i, col): f0 f1 f2 | cell (i, col + 1): g0 g1 g2
+          pacc[p][0] += w0 + w1;
+          pacc[p][1] += w0 * f01.x + w1 * f2g0.y;
+          pacc[p][2] += w0 * f01.y + w1 * g12.x;
+          pacc[p][3] += w0 * f2g0.x + w1 * g12.y;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q <= FEE; ++q) pacc[p][q] = wave_sum(pacc[p][q]);
+    }
+  }
+  // unary factors: wave w takes factors w, w + 4, ...; three at a time so that their feature slabs are in flight together
+  double lab_ee[FEE] = {0.0, 0.0, 0.0}, lab_ed[FED] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // phi at the label (wave-uniform)
+  double exp_ee[FEE] = {0.0, 0.0, 0.0}, exp_ed[FED] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // per-lane partial expected features
+  bool bad = false;
+  constexpr int UB = 3;
+  const int U = d.U;
+  for (int u0 = wave; u0 < U; u0 += 4 * UB) {
+    double b[UB], pv[UB][FED];
+    int kd[UB], at[UB];
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      const int u = u0 + 4 * j;
+      kd[j] = -1;
+      if (u < U) {
+        const int kind = __builtin_amdgcn_readfirstlane(gst[2 * U + u]), obs = __builtin_amdgcn_readfirstlane(gst[3 * U + u]);
+        const int lab = __builtin_amdgcn_readfirstlane(gst[4 * U + u]);
+        const int cols = kind == 2 ? gf.Vde : 64;
+        if ((unsigned)obs >= (unsigned)cols || (unsigned)lab >= 64u || (unsigned)kind > 2u) { bad = true; continue; }
+        kd[j] = kind;
+        const int slot = __builtin_amdgcn_readfirstlane(gst[u]);
+        b[j] = __builtin_amdgcn_readfirstlane(gst[U + u]) ? *reinterpret_cast<const double*>(wb + slot * 512 + lane * 8) : 0.0;
+        if (kind == 2) {
+          const double2* ph = reinterpret_cast<const double2*>(gf.phi_en_de_t + ((size_t)obs * 64 + lane) * FED);
+          at[j] = (obs * 64 + lab) * FED;
+          const double2 a0 = ph[0], a1 = ph[1], a2 = ph[2];
+          pv[j][0] = a0.x; pv[j][1] = a0.y; pv[j][2] = a1.x; pv[j][3] = a1.y; pv[j][4] = a2.x; pv[j][5] = a2.y;
+        } else {
+          const double* ph = (kind ? gf.phi_en_en_w1_t : gf.phi_en_en_t) + ((size_t)obs * 64 + lane) * FEE;
+          at[j] = (obs * 64 + lab) * FEE;
+#pragma unroll
+          for (int q = 0; q < FEE; ++q) pv[j][q] = ph[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      if (kd[j] == 2) {
+#pragma unroll
+        for (int q = 0; q < FED; ++q) { lab_ed[q] += as_const_f64(gf.phi_en_de_t)[at[j] + q]; exp_ed[q] += b[j] * pv[j][q]; }
+      } else if (kd[j] >= 0) {
+        const double* base = kd[j] ? gf.phi_en_en_w1_t : gf.phi_en_en_t;
+#pragma unroll
+        for (int q = 0; q < FEE; ++q) { lab_ee[q] += as_const_f64(base)[at[j] + q]; exp_ee[q] += b[j] * pv[j][q]; }
+      }
+    }
+  }
+  if (bad && lane == 0) atomicExch(d.status, 1);
+  // combine the four waves: per wave NT * (FEE + 1) pair sums, then FEE + FED unary sums
+  constexpr int PER = NT * (FEE + 1) + FEE + FED;
+  {
+    double ue[FEE], ud[FED];
+#pragma unroll
+    for (int q = 0; q < FEE; ++q) ue[q] = lab_ee[q] - wave_sum(exp_ee[q]);
+#pragma unroll
+    for (int q = 0; q < FED; ++q) ud[q] = lab_ed[q] - wave_sum(exp_ed[q]);
+    if (lane == 0) {
+      double* o = scratch + wave * PER;
+#pragma unroll
+      for (int p = 0; p < NT; ++p)
+#pragma unroll
+        for (int q = 0; q <= FEE; ++q) o[p * (FEE + 1) + q] = pacc[p][q];
+#pragma unroll
+      for (int q = 0; q < FEE; ++q) o[NT * (FEE + 1) + q] = ue[q];
+#pragma unroll
+      for (int q = 0; q < FED; ++q) o[NT * (FEE + 1) + FEE + q] = ud[q];
+    }
+  }
+  lds_barrier();
+  if (t == 0) {
+    double tot[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) tot[q] = (scratch[q] + scratch[PER + q]) + (scratch[2 * PER + q] + scratch[3 * PER + q]);
+    double gee[FEE];
+#pragma unroll
+    for (int q = 0; q < FEE; ++q) gee[q] = tot[NT * (FEE + 1) + q];
+    bool lbad = false;
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+      if (p < d.P) {
+        const int l0 = gf.pair_label[((size_t)g * d.P + p) * 2], l1 = gf.pair_label[((size_t)g * d.P + p) * 2 + 1];
+        if ((unsigned)l0 >= 64u || (unsigned)l1 >= 64u) { lbad = true; continue; }
+        const double* phi = gf.pair_phi[p] ? gf.phi_en_en_w1 : gf.phi_en_en;
+        const double Z = tot[p * (FEE + 1)];
+#pragma unroll
+        for (int q = 0; q < FEE; ++q)
+          gee[q] += phi[((size_t)l0 * 64 + l1) * FEE + q] - (Z > 0.0 ? tot[p * (FEE + 1) + 1 + q] / Z : 0.0);     // au.normalize: zero sum -> 0
+      }
+    }
+    if (lbad) atomicExch(d.status, 1);
+#pragma unroll
+    for (int q = 0; q < FEE; ++q) gf.grad_en_en[(size_t)g * FEE + q] = gee[q];
+#pragma unroll
+    for (int q = 0; q < FED; ++q) gf.grad_en_de[(size_t)g * FED + q] = tot[NT * (FEE + 1) + FEE + q];
+  }
+}
+
 // The 64 partial results of one update (lane = state), rescaled by an exact power of two so that ONE normal element
 // lands in [1, 2) (the first one; which one is immaterial -- the scale cancels in everything normalised later).
 // `bad` is raised when the vector cannot be carried this way: a negative / non-finite entry, or no normal entry at all
@@ -230,9 +369,11 @@ __device__ __forceinline__ double rescale(double r, int& bad) {
 // train_mp.py:257-299), sweep in one launch.
 // NL: tables NT .. NT+NL-1 of the graph live in LDS instead of registers (a 7-table chain then fits 242 VGPRs + 70 KB, so two
 // workgroups share a CU, where 8 register-resident tables allow one).
-template <int NT, bool PADX, bool MULTI, int NL>
+// GRAD: FactorGraph.get_unregularized_gradeint (LBP.py:301-320) of the graph as an epilogue (gradient_epilogue): the tables
+// are still in registers and the messages in LDS, so the per-graph gradient costs no second pass over the tables in HBM.
+template <int NT, bool PADX, bool MULTI, int NL, bool GRAD>
 __global__ __launch_bounds__(WG, (NT >= 7 ? 1 : (NT >= 4 ? 2 : 3))) void sweep_x64_lean_kernel(SweepDev d, LeanDev f, const int32_t* groups,
-                                                                                             int n_groups) {
+                                                                                             int n_groups, GradFusedDev gf) {
   int g = blockIdx.x;
   if (MULTI) {
     // groups[k * GROUP_WORDS] = first graph of group k (ascending): the last k with start <= g
@@ -259,6 +400,8 @@ __global__ __launch_bounds__(WG, (NT >= 7 ? 1 : (NT >= 4 ? 2 : 3))) void sweep_x
   double* red = lds + (size_t)(d.n_msgs + f.n_ext) * 64;     // [2 parities][2 bundle slots][4][64]
   int32_t* limg = reinterpret_cast<int32_t*>(red + 4 * 256);      // [n_bundles + 1][16] micro-ops
   double2* tl = reinterpret_cast<double2*>(limg + 16 * (f.n_bundles + 1));      // [NL][8][256] tables kept in LDS
+  // GRAD: per unary factor -- message slot, table total positive?, kind, observed column, label
+  int32_t* gst = reinterpret_cast<int32_t*>(tl + (size_t)NL * 8 * WG);
 
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int X = PADX ? d.X : 64;
@@ -287,18 +430,23 @@ __global__ __launch_bounds__(WG, (NT >= 7 ? 1 : (NT >= 4 ? 2 : 3))) void sweep_x
   PROBE_DECL
   PSTAMP          // 0: start
   if (t == 0) f.bail[g] = 0;
+  int g_kind = 0, g_obs = 0, g_lab = 0;           // GRAD: unary factor t's kind / observed column / label, parked until the
+  if (GRAD && t < d.U) {                          // unary rows have landed (the loads retire in order ahead of them)
+    g_kind = gf.unary_kind[t]; g_obs = gf.unary_obs[(size_t)g * d.U + t]; g_lab = gf.unary_label[(size_t)g * d.U + t];
+  }
   // ---- phase A: every HBM load of the graph is issued before anything waits: unary rows first (they are needed
   //      first and vmcnt retires in order), then the tables, then the (dense) index check ----
   bool ok = true;
   constexpr int HB = 8;                       // unary rows per wave held in registers; more go round again below
   double ur[HB];
-  int uslot[HB];
+  int uslot[HB], ufac[HB];
   {
     const Words16 hl = sload16(img_hoist + wave * 2 * f.HL);      // this wave's (unary slot, message slot) pairs, -1 padded
 #pragma unroll
     for (int j = 0; j < HB; ++j) {
       const int u = hl.w[2 * j];
       uslot[j] = hl.w[2 * j + 1];
+      ufac[j] = u;
       ur[j] = 0.0;
       if (u >= 0) {
         const int row = f.dense ? g * d.U + u : as_const(d.unary_tab)[(size_t)g * d.U + u];
@@ -401,8 +549,10 @@ __global__ __launch_bounds__(WG, (NT >= 7 ? 1 : (NT >= 4 ? 2 : 3))) void sweep_x
       const double m = renorm(ur[j], s, uni_l, true);
       bad_key = max(bad_key, mag_key(m));
       work[uslot[j] * 64 + lane] = m;
+      if (GRAD && lane == 0) { gst[ufac[j]] = uslot[j]; gst[d.U + ufac[j]] = s > 0.0 ? 1 : 0; }
     }
   }
+  if (GRAD && t < d.U) { gst[2 * d.U + t] = g_kind; gst[3 * d.U + t] = g_obs; gst[4 * d.U + t] = g_lab; }
   for (int j = HB; j < f.HL; ++j) {
     const const_i32p hp = as_const(img_hoist + (wave * f.HL + j) * 2);
     const int u = hp[0], slot = hp[1];
@@ -415,6 +565,7 @@ __global__ __launch_bounds__(WG, (NT >= 7 ? 1 : (NT >= 4 ? 2 : 3))) void sweep_x
     const double m = renorm(r, s, uni_l, true);
     bad_key = max(bad_key, mag_key(m));
     work[slot * 64 + lane] = m;
+    if (GRAD && lane == 0) { gst[u] = slot; gst[d.U + u] = s > 0.0 ? 1 : 0; }
   }
   if (!__syncthreads_and(ok ? 1 : 0)) {       // an out-of-range table index: skip the graph, raise the status word
     if (t == 0) atomicExch(d.status, 1);
@@ -546,7 +697,7 @@ __global__ __launch_bounds__(WG, (NT >= 7 ? 1 : (NT >= 4 ? 2 : 3))) void sweep_x
   lds_barrier();        // the normalisation below rewrites slots the read-out above has just read
   // ---- the deferred normalisations (only when the messages go back to memory): exactly the slots the program wrote,
   //      wave w takes its WL-entry list, four at a time ----
-  if (f.keep && !PROBED(1)) {
+  if ((f.keep || GRAD) && !PROBED(1)) {      // (GRAD: the same validity check guards the messages the gradient reads)
     for (int j0 = 0; j0 < f.WL; j0 += 4) {
       const const_i32p wl = as_const(img_written + wave * f.WL + j0);
       int slot[4];
@@ -586,6 +737,9 @@ __global__ __launch_bounds__(WG, (NT >= 7 ? 1 : (NT >= 4 ? 2 : 3))) void sweep_x
     }
   }
   PSTAMP          // 8: marginals issued
+  if (GRAD) {                 // (the verdict barrier above has published the final normalisation)
+    gradient_epilogue<NT>(d, gf, tab, reinterpret_cast<const char*>(work), gst, reinterpret_cast<double*>(red), G, g, R_, c_, b3_);
+  }
 #ifdef MLBP_LEAN_PROBE
   PSTAMP_VM       // 9: stores drained
   PFLUSH
@@ -771,19 +925,23 @@ extern "C" int mlbp_debug_lean_probe(int mask, void* buf) {
 #endif
 
 // Does the lean kernel apply to this (program, arguments) pair?  Fills the device-side descriptions when it does.
-static int lean_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, SweepDev* d, LeanDev* f, size_t* lds) {
+// grad: the call's gradient is fused into the launch (the caller has checked that it can be); a gradient request without
+// it is served by the standalone kernel afterwards, from the messages in memory.
+static int lean_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool grad, bool* ok, SweepDev* d, LeanDev* f, size_t* lds) {
   *ok = false;
   const LeanProgram& lp = prog->lean;
   if (!lp.ok || !prog->d_limage || a->X > 64 || a->X < 2 || !a->normalize_messages || prog->P < 1 || prog->P > 8) return MLBP_OK;
   const bool padx = a->X < 64;
   if (padx && prog->P > 4) return MLBP_OK;
-  if (a->gradient) return MLBP_OK;                // the fused gradient epilogue lives in the older kernels
+  if (a->gradient && padx) return MLBP_OK;
+  if (grad && (prog->P > 3 || prog->U > WG)) return fail(MLBP_EINVAL, "lean kernel: fused gradient needs P <= 3 and U <= %d", WG);
   if (a->flags & MLBP_SWEEP_APPROX_INFERENCE) return MLBP_OK;
   if (a->marginals && !prog->d_lreadout && !padx) return MLBP_OK;
   const int n_ext = 2 + lp.n_cprod;               // uniform, the constant products, ones
   *lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 256) * sizeof(double) + 16 * (size_t)(lp.n_bundles + 1) * sizeof(int32_t);
   if (prog->P == 7 && !padx) *lds += 32 * 1024;   // the seventh table lives in LDS
-  if (*lds > 80 * 1024) return MLBP_OK;           // large graphs: the older kernels' rules apply
+  if (grad) *lds += 5 * (size_t)prog->U * sizeof(int32_t);
+  if (*lds > 80 * 1024) return MLBP_OK;           // large graphs: the generic kernel's rules apply
   const bool dense = (a->flags & MLBP_SWEEP_DENSE_TABLES) != 0;
   if (dense && ((int64_t)a->B * prog->P > a->n_pair_tables || (int64_t)a->B * prog->U > a->n_unary_tables))
     return fail(MLBP_EINVAL, "mlbp_sweep_f64: MLBP_SWEEP_DENSE_TABLES needs B*P pair tables and B*U unary columns");
@@ -802,44 +960,55 @@ static int lean_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* o
   f->image = prog->d_limage; f->readout = (a->marginals && !padx) ? prog->d_lreadout : nullptr; f->bail = mp->d_bail;
   f->n_bundles = lp.n_bundles; f->HL = lp.HL; f->n_cprod = lp.n_cprod; f->WL = lp.WL;
   f->n_ext = n_ext; f->init = a->init_messages; f->dense = dense ? 1 : 0;
-  // the messages go back to memory unless the caller waives them and takes the fused read-out instead
-  f->keep = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && a->marginals && !padx) ? 0 : 1;     // (small X: the read-out is a separate launch over the messages)
+  // the messages go back to memory unless the caller waives them and takes the fused read-outs instead (a gradient that
+  // is NOT fused reads them from memory)
+  const bool waived = (a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && !padx && (a->marginals || grad) && (!a->gradient || grad);
+  f->keep = waived ? 0 : 1;                       // (small X: the read-out is a separate launch over the messages)
   *ok = true;
   return MLBP_OK;
 }
 
+typedef void (*lean_fn)(SweepDev, LeanDev, const int32_t*, int, GradFusedDev);
+
 template <bool MULTI>
-static void (*pick_lean(int P, bool padx))(SweepDev, LeanDev, const int32_t*, int) {
+static lean_fn pick_lean(int P, bool padx) {
   if (padx) {
     switch (P) {
-      case 1: return sweep_x64_lean_kernel<1, true, MULTI, 0>;
-      case 2: return sweep_x64_lean_kernel<2, true, MULTI, 0>;
-      case 3: return sweep_x64_lean_kernel<3, true, MULTI, 0>;
-      default: return sweep_x64_lean_kernel<4, true, MULTI, 0>;
+      case 1: return sweep_x64_lean_kernel<1, true, MULTI, 0, false>;
+      case 2: return sweep_x64_lean_kernel<2, true, MULTI, 0, false>;
+      case 3: return sweep_x64_lean_kernel<3, true, MULTI, 0, false>;
+      default: return sweep_x64_lean_kernel<4, true, MULTI, 0, false>;
     }
   }
   switch (P) {
-    case 1: return sweep_x64_lean_kernel<1, false, MULTI, 0>;
-    case 2: return sweep_x64_lean_kernel<2, false, MULTI, 0>;
-    case 3: return sweep_x64_lean_kernel<3, false, MULTI, 0>;
-    case 4: return sweep_x64_lean_kernel<4, false, MULTI, 0>;
-    case 5: case 6: return sweep_x64_lean_kernel<6, false, MULTI, 0>;
-    case 7: return sweep_x64_lean_kernel<6, false, MULTI, 1>;     // six tables in registers, the seventh in LDS: two workgroups per CU
-    default: return sweep_x64_lean_kernel<8, false, MULTI, 0>;    // part of the tables lives in the accumulator registers
+    case 1: return sweep_x64_lean_kernel<1, false, MULTI, 0, false>;
+    case 2: return sweep_x64_lean_kernel<2, false, MULTI, 0, false>;
+    case 3: return sweep_x64_lean_kernel<3, false, MULTI, 0, false>;
+    case 4: return sweep_x64_lean_kernel<4, false, MULTI, 0, false>;
+    case 5: case 6: return sweep_x64_lean_kernel<6, false, MULTI, 0, false>;
+    case 7: return sweep_x64_lean_kernel<6, false, MULTI, 1, false>;     // six tables in registers, the seventh in LDS: two workgroups per CU
+    default: return sweep_x64_lean_kernel<8, false, MULTI, 0, false>;    // part of the tables lives in the accumulator registers
+  }
+}
+static lean_fn pick_lean_grad(int P) {
+  switch (P) {
+    case 1: return sweep_x64_lean_kernel<1, false, false, 0, true>;
+    case 2: return sweep_x64_lean_kernel<2, false, false, 0, true>;
+    default: return sweep_x64_lean_kernel<3, false, false, 0, true>;
   }
 }
 
-int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched) {
+int launch_lean_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, const GradFusedDev* gf, void* stream, bool* launched) {
   *launched = false;
   SweepDev d;
   LeanDev f;
   size_t lds = 0;
   bool ok = false;
-  if (int e = lean_plan(prog, a, &ok, &d, &f, &lds)) return e;
+  if (int e = lean_plan(prog, a, gf != nullptr, &ok, &d, &f, &lds)) return e;
   if (!ok) return MLBP_OK;
-  void (*k)(SweepDev, LeanDev, const int32_t*, int) = pick_lean<false>(prog->P, a->X < 64);
+  lean_fn k = gf ? pick_lean_grad(prog->P) : pick_lean<false>(prog->P, a->X < 64);
   if (int e = ensure_lds((const void*)k, lds)) return e;
-  hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, (hipStream_t)stream, d, f, nullptr, 0);
+  hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, (hipStream_t)stream, d, f, nullptr, 0, gf ? *gf : GradFusedDev{});
   HIP_TRY(hipGetLastError());
   *launched = true;
   return MLBP_OK;
@@ -866,7 +1035,7 @@ int launch_lean_groups(const mlbp_program* const* progs, const mlbp_sweep_args* 
     LeanDev f;
     size_t lds = 0;
     bool ok = false;
-    if (int e = lean_plan(progs[k], &args[k], &ok, &d, &f, &lds)) return e;
+    if (int e = lean_plan(progs[k], &args[k], false, &ok, &d, &f, &lds)) return e;
     if (!ok) return MLBP_OK;
     if (k == 0) { d0 = d; f0 = f; }
     else if (f.init != f0.init || f.keep != f0.keep || (f.readout != nullptr) != (f0.readout != nullptr)) return MLBP_OK;
@@ -894,9 +1063,9 @@ int launch_lean_groups(const mlbp_program* const* progs, const mlbp_sweep_args* 
     owner->h_gtable = table;
     HIP_TRY(hipMemcpyAsync(owner->d_gtable, owner->h_gtable.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
   }
-  void (*k)(SweepDev, LeanDev, const int32_t*, int) = pick_lean<true>(p_max, false);
+  lean_fn k = pick_lean<true>(p_max, false);
   if (int e = ensure_lds((const void*)k, lds_max)) return e;
-  hipLaunchKernelGGL(k, dim3(total), dim3(WG), lds_max, (hipStream_t)stream, d0, f0, owner->d_gtable, n_groups);
+  hipLaunchKernelGGL(k, dim3(total), dim3(WG), lds_max, (hipStream_t)stream, d0, f0, owner->d_gtable, n_groups, GradFusedDev{});
   HIP_TRY(hipGetLastError());
   *launched = true;
   return MLBP_OK;

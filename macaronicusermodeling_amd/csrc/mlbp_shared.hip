@@ -914,7 +914,6 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   const size_t fixed = (size_t)sp.n_live * 64 * sizeof(double) + words * sizeof(int32_t);
   int n_res = sp.n_live;
   while (n_res > 0 && fixed + (size_t)n_res * TILE * sizeof(double) > 80 * 1024) --n_res;
-  if (const char* e = getenv("MLBP_SHARED_NRES")) { const int v = atoi(e); if (v >= 1 && v <= sp.n_live) n_res = v; }   // experiments
   const size_t lds = fixed + (size_t)n_res * TILE * sizeof(double);
   if (n_res < 1 || sp.n_live - n_res > 16 || lds > 160 * 1024)   // too much would spill: the per-graph kernels do better
     return fail(MLBP_OK, "shared-table kernel not used: %d live message tiles, %d fit LDS", sp.n_live, n_res);

@@ -54,141 +54,10 @@ __device__ __forceinline__ bool tables_in_range(const SweepDev& d, int g) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// X = 64, float64: the BASELINE configs 2-4.
-// thread t: row group rg = t >> 5 (0..7), column pair cp = t & 31 (columns 2cp, 2cp+1).
-// Table element (as double2) k*256 + t  is row 8k+rg, columns 2cp..2cp+1.
-// ------------------------------------------------------------------------------------------------
-template <bool NORM>
-__global__ __launch_bounds__(WG) void sweep_x64_kernel(SweepDev d) {
-  extern __shared__ double lds[];
-  double* msg = lds;                       // [n_msgs][64]
-  double* red = lds + (size_t)d.n_msgs * 64;  // [8][64] partial sums / raw results
-
-  const int g = blockIdx.x;
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int rg = t >> 5, cp = t & 31;
-  if (!tables_in_range(d, g)) return;
-
-  double* gm = d.msgs + (size_t)g * d.n_msgs * 64;
-  {
-    const double2* src = reinterpret_cast<const double2*>(gm);
-    double2* dst = reinterpret_cast<double2*>(msg);
-    for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = src[i];
-  }
-  const int32_t* ptab = d.pair_tab + (size_t)g * d.P;
-  const int32_t* utab = d.unary_tab + (size_t)g * d.U;
-
-  double2 nxt[8];
-  int pair_k = 0;  // index into pairseq of the next pair op to execute
-  {
-    int s0 = d.pairseq[0];
-    if (s0 >= 0) {
-      const double2* T = reinterpret_cast<const double2*>(d.pair_tables + (size_t)ptab[s0] * 4096);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) nxt[k] = T[k * WG + t];
-    }
-  }
-  __syncthreads();
-
-  const double uniform = 1.0 / 64.0;
-  for (int s = 0; s < d.n_sweeps; ++s) {
-    const int op0 = d.sweeps[2 * s], nop = d.sweeps[2 * s + 1];
-    for (int o = op0; o < op0 + nop; ++o) {
-      const int kind = d.ops[4 * o], a = d.ops[4 * o + 1], b = d.ops[4 * o + 2], c = d.ops[4 * o + 3];
-      if (kind == MLBP_OP_PAIR_TM || kind == MLBP_OP_PAIR_MT) {
-        double2 cur[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
-        ++pair_k;
-        {
-          int sn = d.pairseq[pair_k];
-          if (sn >= 0) {
-            const double2* T = reinterpret_cast<const double2*>(d.pair_tables + (size_t)ptab[sn] * 4096);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) nxt[k] = T[k * WG + t];
-          }
-        }
-        const double* m = msg + b * 64;
-        if (kind == MLBP_OP_PAIR_MT) {
-          // out_j = sum_i m_i T[i][j]: accumulate my 8 rows, then add the 8 row groups through LDS
-          double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            double mi = m[8 * k + rg];
-            a0 += mi * cur[k].x;
-            a1 += mi * cur[k].y;
-          }
-          reinterpret_cast<double2*>(red + rg * 64)[cp] = make_double2(a0, a1);
-        } else {
-          // out_i = sum_j T[i][j] m_j: 8 row partials per lane, transposing butterfly over the
-          // 32 lanes that share a row group (halves the live values at each of the first 3 steps)
-          const double2 mj = reinterpret_cast<const double2*>(m)[cp];
-          double v[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = cur[k].x * mj.x + cur[k].y * mj.y;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            bool up = lane & 16;
-            double send = up ? v[i] : v[i + 4], keep = up ? v[i + 4] : v[i];
-            v[i] = keep + __shfl_xor(send, 16, 64);
-          }
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            bool up = lane & 8;
-            double send = up ? v[i] : v[i + 2], keep = up ? v[i + 2] : v[i];
-            v[i] = keep + __shfl_xor(send, 8, 64);
-          }
-          {
-            bool up = lane & 4;
-            double send = up ? v[0] : v[1], keep = up ? v[1] : v[0];
-            v[0] = keep + __shfl_xor(send, 4, 64);
-          }
-          v[0] += __shfl_xor(v[0], 2, 64);
-          v[0] += __shfl_xor(v[0], 1, 64);
-          if ((lane & 3) == 0) {
-            int k = ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-            red[8 * k + rg] = v[0];
-          }
-        }
-        __syncthreads();
-        if (t < 64) {
-          double r;
-          if (kind == MLBP_OP_PAIR_MT) {
-            r = 0.0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) r += red[q * 64 + t];
-          } else {
-            r = red[t];
-          }
-          msg[c * 64 + t] = renorm(r, wave_sum(r), uniform, NORM);
-        }
-        __syncthreads();
-      } else if (kind == MLBP_OP_VAR) {
-        if (t < 64) {
-          double acc = uniform;
-          for (int q = 0; q < b; ++q) acc = nan_to_num(msg[d.srcs[a + q] * 64 + t] * acc);
-          msg[c * 64 + t] = renorm(acc, wave_sum(acc), uniform, NORM);
-        }
-        __syncthreads();
-      } else {  // MLBP_OP_UNARY
-        if (t < 64) {
-          double r = d.unary_tables[(size_t)utab[a] * 64 + t];
-          msg[c * 64 + t] = renorm(r, wave_sum(r), uniform, NORM);
-        }
-        __syncthreads();
-      }
-    }
-  }
-  {
-    const double2* src = reinterpret_cast<const double2*>(msg);
-    double2* dst = reinterpret_cast<double2*>(gm);
-    for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = src[i];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// X = 64, float64, second generation ("fused" program form, see build_fused_program):
+// X = 64, float64, the EXACT kernel ("fused" program form, see build_fused_program): thread t holds rows 8k + (t >> 5),
+// columns 2 (t & 31) .. +1 of a resident table (as double2 element k * 256 + t).  It normalises after every update like the
+// reference and is the fix-up pass behind the fast kernels (mlbp_lean.hip, mlbp_shared.hip), the kernel for
+// normalize_messages = False and for programs whose unary updates cannot be hoisted:
 //   * unary factor->variable messages depend on nothing but their table, so when the program
 //     allows it (every such slot is written before it is first read) they are all computed once,
 //     in parallel over the 4 waves, before the first sweep, and the UNARY ops are dropped -- the
@@ -318,15 +187,6 @@ __device__ __forceinline__ void pair_partials(const double2 (&T)[8], const doubl
 // factor's normalised message IS its belief vector au.normalize(table) whenever the table's total is
 // positive (LBP.py:540 vs 494-498).  Only the shared feature tensors come from L2.  Saves the
 // standalone gradient kernel's second pass over every table in HBM.
-struct GradFusedDev {
-  const int32_t* pair_c_slot; const int32_t* pair_r_slot; const int32_t* pair_phi; const int32_t* pair_label;
-  const int32_t* unary_kind; const int32_t* unary_obs; const int32_t* unary_label;
-  const double* phi_en_en; const double* phi_en_en_w1;
-  const double* phi_en_en_t; const double* phi_en_en_w1_t; const double* phi_en_de_t;
-  double* grad_en_en; double* grad_en_de;
-  int32_t Vde, enabled;
-};
-
 // umsg[u] = message slot of unary slot u's factor->variable message, upos[u] = 1 when its table total
 // was positive (both filled in the prologue from the hoist list).  scratch: >= 4*24 doubles of LDS.
 template <int NT>
@@ -719,25 +579,6 @@ __device__ __forceinline__ void sweep_x64_fused_body(const SweepDev& d, const Fu
   if (GRAD && NT > 0) gradient_epilogue_x64<(NT > 0 ? NT : 1)>(d, gf, tab, msg, umsg, upos, red, g);
 }
 
-// ------------------------------------------------------------------------------------------------
-// X = 64, float64, "scale-free" form of the fused kernel (normalize_messages only).
-//
-// Every normalisation of the reference divides a vector by a positive scalar, and every later use
-// of that vector is linear in it, so the scalars cancel in every NORMALISED quantity.  This kernel
-// therefore carries each message multiplied by an exact power of two (largest element in [1,2))
-// instead of normalised -- v_ldexp, no rounding -- and performs the true normalisations (sum and
-// divide, LBP.py:649-657) once, after the last sweep, for exactly the slots the program wrote.
-// What that removes from the critical path of every update: both wave reductions + divisions and
-// one of the two workgroup barriers.  All four waves run the same instruction stream (each keeps
-// its own copy of the 64-state vectors; only the table contraction is split), so the one barrier
-// per pairwise update is the exchange of partial sums.
-//
-// The rescaling changes results only at rounding level (<= 1 ulp per update).  Inputs where the
-// reference's rules act on absolute values are NOT handled here: a negative or non-finite entry, a
-// subnormal/zero maximum (zero-sum -> uniform rule, LBP.py:655-657), or nan_to_num acting inside a
-// constant product make the workgroup leave its graph untouched and raise bail[g]; the launcher
-// then runs the exact kernel (sweep_x64_fused_kernel) on the flagged graphs only.
-// ------------------------------------------------------------------------------------------------
 // One workgroup per graph -- or, as the fix-up pass behind a fast kernel (f.only), one workgroup per 64 graphs that
 // walks their flags and redoes the (normally zero) flagged ones: 128 workgroups instead of 8192 that exit at once.
 template <bool NORM, int NT, bool GRAD>
@@ -756,277 +597,6 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
     sweep_x64_fused_body<NORM, NT, GRAD>(d, f, gf, base + i);
     if (todo) __syncthreads();
   }
-}
-
-struct ScaleFreeDev {
-  const int32_t* image;      // as FusedDev::image, followed by the written-slot list
-  const int32_t* fsweeps;
-  uint8_t* bail;             // [B] set to 1 when the graph must be redone by the exact kernel
-  int32_t n_fops, n_psrcs, n_hoist, n_cprod, n_cpw, n_ext, n_written, init, n_readout;
-};
-
-// ---- pieces of the scale-free main loop ----
-// Input vector of a pairwise update (lane i = state i).  Returns false for a lone variable update
-// (stored, nothing else to do).
-__device__ __forceinline__ bool sf_input(int kind, const int4& h0, const int4& h1, double* work, const int32_t* psrcs,
-                                         int lane, bool ablate, double& m, int& pslot, int& dst, bool& mt) {
-  const int c = __builtin_amdgcn_readfirstlane(h0.w);
-  if (kind == FOP_VAR || kind == FOP_VAR_PAIR_TM || kind == FOP_VAR_PAIR_MT) {
-    const int a = __builtin_amdgcn_readfirstlane(h0.y), n = __builtin_amdgcn_readfirstlane(h0.z);
-    const int4 s4 = *reinterpret_cast<const int4*>(psrcs + a);
-    m = ablate ? 1.0 / 64.0 : work[s4.x * 64 + lane];
-    if (n > 1 && !ablate) m *= work[s4.y * 64 + lane];
-    if (n > 2) m *= work[s4.z * 64 + lane];
-    if (n > 3) m *= work[s4.w * 64 + lane];
-    for (int q = 4; q < n; ++q) m *= work[psrcs[a + q] * 64 + lane];
-    work[c * 64 + lane] = m;                      // every wave stores its (identical) copy
-    if (kind == FOP_VAR) return false;
-    pslot = __builtin_amdgcn_readfirstlane(h1.x);
-    dst = __builtin_amdgcn_readfirstlane(h1.y);
-  } else {
-    pslot = __builtin_amdgcn_readfirstlane(h0.y);
-    m = work[__builtin_amdgcn_readfirstlane(h0.z) * 64 + lane];
-    dst = c;
-  }
-  mt = (kind == FOP_PAIR_MT || kind == FOP_VAR_PAIR_MT);
-  return true;
-}
-
-template <int NT>
-__device__ __forceinline__ void sf_partials(const double2 (&tab)[NT][8], int pslot, bool mt, const double* m, double* red,
-                                            int rg, int cp, int lane) {
-#pragma unroll
-  for (int p = 0; p < NT; ++p) {
-    if (p == pslot) {
-      if (mt) pair_partials<true>(tab[p], m, red, rg, cp, lane);
-      else pair_partials<false>(tab[p], m, red, rg, cp, lane);
-    }
-  }
-}
-
-__device__ __forceinline__ double sf_gather(bool mt, const double* red, int lane) {
-  if (mt) {
-    double r = 0.0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) r += red[q * 64 + lane];
-    return r;
-  }
-  return red[lane] + red[64 + lane];
-}
-
-template <int NT, bool GRAD>
-__global__ __launch_bounds__(WG, (NT >= 3 ? 3 : 4)) void sweep_x64_sf_kernel(SweepDev d, ScaleFreeDev f, GradFusedDev gf) {
-  extern __shared__ double lds[];
-  double* work = lds;                                       // [n_msgs + n_ext][64] scaled messages
-  double* gin = lds + (size_t)(d.n_msgs + f.n_ext) * 64;    // [4 waves][2][64] contraction inputs
-  double* red0 = gin + 4 * 128;                             // 2 parities x 2 bundle slots x [8][64]
-  int32_t* prog = reinterpret_cast<int32_t*>(red0 + 4 * 512);
-  const int32_t* psrcs = prog + f.n_fops * 8;
-  const int32_t* phoist = psrcs + f.n_psrcs;
-  const int32_t* pcp = phoist + 2 * f.n_hoist;
-  const int32_t* pwritten = pcp + f.n_cpw;
-  int32_t* tabidx = const_cast<int32_t*>(pwritten) + f.n_written;
-  int32_t* lflag = tabidx + d.P + d.U;                    // [1] set when the final pass finds a bad vector
-  int32_t* lread = lflag + 1;                             // read-out tables: in_off [n_vars+1], in_slots
-  int32_t* umsg = lread + f.n_readout;                    // [U] message slot of each unary factor's message
-  int32_t* upos = umsg + d.U;                             // [U] 1 when that factor's table total was positive
-
-  ABLATE_DECL
-  STAMP_DECL
-  STAMP_START
-  const int g = blockIdx.x;
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int rg = t >> 5, cp = t & 31;
-  double* gm = d.msgs + (size_t)g * d.n_msgs * 64;
-  double* gin_w = gin + wave * 128;
-  const double uniform = 1.0 / 64.0;
-  const const_i32p c_fsweeps = as_const(f.fsweeps);
-
-  if (t == 0) f.bail[g] = 0;      // this workgroup owns the flag: cleared here (no separate memset), raised below by the same thread
-  // ---- phase A: table indices (range-checked), program image, messages ----
-  bool ok = true;
-  for (int i = t; i < d.P + d.U; i += WG) {
-    const int v = i < d.P ? d.pair_tab[(size_t)g * d.P + i] : d.unary_tab[(size_t)g * d.U + (i - d.P)];
-    ok &= (unsigned)v < (unsigned)(i < d.P ? d.n_pair_tables : d.n_unary_tables);
-    tabidx[i] = v;
-  }
-  unsigned bad_key = 0;
-  {
-    const int n_img = f.n_fops * 8 + f.n_psrcs + 2 * f.n_hoist + f.n_cpw + f.n_written;
-    for (int i = t; i < n_img; i += WG) prog[i] = f.image[i];
-    double2* dst = reinterpret_cast<double2*>(work);
-    if (f.init) {
-      for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = make_double2(uniform, uniform);
-    } else {
-      const double2* src = reinterpret_cast<const double2*>(gm);
-      for (int i = t; i < d.n_msgs * 32; i += WG) {
-        const double2 v = src[i];
-        bad_key = max(bad_key, max(mag_key(v.x), mag_key(v.y)));     // incoming messages must be clean too
-        dst[i] = v;
-      }
-    }
-    if (t < 32) dst[d.n_msgs * 32 + t] = make_double2(uniform, uniform);    // ext slot 0
-    if (t == 0) lflag[0] = 0;
-    if (d.marginals)
-      for (int i = t; i < f.n_readout; i += WG) lread[i] = d.readout[i];
-    if (GRAD)
-      for (int i = t; i < d.U; i += WG) {
-        umsg[i] = -1; upos[i] = 0;
-        upos[d.U + i] = gf.unary_kind[i];
-        upos[2 * d.U + i] = gf.unary_obs[(size_t)g * d.U + i];
-        upos[3 * d.U + i] = gf.unary_label[(size_t)g * d.U + i];
-      }
-  }
-  if (!__syncthreads_and(ok ? 1 : 0)) {
-    if (t == 0) atomicExch(d.status, 1);
-    return;
-  }
-
-  STAMP(0)
-  // ---- phase B: tables + hoisted unary messages, all loads in flight together ----
-  double2 tab[NT][8];
-#pragma unroll
-  for (int p = 0; p < NT; ++p) {
-    if (p < d.P) {
-      const int ti = __builtin_amdgcn_readfirstlane(tabidx[p]);
-      const double2* T = reinterpret_cast<const double2*>(d.pair_tables + (size_t)ti * 4096);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) tab[p][k] = T[k * WG + t];
-    }
-  }
-  constexpr int HB = 8;
-  for (int h0 = wave; h0 < f.n_hoist; h0 += 4 * HB) {
-    double r[HB];
-#pragma unroll
-    for (int j = 0; j < HB; ++j) {
-      const int h = h0 + 4 * j;
-      r[j] = (h < f.n_hoist) ? d.unary_tables[(size_t)tabidx[d.P + phoist[2 * h]] * 64 + lane] : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < HB; ++j) {
-      const int h = h0 + 4 * j;
-      if (h < f.n_hoist) {
-        const double s = ABLATED(9) ? 1.0 : wave_sum(r[j]);
-        const double m = ABLATED(9) ? r[j] : renorm(r[j], s, uniform, true);        // exact, these are final values
-        bad_key = max(bad_key, mag_key(m));
-        work[phoist[2 * h + 1] * 64 + lane] = m;
-        if (GRAD && lane == 0) { umsg[phoist[2 * h]] = phoist[2 * h + 1]; upos[phoist[2 * h]] = s > 0.0 ? 1 : 0; }
-      }
-    }
-  }
-  wg_barrier();
-  {
-    int at = 0;
-    for (int k = 0; k < f.n_cprod; ++k) {
-      const int cnt = pcp[at];
-      if ((k & 3) == wave && !ABLATED(10)) {
-        double acc = uniform;
-        for (int q = 0; q < cnt; ++q) {
-          acc *= work[pcp[at + 1 + q] * 64 + lane];
-          bad_key = max(bad_key, mag_key(acc));               // non-finite intermediate => nan_to_num territory
-        }
-        work[(d.n_msgs + 1 + k) * 64 + lane] = acc;
-      }
-      at += 1 + cnt;
-    }
-  }
-  if (__syncthreads_or(bad_key >= KEY_BAD ? 1 : 0)) {
-    if (t == 0) f.bail[g] = 1;                    // bail codes: 1 prologue, 2 main loop, 3 final pass
-    return;
-  }
-
-  STAMP(1)
-  // ---- main loop: identical in all four waves; one barrier per BUNDLE of pairwise updates ----
-  // The host marks an update "bundled with the next" when the two touch disjoint message slots
-  // (e.g. the two directions of a loop-closing factor, or the two branches below a root): both
-  // run between the same pair of barriers, so their LDS round trips and reductions overlap.
-  int parity = 0;
-  for (int s = 0; s < d.n_sweeps; ++s) {
-    const int op0 = c_fsweeps[2 * s], op1 = op0 + c_fsweeps[2 * s + 1];
-    int o = op0;
-    while (o < op1) {
-      const int4 hA0 = reinterpret_cast<const int4*>(prog)[2 * o];
-      const int4 hA1 = reinterpret_cast<const int4*>(prog)[2 * o + 1];
-      const int kindA = __builtin_amdgcn_readfirstlane(hA0.x);
-      const int two = (kindA >> 8) & 1;           // FOP_BUNDLED; kept as a scalar int on purpose
-      const int4 hB0 = reinterpret_cast<const int4*>(prog)[2 * (o + two)];
-      const int4 hB1 = reinterpret_cast<const int4*>(prog)[2 * (o + two) + 1];
-      int pslotA = 0, dstA = 0, pslotB = 0, dstB = 0;
-      bool mtA = false, mtB = false;
-      double mA = 0.0, mB = 0.0;
-      if (!sf_input(kindA & 0xFF, hA0, hA1, work, psrcs, lane, ABLATED(0), mA, pslotA, dstA, mtA)) {
-        ++o;                                      // a lone variable update: no contraction, no barrier
-        continue;
-      }
-      double* redA = red0 + parity * 1024;
-      double* redB = redA + 512;
-      parity ^= 1;
-      gin_w[lane] = mA;                           // own-wave exchange: each lane needs other states
-      if (two != 0) {
-        sf_input(__builtin_amdgcn_readfirstlane(hB0.x) & 0xFF, hB0, hB1, work, psrcs, lane, ABLATED(0), mB, pslotB, dstB, mtB);
-        gin_w[64 + lane] = mB;
-      }
-      if (!ABLATED(1)) {
-        sf_partials<NT>(tab, pslotA, mtA, gin_w, redA, rg, cp, lane);
-        if (two != 0) sf_partials<NT>(tab, pslotB, mtB, gin_w + 64, redB, rg, cp, lane);
-      }
-      STAMP(2)
-      if (!ABLATED(4)) wg_barrier();
-      STAMP(3)
-      // exact power-of-two rescale (largest element -> [1,2)); anything the rescale cannot represent
-      // faithfully sends the graph to the exact kernel.  Same decision in every wave: r is identical.
-      double rA = 1.5, rB = 1.5;
-      unsigned keyA = 0x3FF00000u, keyB = 0x3FF00000u;
-      if (!ABLATED(2)) rA = sf_gather(mtA, redA, lane);
-      if (!ABLATED(3)) keyA = wave_max_u32(mag_key(rA));
-      if (two != 0) {
-        if (!ABLATED(2)) rB = sf_gather(mtB, redB, lane);
-        if (!ABLATED(3)) keyB = wave_max_u32(mag_key(rB));
-      }
-#ifdef MLBP_DEBUG_PRINT
-      if (g == 0 && t == 0) printf("o=%d kindA=%x two=%d pslotA=%d dstA=%d mtA=%d pslotB=%d dstB=%d keyA=%x keyB=%x rA=%g rB=%g\n", o, kindA, two, pslotA, dstA, (int)mtA, pslotB, dstB, keyA, keyB, rA, rB);
-#endif
-      if (__builtin_expect(keyA >= KEY_BAD || keyA < KEY_MIN || keyB >= KEY_BAD || keyB < KEY_MIN, 0)) {
-        if (t == 0) f.bail[g] = 2;
-        return;
-      }
-      work[dstA * 64 + lane] = __builtin_ldexp(rA, 1023 - (int)(keyA >> 20));
-      if (two != 0) work[dstB * 64 + lane] = __builtin_ldexp(rB, 1023 - (int)(keyB >> 20));
-      o += 1 + two;
-      STAMP(4)
-    }
-  }
-  wg_barrier();
-  // ---- the deferred normalisations: exactly the slots the program wrote ----
-  for (int i = wave; i < f.n_written && !ABLATED(11); i += 4) {
-    const int slot = pwritten[i];
-    const double v = work[slot * 64 + lane];
-    const unsigned key = wave_max_u32(mag_key(v));
-    if (key >= KEY_BAD || key < KEY_MIN) lflag[0] = 1;   // a variable product underflowed or vanished
-    work[slot * 64 + lane] = v / wave_sum(v);
-  }
-  wg_barrier();
-  STAMP(5)
-  if (lflag[0]) {                                 // messages of a bailed graph are not written back
-    if (t == 0) f.bail[g] = 3;
-    return;
-  }
-  {
-    const double2* src = reinterpret_cast<const double2*>(work);
-    double2* dst = reinterpret_cast<double2*>(gm);
-    for (int i = t; i < d.n_msgs * 32 && !ABLATED(13); i += WG) dst[i] = src[i];
-  }
-  if (d.marginals && !ABLATED(12)) {
-    for (int v = wave; v < d.n_vars; v += 4) {
-      double acc = uniform;
-      for (int q = lread[v]; q < lread[v + 1]; ++q) acc = mul_nan_to_num(work[lread[d.n_vars + 1 + q] * 64 + lane], acc);
-      d.marginals[((size_t)g * d.n_vars + v) * 64 + lane] = renorm(acc, wave_sum(acc), uniform, true);
-    }
-  }
-  STAMP(6)
-  STAMP_FLUSH
-  if (GRAD) gradient_epilogue_x64<NT>(d, gf, tab, work, umsg, upos, red0, g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1393,32 +963,31 @@ void build_fused_program(const int32_t* ops_in, const int32_t* srcs, const int32
   int n_total = 0;
   for (int s = 0; s < n_sweeps; ++s) n_total = std::max(n_total, sweeps[2 * s] + sweeps[2 * s + 1]);
   std::vector<int32_t> ops_v(ops_in, ops_in + 4 * (size_t)n_total);
-  if (!getenv("MLBP_NO_SINK"))
-    for (int s = 0; s < n_sweeps; ++s) {
-      const int first = sweeps[2 * s], cnt = sweeps[2 * s + 1];
-      int32_t* q = ops_v.data() + 4 * (size_t)first;
-      auto is_pair = [&](int i) { return q[4 * i] == MLBP_OP_PAIR_TM || q[4 * i] == MLBP_OP_PAIR_MT; };
-      for (int i = 0; i < cnt; ++i) {
-        if (q[4 * i] != MLBP_OP_VAR) continue;
-        const int a = q[4 * i + 1], b = q[4 * i + 2], c = q[4 * i + 3];
-        int j = i + 1;
-        bool legal = true;
-        for (; j < cnt && legal; ++j) {
-          if (is_pair(j) && q[4 * j + 2] == c) break;                                  // the consumer
-          const int w = q[4 * j + 3];
-          if (w == c) legal = false;
-          for (int k = a; k < a + b && legal; ++k) if (srcs[k] == w) legal = false;
-          if (q[4 * j] == MLBP_OP_VAR)
-            for (int k = q[4 * j + 1]; k < q[4 * j + 1] + q[4 * j + 2] && legal; ++k) if (srcs[k] == c) legal = false;
-        }
-        if (!legal || j >= cnt || j == i + 1) continue;
-        const int32_t v[4] = {q[4 * i], a, b, c};
-        for (int k = i; k < j - 1; ++k)
-          for (int e = 0; e < 4; ++e) q[4 * k + e] = q[4 * (k + 1) + e];
-        for (int e = 0; e < 4; ++e) q[4 * (j - 1) + e] = v[e];
-        --i;                                                                           // the op that slid into place i
+  for (int s = 0; s < n_sweeps; ++s) {
+    const int first = sweeps[2 * s], cnt = sweeps[2 * s + 1];
+    int32_t* q = ops_v.data() + 4 * (size_t)first;
+    auto is_pair = [&](int i) { return q[4 * i] == MLBP_OP_PAIR_TM || q[4 * i] == MLBP_OP_PAIR_MT; };
+    for (int i = 0; i < cnt; ++i) {
+      if (q[4 * i] != MLBP_OP_VAR) continue;
+      const int a = q[4 * i + 1], b = q[4 * i + 2], c = q[4 * i + 3];
+      int j = i + 1;
+      bool legal = true;
+      for (; j < cnt && legal; ++j) {
+        if (is_pair(j) && q[4 * j + 2] == c) break;                                  // the consumer
+        const int w = q[4 * j + 3];
+        if (w == c) legal = false;
+        for (int k = a; k < a + b && legal; ++k) if (srcs[k] == w) legal = false;
+        if (q[4 * j] == MLBP_OP_VAR)
+          for (int k = q[4 * j + 1]; k < q[4 * j + 1] + q[4 * j + 2] && legal; ++k) if (srcs[k] == c) legal = false;
       }
+      if (!legal || j >= cnt || j == i + 1) continue;
+      const int32_t v[4] = {q[4 * i], a, b, c};
+      for (int k = i; k < j - 1; ++k)
+        for (int e = 0; e < 4; ++e) q[4 * k + e] = q[4 * (k + 1) + e];
+      for (int e = 0; e < 4; ++e) q[4 * (j - 1) + e] = v[e];
+      --i;                                                                           // the op that slid into place i
     }
+  }
   const int32_t* ops = ops_v.data();
   // 1. may the unary messages be hoisted?  Every read of a unary factor's message slot must come
   //    after a UNARY op has written that slot (then the value read is always the same constant).
@@ -1509,7 +1078,7 @@ void build_fused_program(const int32_t* ops_in, const int32_t* srcs, const int32
   // 3b. drop lone variable->factor updates whose result is overwritten before anything reads it (the last two of a
   //     sweep when the next sweep's root differs: the new schedule recomputes those messages first).  Backward
   //     liveness over the whole call; every slot is live at the end (the messages are an output).
-  if (!getenv("MLBP_NO_SINK")) {
+  {
     const int n = (int)out.fops.size() / 8;
     std::vector<char> live(n_msgs + 1 + (int)cprods.size(), 1), dead(n, 0);
     for (int i = n - 1; i >= 0; --i) {
@@ -1553,8 +1122,7 @@ void build_fused_program(const int32_t* ops_in, const int32_t* srcs, const int32
         return false;
       };
       std::vector<int> ra, wa, rb, wb;
-      const bool no_bundle = getenv("MLBP_NO_BUNDLE") != nullptr;     // A/B switch for measurements
-      for (int i = f0; i + 1 < f1 && !no_bundle; ++i) {
+      for (int i = f0; i + 1 < f1; ++i) {
         if (!is_pair(i) || !is_pair(i + 1)) continue;
         sets(i, ra, wa); sets(i + 1, rb, wb);
         if (meets(wa, rb) || meets(wb, ra) || meets(wa, wb)) continue;
@@ -1584,19 +1152,12 @@ void build_fused_program(const int32_t* ops_in, const int32_t* srcs, const int32
   }
 }
 
-// MLBP_SWEEP_VARIANT (experiments / A-B profiling only): 0 = first-generation kernel, 1 = fused
-// kernel with the default table-residency rule (default), 10+N = fused kernel forcing N resident
-// tables (N = 0 streams).
-int g_sweep_variant = -1;
+// mlbp_set_sweep_variant: 1 = the fast kernels with the exact kernel as fix-up (default), 3 = the exact / per-graph
+// kernels on every graph (the tests' reference on the same inputs).
+int g_sweep_variant = 1;
 thread_local int g_last_kernel = -1;       // mlbp_last_sweep_kernel()
 thread_local bool g_lean_predone = false;  // set by mlbp_sweep_groups_f64 around the per-group fix-up calls
-int sweep_variant() {
-  if (g_sweep_variant < 0) {
-    const char* e = getenv("MLBP_SWEEP_VARIANT");
-    g_sweep_variant = e ? atoi(e) : 1;
-  }
-  return g_sweep_variant;
-}
+int sweep_variant() { return g_sweep_variant; }
 
 // hipFuncSetAttribute is a slow host call (~0.1 ms); remember the largest dynamic-LDS size already
 // granted per kernel and only call again when a launch needs more.
@@ -1905,36 +1466,27 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   const bool norm = a->normalize_messages != 0;
   const size_t LDS_MAX = 160 * 1024;
   const int variant = sweep_variant();
-  if (a->X == 64 && variant != 0) {
+  if (a->X == 64) {
     const int n_ext = 1 + prog->n_cprod;
     const size_t img_words = (size_t)prog->n_fops * 8 + prog->n_psrcs + 2 * prog->n_hoist + prog->n_cpw + prog->n_written;
-    // residency rule: tables stay in registers when the graph has at most 3 (4 for the scale-free
-    // kernel, whose smaller working set still fits 3 workgroups per CU) of them
-    int nt = (prog->P <= 3) ? prog->P : 0;
-    bool want_sf = norm && prog->sf_ok && prog->P >= 1 && prog->P <= 4 && variant != 3;     // variant 2: as 1 without the lean kernel
-    if (variant >= 10 && variant < 20) { nt = (prog->P <= variant - 10) ? variant - 10 : 0; want_sf = false; }
-    if (variant >= 20 && variant < 30) { want_sf = want_sf && prog->P <= variant - 20; nt = variant - 20; }
-    else if (want_sf) nt = prog->P;
-    if (prog->P == 0 || (!want_sf && nt < prog->P)) nt = 0;
-    if (nt > 4) nt = 0;
-    const size_t lds_sf = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 128 + 4 * 512) * sizeof(double) +
-                          (img_words + prog->P + 6 * prog->U + 8 + prog->n_readout) * sizeof(int32_t);
+    // the exact kernel keeps the tables in registers when the graph has at most 3 of them, else it streams them
+    const int nt = (prog->P >= 1 && prog->P <= 3) ? prog->P : 0;
     const size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 64 + 512) * sizeof(double) +
                        (img_words + prog->P + 6 * prog->U + 8) * sizeof(int32_t);
-    if (lds_sf > LDS_MAX) want_sf = false;
     if (lds <= LDS_MAX) {
       mlbp_program* mp = const_cast<mlbp_program*>(prog);
+      const bool fast = variant == 1;               // variant 3: the exact kernel on every graph
       if (norm) d.marginals = a->marginals;         // read-out fused into the kernels' epilogue
-      // gradient fused into the epilogue when the tables end up in registers in BOTH kernels
+      // the gradient runs as the sweep kernels' epilogue when the tables are on chip in BOTH the fast and the exact kernel
       GradFusedDev gf = {};
       const mlbp_gradient_args* ga = a->gradient;
       bool grad_fused = false;
       if (ga) {
         if (ga->B != a->B || ga->X != a->X || ga->P != prog->P || ga->U != prog->U || ga->n_msgs != prog->n_msgs || ga->msgs != a->msgs)
           return fail(MLBP_EINVAL, "mlbp_sweep_f64: gradient arguments do not describe the same batch");
-        grad_fused = norm && ga->F_ee == 3 && ga->F_ed == 6 && prog->P >= 1 && prog->P <= 3 && nt == prog->P &&
-                     prog->n_hoist == prog->U && ga->phi_en_en_t && ga->phi_en_en_w1_t && ga->phi_en_de_t &&
-                     (variant == 1 || variant == 2 || variant == 3 || variant >= 20 || variant == 10 + prog->P);
+        grad_fused = norm && ga->F_ee == 3 && ga->F_ed == 6 && nt >= 1 && prog->n_hoist == prog->U && prog->U <= WG &&
+                     ga->phi_en_en_t && ga->phi_en_en_w1_t && ga->phi_en_de_t && !(ga->flags & MLBP_GRADIENT_APPROX_BELIEFS) &&
+                     !g_lean_predone;
         if (grad_fused) {
           gf.pair_c_slot = ga->pair_c_slot; gf.pair_r_slot = ga->pair_r_slot; gf.pair_phi = ga->pair_phi; gf.pair_label = ga->pair_label;
           gf.unary_kind = ga->unary_kind; gf.unary_obs = ga->unary_obs; gf.unary_label = ga->unary_label;
@@ -1944,55 +1496,31 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
         }
       }
       bool shared_done = false;                // shared-table batches: 16 graphs per workgroup on the matrix cores
-      if ((variant == 1 || variant == 2 || variant == 30) && !g_lean_predone)
+      if (fast && !g_lean_predone)
         if (int e = mlbp::launch_shared_sweep(prog, a, stream, &shared_done)) return e;
-      if (shared_done) { want_sf = false; grad_fused = false; gf = GradFusedDev{}; }
-      bool lean_done = false;                  // default scale-free path: the lean kernel (mlbp_lean.hip), up to 8 resident tables
+      if (shared_done) { grad_fused = false; gf = GradFusedDev{}; }
+      bool lean_done = false;                  // default path: the lean scale-free kernel (mlbp_lean.hip), up to 8 resident tables
       if (g_lean_predone) lean_done = true;     // mlbp_sweep_groups_f64 ran the lean kernel for this group already
-      else if (norm && prog->sf_ok && prog->P >= 1 && prog->P <= 8 && !shared_done && variant == 1)
-        if (int e = mlbp::launch_lean_sweep(prog, a, stream, &lean_done)) return e;
-      g_last_kernel = shared_done ? MLBP_KERNEL_SHARED_MFMA : (lean_done ? MLBP_KERNEL_LEAN : (want_sf ? MLBP_KERNEL_SCALE_FREE : MLBP_KERNEL_EXACT));
-      if (want_sf && !lean_done) {
-        if (mp->bail_cap < a->B)              // not reserved for this batch size: allocate now (a stream-
-          if (int e = mlbp_program_reserve(mp, a->B)) return e;   // capturing caller reserves up front instead)
-        ScaleFreeDev sf;
-        sf.image = prog->d_fops; sf.fsweeps = prog->d_fsweeps; sf.bail = mp->d_bail;
-        sf.n_fops = prog->n_fops; sf.n_psrcs = prog->n_psrcs; sf.n_hoist = prog->n_hoist;
-        sf.n_cprod = prog->n_cprod; sf.n_cpw = prog->n_cpw; sf.n_ext = n_ext; sf.n_written = prog->n_written;
-        sf.init = a->init_messages;
-        sf.n_readout = prog->n_readout;
-        void (*ks)(SweepDev, ScaleFreeDev, GradFusedDev) = nullptr;
-        switch (nt) {
-          case 1: ks = grad_fused ? sweep_x64_sf_kernel<1, true> : sweep_x64_sf_kernel<1, false>; break;
-          case 2: ks = grad_fused ? sweep_x64_sf_kernel<2, true> : sweep_x64_sf_kernel<2, false>; break;
-          case 3: ks = grad_fused ? sweep_x64_sf_kernel<3, true> : sweep_x64_sf_kernel<3, false>; break;
-          default: ks = sweep_x64_sf_kernel<4, false>; nt = 4; break;
-        }
-        if (int e = ensure_dynamic_lds((const void*)ks, lds_sf)) return e;
-        hipLaunchKernelGGL(ks, dim3(a->B), dim3(WG), lds_sf, st, d, sf, gf);
-        HIP_TRY(hipGetLastError());
-      }
+      else if (fast && norm && prog->sf_ok && prog->P >= 1 && prog->P <= 8 && !shared_done)
+        if (int e = mlbp::launch_lean_sweep(prog, a, grad_fused ? &gf : nullptr, stream, &lean_done)) return e;
+      g_last_kernel = shared_done ? MLBP_KERNEL_SHARED_MFMA : (lean_done ? MLBP_KERNEL_LEAN : MLBP_KERNEL_EXACT);
       FusedDev f;
-      f.only = (want_sf || shared_done || lean_done) ? mp->d_bail : nullptr;     // after a fast pass: flagged graphs only
+      f.only = (shared_done || lean_done) ? mp->d_bail : nullptr;     // after a fast pass: flagged graphs only
       f.image = prog->d_fops; f.fsweeps = prog->d_fsweeps;
       f.n_fops = prog->n_fops; f.n_psrcs = prog->n_psrcs; f.n_hoist = prog->n_hoist;
       f.n_cprod = prog->n_cprod; f.n_cpw = prog->n_cpw; f.n_ext = n_ext;
       f.init = a->init_messages;
       f.n_graphs = a->B;
       d.pairseq = prog->d_fpairseq;
-      if (want_sf && nt > 3) nt = (prog->P <= 3) ? prog->P : 0;   // exact kernel keeps its own rule
       void (*k)(SweepDev, FusedDev, GradFusedDev) = nullptr;
-#define MLBP_PICK(N) k = norm ? sweep_x64_fused_kernel<true, N, false> : sweep_x64_fused_kernel<false, N, false>
-#define MLBP_PICKG(N) k = grad_fused ? sweep_x64_fused_kernel<true, N, true> : (norm ? sweep_x64_fused_kernel<true, N, false> : sweep_x64_fused_kernel<false, N, false>)
+#define MLBP_PICK(N) k = grad_fused ? sweep_x64_fused_kernel<true, N, true> : (norm ? sweep_x64_fused_kernel<true, N, false> : sweep_x64_fused_kernel<false, N, false>)
       switch (nt) {
-        case 1: MLBP_PICKG(1); break;
-        case 2: MLBP_PICKG(2); break;
-        case 3: MLBP_PICKG(3); break;
-        case 4: MLBP_PICK(4); break;
-        default: MLBP_PICK(0); break;
+        case 1: MLBP_PICK(1); break;
+        case 2: MLBP_PICK(2); break;
+        case 3: MLBP_PICK(3); break;
+        default: k = norm ? sweep_x64_fused_kernel<true, 0, false> : sweep_x64_fused_kernel<false, 0, false>; break;
       }
 #undef MLBP_PICK
-#undef MLBP_PICKG
       if (int e = ensure_dynamic_lds((const void*)k, lds)) return e;
       hipLaunchKernelGGL(k, dim3(f.only ? (a->B + FIXUP_GRAPHS_PER_WG - 1) / FIXUP_GRAPHS_PER_WG : a->B), dim3(WG), lds, st, d, f, gf);
       HIP_TRY(hipGetLastError());
@@ -2010,23 +1538,8 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     int e = mlbp_init_messages_f64(a->msgs, (int64_t)a->B * prog->n_msgs, a->X, stream);
     if (e) return e;
   }
-  if (a->X == 64) {
-    size_t lds = ((size_t)prog->n_msgs * 64 + 8 * 64) * sizeof(double);
-    if (lds <= LDS_MAX) {
-      g_last_kernel = MLBP_KERNEL_FIRST_GEN;
-      auto k = norm ? sweep_x64_kernel<true> : sweep_x64_kernel<false>;
-      if (int e = ensure_dynamic_lds((const void*)k, lds)) return e;
-      hipLaunchKernelGGL(k, dim3(a->B), dim3(WG), lds, st, d);
-      HIP_TRY(hipGetLastError());
-      if (a->marginals)
-        if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
-                                       prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;
-      if (a->gradient) return mlbp_gradient_f64(a->gradient, stream);
-      return MLBP_OK;
-    }
-  }
   if ((a->flags & MLBP_SWEEP_SHARED_PAIR_TABLES) && a->pair_tab_host && mlbp::gemm_path_supports(a->X) && !approx &&
-      prog->P >= 1 && prog->P <= 16 && (variant == 1 || variant == 2 || variant == 30)) {
+      prog->P >= 1 && prog->P <= 16 && variant == 1) {
     // shared tables at a large state space: every contraction is one MFMA launch over the whole batch
     if ((a->flags & MLBP_SWEEP_PAIR_TABLES_F32) && a->gradient)
       return fail(MLBP_EUNSUPPORTED, "mlbp_sweep_f64: no gradient with float32 pairwise tables");
@@ -2051,7 +1564,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   d.approx_k = approx ? MLBP_APPROX_K : 0;
   const bool wide_exact = a->X == 128 || a->X == 256 || a->X == 512;
   const bool wide_padded = !wide_exact && !f32_tables && norm && a->X > 64 && a->X <= 1024;
-  if ((wide_exact || wide_padded) && (variant != 0 || f32_tables)) {
+  if (wide_exact || wide_padded) {
     g_last_kernel = MLBP_KERNEL_WIDE;
     void (*kw)(SweepDev) = nullptr;
     int xp = a->X;
@@ -2087,7 +1600,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   // by the generic kernel below in its fix-up mode
   bool lean_small = false;
   if (a->X < 64 && a->X >= 2 && norm && prog->sf_ok && prog->P >= 1 && prog->P <= 4 && variant == 1 && !a->gradient) {
-    if (int e = mlbp::launch_lean_sweep(prog, a, stream, &lean_small)) return e;
+    if (int e = mlbp::launch_lean_sweep(prog, a, nullptr, stream, &lean_small)) return e;
     if (lean_small) {
       d.only = const_cast<mlbp_program*>(prog)->d_bail;
       d.fill_uniform = a->init_messages;
@@ -2201,7 +1714,7 @@ int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_
 }
 
 int mlbp_set_sweep_variant(int32_t variant) {
-  const bool known = variant == 0 || variant == 1 || variant == 2 || variant == 3 || variant == 30 || (variant >= 10 && variant <= 14) || (variant >= 21 && variant <= 24);
+  const bool known = variant == 1 || variant == 3;
   if (!known) return fail(MLBP_EINVAL, "unknown sweep variant %d", variant);
   g_sweep_variant = variant;
   return MLBP_OK;

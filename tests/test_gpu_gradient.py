@@ -63,6 +63,8 @@ def test_batched_gradient_and_beliefs(case):
     fb.initialize(case['roots'][0])
     prog = fb.sweep((case['roots'] * 10)[:n], gradient=(f_ee, f_ed))
     assert prog.status() == 0
+    if spec['X'] == 64 and 1 <= topo.P <= 3:        # the default kernel carries the gradient as its epilogue
+        assert _ffi.lib.mlbp_last_sweep_kernel() == 7 and prog.exact_count(nb) == 0
     np.testing.assert_allclose(f_ee.cpu().numpy(), g_ee, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(f_ed.cpu().numpy(), g_ed, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(g_ee[0], gold['grad_unreg_en_en'].reshape(-1), rtol=1e-8, atol=1e-11)
@@ -580,6 +582,7 @@ def test_gradient_fused_into_a_sweep_that_skips_unchanged_updates(shared):
     """MLBP_SWEEP_SKIP_UNCHANGED with the gradient in the same call: the fused gradient reads the final messages and the
     resident tables, so it must equal the full schedule's (to rounding: these kernels fuse adjacent updates), with
     per-graph tables (the scale-free kernel's epilogue) and with shared pots (separate gradient kernel after the MFMA sweep)."""
+    from macaronicusermodeling_amd import _ffi
     from macaronicusermodeling_amd.train import UserGraphTrainer
     from macaronicusermodeling_amd.topology import GraphTopology
     spec = C.user_spec(10, [1, 4, 7], 64, 48, seed=1)
@@ -595,5 +598,6 @@ def test_gradient_fused_into_a_sweep_that_skips_unchanged_updates(shared):
         tr.batch.pair_tables_shared = shared
         stats = tr.local_statistics().clone()
         assert tr.batch.program(tr.roots[:tr.n_sweeps_run]).skippable_updates() > 0
+        assert _ffi.lib.mlbp_last_sweep_kernel() == (3 if shared else 7)
         outs.append(stats.cpu().numpy())
     np.testing.assert_allclose(outs[1], outs[0], rtol=1e-11, atol=1e-13)

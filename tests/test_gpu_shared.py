@@ -12,7 +12,7 @@ torch = pytest.importorskip('torch')
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-10
-KERNEL_SHARED_MFMA, KERNEL_SCALE_FREE = 3, 1
+KERNEL_SHARED_MFMA = 3
 
 
 def _shared_batch(spec, B, seed=7, mutate=None):

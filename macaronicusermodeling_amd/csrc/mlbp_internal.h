@@ -47,9 +47,11 @@ int launch_lean_groups(const mlbp_program* const* progs, const mlbp_sweep_args* 
 struct SharedProgram {
   bool ok = false;
   const char* why = "";               // when !ok: what rules the program out
-  int n_ops = 0, n_live = 0, n_lists = 0, n_cpw = 0, n_back = 0, n_fill = 0, off_sweeps = 0;
-  std::vector<int32_t> sweeps;         // {first op, count} per sweep of the transformed op list
-  std::vector<int32_t> image;          // ops [n_ops][8], lists [n_lists], cprod lists [n_cpw], write-back pairs [n_back][2], fill slots [n_fill]
+  int n_ops = 0, n_live = 0, n_cpw = 0, n_back = 0, n_fill = 0, n_init = 0, n_bundles = 0;
+  int off_ent = 0, off_back = 0, off_fill = 0, off_init = 0, off_ptile = 0;
+  int max_sources = 1;                 // most tiles any variable update multiplies
+  std::vector<int32_t> sweeps;         // {first op, count} of the transformed op list (one sequence: sweep boundaries mean nothing here)
+  std::vector<int32_t> image;          // bundles [n_bundles + 1][2][16] | cprod entries [n_cpw] | write-back pairs [n_back][2] | fill slots [n_fill] | uniform tiles [n_init]
   std::vector<int32_t> live_of_slot;   // [n_msgs + 1 + n_cprod] LDS tile of a slot (ext slots included) or -1
   std::vector<int32_t> hoisted;        // [n_msgs] unary factor whose constant message the slot holds, or -1
   std::vector<char> written;           // [n_msgs] some update of the program writes the slot
@@ -114,6 +116,8 @@ struct mlbp_program {
   int32_t n_sreadout;
   double* d_tfrag;        // [32][2][4096] table fragments in MFMA operand order (lazily allocated)
   double* d_spill = nullptr;   // message tiles of the shared-table kernel that do not fit LDS (lazily allocated)
+  double* d_ptiles = nullptr;  // constant-product tiles of the shared-table kernel [groups][n_cprod][1024] (lazily allocated)
+  size_t ptiles_cap = 0;       // in doubles
   size_t spill_cap = 0;        // in doubles
   std::vector<int32_t> h_ops, h_sweeps;   // host copies of the validated op list (the op-by-op GEMM path walks them)
 };

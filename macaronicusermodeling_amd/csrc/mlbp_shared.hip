@@ -24,8 +24,11 @@
 // Flops per pairwise update per graph: 2 * 64 * 64 = 8192 (shared-table mode).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "mlbp_internal.h"
@@ -144,30 +147,99 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
       for (int s = 0; s < n_all; ++s)
         if (live[s] && (is_vf[s] ? 1 : 0) == pass) out.live_of_slot[s] = out.n_live++;
   }
-  // ops + source lists
-  std::vector<int32_t> ops((size_t)n_ops * 8, 0), lists;
+  // Members: one record per update, MW words --
+  //   [0] flags: 1 contraction, 2 m^T.T (else T.m), 4 the variable->factor product is kept as tile [3], 8 it is this
+  //       slot's last value and goes straight to memory (message slot [4]), 16 variable update only; bits 8-11 = number of
+  //       source tiles   [1] pair slot   [2] destination tile   [3] product tile or -1   [4] message slot of the product
+  //   [8..15] source tiles (the first one -1: a message nothing has updated yet, i.e. the uniform vector)
+  // (packed into 8 words for the device, pack_member below).
+  // Bundles: two members that touch disjoint tiles share one barrier; the kernel runs them on different halves of its
+  // eight waves when their (table, orientation) pairs live in different halves (it decides: the tables are device data).
+  constexpr int MW = 16;
+  std::vector<int32_t> mem((size_t)n_ops * MW, 0);
   std::vector<int> last_var_write(n_msgs, -1);
+  out.why = "more than 254 live tiles or 65535 message slots";
+  if (out.n_live > 254 || n_msgs > 65535) return;
+  out.why = "a variable update multiplies more than 8 tiles";
   for (int i = 0; i < n_ops; ++i) {
     const int32_t* w = &fops[8 * i];
-    int32_t* so = &ops[8 * (size_t)i];
+    int32_t* m = &mem[(size_t)i * MW];
     const int kind = w[0] & 0xFF;
-    so[0] = kind;
+    for (int q = 0; q < 8; ++q) m[8 + q] = -1;
+    m[2] = m[3] = -1;
     if (kind == FOP_PAIR_TM || kind == FOP_PAIR_MT) {
-      so[1] = w[2] < 0 ? -1 : out.live_of_slot[w[2]]; so[4] = w[1]; so[5] = out.live_of_slot[w[3]];
+      m[0] = 1 | (kind == FOP_PAIR_MT ? 2 : 0) | (1 << 8);
+      m[1] = w[1]; m[2] = out.live_of_slot[w[3]];
+      m[8] = w[2] < 0 ? -1 : out.live_of_slot[w[2]];
     } else {
-      while (lists.size() % 4) lists.push_back(0);
-      so[1] = (int)lists.size(); so[2] = w[2];
-      for (int q = 0; q < w[2]; ++q) lists.push_back(out.live_of_slot[fp.psrcs[w[1] + q]]);
-      so[3] = out.live_of_slot[w[3]]; so[6] = w[3];
-      if (kind != FOP_VAR) { so[4] = w[4]; so[5] = out.live_of_slot[w[5]]; }
-      if (so[3] < 0) last_var_write[w[3]] = i;
+      if (w[2] > 8 || w[2] < 1) return;
+      out.max_sources = std::max(out.max_sources, (int)w[2]);
+      for (int q = 0; q < w[2]; ++q) m[8 + q] = out.live_of_slot[fp.psrcs[w[1] + q]];
+      m[0] = (w[2] << 8) | (kind == FOP_VAR ? 16 : (1 | (kind == FOP_VAR_PAIR_MT ? 2 : 0)));
+      m[3] = out.live_of_slot[w[3]]; m[4] = w[3];
+      if (m[3] >= 0) m[0] |= 4;
+      else last_var_write[w[3]] = i;
+      if (kind != FOP_VAR) { m[1] = w[4]; m[2] = out.live_of_slot[w[5]]; }
     }
   }
   for (int c = 0; c < n_msgs; ++c)
-    if (last_var_write[c] >= 0) ops[8 * (size_t)last_var_write[c]] |= 0x200;     // write this v->f message out here
-  while (lists.size() % 4) lists.push_back(0);
+    if (last_var_write[c] >= 0) mem[(size_t)last_var_write[c] * MW] |= 8;        // write this v->f message out here
+  // tiles read before anything in the program has written them start as the uniform vector (FactorGraph.initialize)
+  std::vector<int32_t> init_tiles;
+  {
+    std::vector<char> have(out.n_live, 0);
+    for (int k = 0; k < fp.n_cprod; ++k) have[out.live_of_slot[n_msgs + 1 + k]] = 1;        // written by the prologue
+    for (int i = 0; i < n_ops; ++i) {
+      const int32_t* m = &mem[(size_t)i * MW];
+      const int n = (m[0] >> 8) & 15;
+      for (int q = 0; q < n; ++q)
+        if (m[8 + q] >= 0 && !have[m[8 + q]]) { have[m[8 + q]] = 1; init_tiles.push_back(m[8 + q]); }
+      if (m[2] >= 0) have[m[2]] = 1;
+      if (m[3] >= 0) have[m[3]] = 1;
+    }
+  }
+  std::vector<int32_t> bundles;
+  const int32_t nop[MW] = {0, 0, -1, -1, 0, 0, 0, 0, -1, -1, -1, -1, -1, -1, -1, -1};
+  // device form, 4 words: [0] flags | nsrc << 8 | pair slot << 16   [1] destination tile | product tile << 8 (0xFF = none) |
+  // message slot of the product << 16   [2] source tiles 0-3, [3] 4-7, one byte each (0xFF = none)
+  auto pack_member = [&](const int32_t* m) {
+    int32_t w[4] = {0, 0, 0, 0};
+    w[0] = m[0] | (m[1] << 16);
+    w[1] = (m[2] & 0xFF) | ((m[3] & 0xFF) << 8) | (m[4] << 16);
+    for (int q = 0; q < 8; ++q) w[2 + (q >> 2)] |= (m[8 + q] & 0xFF) << (8 * (q & 3));
+    bundles.insert(bundles.end(), w, w + 4);
+  };
+  auto disjoint = [&](const int32_t* x, const int32_t* y) {
+    // y reads nothing x writes, and writes nothing x reads or writes
+    auto writes = [](const int32_t* m, int tile) { return tile >= 0 && (m[2] == tile || m[3] == tile); };
+    for (int q = 0; q < 8; ++q) if (writes(x, y[8 + q]) || writes(y, x[8 + q])) return false;
+    return !(writes(x, y[2]) || writes(x, y[3]));
+  };
+  for (int i = 0; i < n_ops;) {
+    const int32_t* x = &mem[(size_t)i * MW];
+    pack_member(x);
+    if (i + 1 < n_ops && disjoint(x, &mem[(size_t)(i + 1) * MW])) {
+      pack_member(&mem[(size_t)(i + 1) * MW]);
+      i += 2;
+    } else {
+      pack_member(nop);
+      i += 1;
+    }
+  }
+  out.n_bundles = (int)bundles.size() / 8;
+  if (getenv("MLBP_DEBUG_BUNDLES")) {
+    for (int i = 0; i < n_ops; ++i) {
+      const int32_t* m = &mem[(size_t)i * MW];
+      fprintf(stderr, "op %2d flags %03x pslot %d dst %2d ct %2d gslot %2d src", i, m[0], m[1], m[2], m[3], m[4]);
+      for (int q = 0; q < ((m[0] >> 8) & 15); ++q) fprintf(stderr, " %d", m[8 + q]);
+      fprintf(stderr, "\n");
+    }
+    for (int b = 0; b < out.n_bundles; ++b) fprintf(stderr, "bundle %d: %08x %08x\n", b, bundles[8 * b], bundles[8 * b + 4]);
+  }
+  pack_member(nop); pack_member(nop);                            // the kernel prefetches one bundle past the end
   // constant products, flattened: {unary factor, message slot, tile, 1 = first | 2 = last of its product}
   std::vector<int32_t> ent;
+  out.why = "unsupported update kind or slot use";
   for (int k = 0; k < fp.n_cprod; ++k) {
     const int tile = out.live_of_slot[n_msgs + 1 + k];
     if (tile < 0 || out.cprods[k].empty()) return;
@@ -185,16 +257,21 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
     if (written[c] && out.live_of_slot[c] >= 0) { back.push_back(out.live_of_slot[c]); back.push_back(c | (is_vf[c] ? 0x40000000 : 0)); }
     else if (!written[c]) fill.push_back(c);
   }
-  out.n_ops = n_ops; out.n_lists = (int)lists.size(); out.n_cpw = (int)ent.size();
-  out.n_back = (int)back.size() / 2; out.n_fill = (int)fill.size();
-  out.image = ops;
-  out.image.insert(out.image.end(), lists.begin(), lists.end());
+  out.n_ops = n_ops; out.n_cpw = (int)ent.size();
+  out.n_back = (int)back.size() / 2; out.n_fill = (int)fill.size(); out.n_init = (int)init_tiles.size();
+  // device image: bundles [n_bundles + 1][2][4] | cprod entries | write-back pairs | fill slots | uniform tiles | product tiles
+  out.image = bundles;
+  out.off_ent = (int)out.image.size();
   out.image.insert(out.image.end(), ent.begin(), ent.end());
+  out.off_back = (int)out.image.size();
   out.image.insert(out.image.end(), back.begin(), back.end());
+  out.off_fill = (int)out.image.size();
   out.image.insert(out.image.end(), fill.begin(), fill.end());
-  out.off_sweeps = (int)out.image.size();
-  out.image.insert(out.image.end(), out.sweeps.begin(), out.sweeps.end());
-  out.image.push_back(0);
+  out.off_init = (int)out.image.size();
+  out.image.insert(out.image.end(), init_tiles.begin(), init_tiles.end());
+  out.off_ptile = (int)out.image.size();                         // tile of constant product k
+  for (int k = 0; k < fp.n_cprod; ++k) out.image.push_back(out.live_of_slot[n_msgs + 1 + k]);
+  for (int q = 0; q < 16; ++q) out.image.push_back(0);
   out.why = "";
   out.ok = true;
 }
@@ -230,9 +307,11 @@ bool build_shared_readout(const SharedProgram& sp, int n_msgs, int n_vars, const
 
 namespace {
 
-constexpr int WG = 256;
+constexpr int WG = 256;                // the gradient kernels and the small helpers
+constexpr int SWG = 512;               // the sweep kernel: eight waves
 constexpr int G = 16;                 // graphs per workgroup = the N of v_mfma_f64_16x16x4_f64
 constexpr int TILE = 64 * G;          // doubles per message tile
+constexpr int MW = 4;                 // words per packed member record (build_shared_program); a bundle = 8 words
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
@@ -269,6 +348,8 @@ __device__ __forceinline__ double column_sum(double v) {
 __device__ __forceinline__ bool total_ok(double t) { return t >= 1e-280 && t <= 1e280; }
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef const int32_t __attribute__((address_space(4))) * const_i32p;
+__device__ __forceinline__ const_i32p as_const(const int32_t* p) { return (const_i32p)(uintptr_t)p; }
 
 struct SharedDev {
   const double* pair_tables;
@@ -279,41 +360,16 @@ struct SharedDev {
   double* marginals;            // [B][n_vars][64] or NULL
   int32_t* status;
   uint8_t* bail;
-  const int32_t* image;
-  const int32_t* fsweeps;
+  const int32_t* image;         // SharedProgram::image (global memory; the bundles are read through the scalar cache)
   const int32_t* readout;
-  int32_t B, n_sweeps, n_msgs, P, U, n_pair_tables, n_unary_tables, n_vars;
-  int32_t n_ops, n_live, n_lists, n_cpw, n_back, n_fill, n_readout;
+  int32_t B, n_msgs, P, U, n_pair_tables, n_unary_tables, n_vars;
+  int32_t n_bundles, n_live, n_cprod, n_back, n_fill, n_init, off_back, off_fill, off_init, off_ptile;
+  const double* ptiles;         // [groups][n_cprod][1024] constant products as tiles (shared_prepare_kernel)
   int32_t vf_only;              // write back only the variable->factor messages (what the gradient reads)
   int32_t n_res;                // tiles [0, n_res) live in LDS, the rest in `spill`
   double* spill;                // [workgroups][n_live - n_res][64][16] or NULL
   const double* tfrag;          // [n_pair_tables][2][4096] A fragments of every table (only when there are <= FRAG_TABLES), or NULL
 };
-
-#ifdef MLBP_STAMPS
-__device__ unsigned long long* g_sh_stamp = nullptr;
-__device__ int g_sh_ablate = 0;
-#define ABL(bit) (abl_ & (1 << (bit)))
-#define ABL_DECL const int abl_ = __builtin_amdgcn_readfirstlane(g_sh_ablate);
-#define STAMP_DECL unsigned long long _t0 = 0, _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t0) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-#ifdef MLBP_STAMPS_LIGHT      // only the workgroup's lifetime (start -> last stamp): the shader clock the kernel runs at, undisturbed
-#define STAMPV(i) if ((i) == 6) { unsigned long long _t1; asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t1) :: "memory"); _ph[6] += _t1 - _t0; _t0 = _t1; }
-#define STAMP(i)
-#else
-#define STAMPV(i) { unsigned long long _t1; __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t1) :: "memory"); __builtin_amdgcn_sched_barrier(0); _ph[i] += _t1 - _t0; _t0 = _t1; }
-#define STAMP(i) { unsigned long long _t1; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t1) :: "memory"); __builtin_amdgcn_sched_barrier(0); _ph[i] += _t1 - _t0; _t0 = _t1; }
-#endif
-#define STAMP_FLUSH if (g_sh_stamp && blockIdx.x < 64 && threadIdx.x == 0) { for (int _i = 0; _i < 8; ++_i) g_sh_stamp[blockIdx.x * 8 + _i] = _ph[_i]; }
-#else
-#define STAMP_DECL
-#define STAMP_START
-#define STAMP(i)
-#define STAMPV(i)
-#define ABL(bit) 0
-#define ABL_DECL
-#define STAMP_FLUSH
-#endif
 
 #define MLBP_MFMA16(A)                                                               \
   _Pragma("unroll") for (int s_ = 0; s_ < 16; s_ += 2) {                            \
@@ -321,326 +377,465 @@ __device__ int g_sh_ablate = 0;
     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[s_ + 1], b[s_ + 1], acc1, 0, 0, 0); \
   }
 
-// out[table][0 | 1][wave w][k-step s][lane] = the A fragments of every table for T.m and m^T.T: element
-// (16w + (lane & 15), 4s + (lane >> 4)) of T resp. T^T.
-constexpr int FRAG_TABLES = 32;                                  // shared-table batches have a handful of tables
-__global__ __launch_bounds__(WG) void table_fragments_kernel(const double* pair_tables, double* out) {
-  const int ti = blockIdx.x >> 1, mt = blockIdx.x & 1;
-  const double* T = pair_tables + (size_t)ti * 4096;
-  double* o = out + ((size_t)ti * 2 + mt) * 4096;
-  for (int e = threadIdx.x; e < 4096; e += WG) {
-    const int lane = e & 63, s = (e >> 6) & 15, w = e >> 10;
-    const int i = 16 * w + (lane & 15), k = 4 * s + (lane >> 4);
-    o[e] = mt ? T[k * 64 + i] : T[i * 64 + k];
-  }
+#ifdef MLBP_STAMPS
+__device__ unsigned long long* g_sh_stamp = nullptr;
+__device__ int g_sh_ablate = 0;      // timing experiments of tools/stamp_shared.py (results become wrong): 1 no MFMAs, 2 no tile reads, 4 no result stores
+#define ABL(bit) (abl_ & (bit))
+#define ABL_DECL const int abl_ = __builtin_amdgcn_readfirstlane(g_sh_ablate);
+#define STAMP_DECL unsigned long long _t0 = 0, _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t0) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define STAMP(i) { unsigned long long _t1; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t1) :: "memory"); __builtin_amdgcn_sched_barrier(0); _ph[i] += _t1 - _t0; _t0 = _t1; }
+#define STAMP_FLUSH if (g_sh_stamp && blockIdx.x < 64 && (threadIdx.x & 63) == 0) { for (int _i = 0; _i < 8; ++_i) g_sh_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + _i] = _ph[_i]; }
+#else
+#define ABL(bit) 0
+#define ABL_DECL
+#define STAMP_DECL
+#define STAMP_START
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
+// Message tiles: 64 states x 16 graphs as [k-step pair sp][lane][2] doubles -- lane l = (state & 3) * 16 + graph, k-step
+// s = state >> 2 -- so that one 16-byte LDS read per lane is two k-steps of the MFMA B operand (the D fragment of row block
+// rb, registers r = 0..3 = k-steps 4 rb + r, goes back as two 16-byte writes).  8-byte accesses in ds_read2 form run at
+// half the LDS rate (MI355X_MICROARCH.md, LDS table) and were 60 % of the CU's LDS cycles.
+__device__ __forceinline__ int tile_index(int state, int graph) {
+  const int s = state >> 2, cq = state & 3;
+  return (((s >> 1) * 64 + cq * 16 + graph) << 1) | (s & 1);
 }
 
-template <int NTAB, bool SPILL>
-__global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
+// Everything of a shared-table sweep that does not depend on the sweeps, as ONE streaming launch in front of it:
+//   one wave per graph: the constant products of the graph -- per variable the product of its unary factors' table columns
+//     (LBP.py:494-498, 381-386), normalised -- written as its column of its group's message tiles in `ptiles`
+//     [group][product][1024], and the per-graph verdict in bail[] (0 = clean, 1 = the exact kernel must redo the graph),
+//     which also clears the flags;
+//   and, spread over the first blocks, fragment-ordered copies of every pairwise table: out[table][0 | 1][row block w]
+//     [k-step s][lane] = element (16 w + (lane & 15), 4 s + (lane >> 4)) of T resp. T^T (the MFMA A operand).
+// The dependent chain (row index -> rows -> product) that cost the sweep kernel a fifth of its single round runs here at
+// full occupancy instead: 8192 independent waves, two batches of rows in flight each.
+constexpr int FRAG_TABLES = 32;                                  // shared-table batches have a handful of tables
+constexpr int PWG = 256, PGB = 4;                                // threads / graphs per block of the prepare kernel
+struct PrepareDev {
+  const double* pair_tables; double* tfrag; int32_t n_frag_tables;
+  const double* unary_tables; const int32_t* unary_tab; const int32_t* ent;      // ent: [E][4] unary factor, slot, tile, first | last flags
+  double* ptiles; uint8_t* bail; int32_t* status;
+  int32_t B, U, n_unary_tables, E, n_cprod, n_groups;
+};
+__global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d) {
+  ABL_DECL
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int q = blockIdx.x; q < 2 * d.n_frag_tables; q += gridDim.x) {
+    const int ti = q >> 1, mt = q & 1;
+    const double* T = d.pair_tables + (size_t)ti * 4096;
+    double* o = d.tfrag + ((size_t)ti * 2 + mt) * 4096;
+    for (int e = t; e < 4096; e += PWG) {
+      const int l = e & 63, sk = (e >> 6) & 15, w = e >> 10;
+      const int i = 16 * w + (l & 15), k = 4 * sk + (l >> 4);
+      o[e] = mt ? T[k * 64 + i] : T[i * 64 + k];
+    }
+  }
+  const int g = blockIdx.x * PGB + wave;
+  if (g >= d.B) return;
+  double* tiles_out = d.ptiles + (size_t)(g >> 4) * d.n_cprod * TILE;       // this graph is column g & 15 of its group's tiles
+  const int col = g & 15;
+  constexpr int RB = 8;
+  constexpr unsigned KEY_LIMIT = 0x7A11A0FCu;                    // high word of 1e280
+  double cur = 1.0;
+  unsigned key = 0;
+  int k_out = 0;
+  bool flagged = false;
+  // lane u holds the table row of the graph's unary factor u (U <= 64: build_shared_program), lane e entry e of the
+  // constant-product list; both loads are independent, the entry's row then comes through the lane crossbar
+  int my_row = lane < d.U ? d.unary_tab[(size_t)g * d.U + lane] : 0;
+  if ((unsigned)my_row >= (unsigned)d.n_unary_tables) { flagged = true; my_row = 0; }    // the exact kernel meets it again and reports it
+  for (int c0 = 0; c0 < d.E; c0 += 64) {                          // (more than 64 entries: a chunk at a time)
+    const int el = min(c0 + lane, d.E - 1), n_here = min(64, d.E - c0);
+    const int ent_u = d.ent[4 * el], ent_flags = d.ent[4 * el + 3];
+    const int row = __shfl(my_row, ent_u);
+    // The scale of a unary message cancels in everything downstream (only its normalised form is ever stored, by
+    // unary_writeback_kernel), so the raw columns are multiplied and the PRODUCT is normalised once (hardware
+    // reciprocal: only the magnitude matters).  A column Message.renormalize would replace by the uniform vector
+    // (total <= 0, LBP.py:655-657) zeroes the product, and an entry that is negative, not finite or huge shows in the
+    // high words: either sends the graph to the exact kernel, decided once per product.
+    auto fetch = [&](double (&r)[RB], int e0) {
+#pragma unroll
+      for (int j = 0; j < RB; ++j) r[j] = ABL(8) ? 0.5 : d.unary_tables[(size_t)__builtin_amdgcn_readlane(row, min(e0 + j, n_here - 1)) * 64 + lane];
+    };
+    auto reduce = [&](const double (&r)[RB], int e0) {
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        if (e0 + j < n_here) {
+          const int flags = __builtin_amdgcn_readlane(ent_flags, e0 + j);
+          if (flags & 1) { cur = 1.0; key = 0; }
+          key = max(key, (unsigned)__double2hiint(r[j]));
+          cur *= r[j];
+          if (flags & 2) {
+            const double sum = wave_sum(cur);
+            flagged |= !total_ok(sum) || __any(key > KEY_LIMIT);
+            if (!ABL(16)) tiles_out[(size_t)k_out * TILE + tile_index(lane, col)] = cur * __builtin_amdgcn_rcp(sum);
+            ++k_out;
+          }
+        }
+      }
+    };
+    double ra[RB], rc[RB];                                        // two batches of rows: one in flight behind the one being reduced
+    fetch(ra, 0);
+    for (int e0 = 0; e0 < n_here; e0 += 2 * RB) {
+      if (e0 + RB < n_here) fetch(rc, e0 + RB);
+      reduce(ra, e0);
+      if (e0 + 2 * RB < n_here) fetch(ra, e0 + 2 * RB);
+      if (e0 + RB < n_here) reduce(rc, e0 + RB);
+    }
+  }
+  if (__any(flagged)) flagged = true;
+  if (lane == 0) d.bail[g] = flagged ? 1 : 0;
+}
+
+// 16 consecutive words through the scalar data cache (s_load_dwordx16): wave-uniform program data lands in SGPRs.
+struct Words16 { int32_t w[16]; };
+typedef int v16i __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ Words16 sload16(const int32_t* p) {
+  const v16i v = *(const v16i __attribute__((address_space(4)))*)(uintptr_t)p;
+  Words16 r;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r.w[i] = v[i];
+  return r;
+}
+
+// Which half of the workgroup holds (table rank, orientation) pair `sel` = 2 * rank + mt, under partition `mode`:
+//   mode 0: {T0.m, m.T1 | m.T0, T1.m}   mode 1: {T0.m, m.T0 | T1.m, m.T1}   mode 2: {T0.m, T1.m | m.T0, m.T1}
+// and its position (0 / 1) among the two that half holds.
+__device__ __forceinline__ int half_of(int mode, int sel) { return ((mode == 0 ? 0x6 : (mode == 1 ? 0xC : 0xA)) >> sel) & 1; }
+__device__ __forceinline__ int index_in_half(int mode, int sel) { return ((mode == 0 ? 0xC : (mode == 1 ? 0xA : 0xC)) >> sel) & 1; }
+
+// One workgroup = 16 graphs x 8 waves.  Wave w: half h = w >> 2, row block r = w & 3.  Each half keeps TWO of the four
+// (table, orientation) fragment sets in registers (64 VGPRs instead of 128: four waves per SIMD instead of two), and a
+// bundle's two independent updates run side by side, one per half, under one barrier -- the dependent chain of a
+// three-sweep K3 program is 9 bundles instead of 18 updates, and every SIMD has four waves to interleave matrix work
+// with tile reads.  Which sets a half holds (one of three partitions) is chosen on the device from the program and the
+// batch's table indices so that as many bundles as possible split.
+template <int NTAB, bool SPILL, bool WIDE>
+__global__ __launch_bounds__(SWG, 4) void sweep_x64_shared_kernel(SharedDev d) {
   extern __shared__ double lds[];
   double* tiles = lds;                                           // [n_res][64 states][16 graphs]
-  double* tot = tiles + (size_t)d.n_res * TILE;                  // [n_live][4 waves][16 graphs] partial column sums
+  double* tot = tiles + (size_t)d.n_res * TILE;                  // [n_live][16 graphs][4 row blocks] partial column sums
+  double2* dummy = reinterpret_cast<double2*>(tot + (size_t)d.n_live * 64);          // {1/64, 1/64}, {1, 1}, {0.25, 0.25} x 2: absent sources
+  int32_t* limg = reinterpret_cast<int32_t*>(dummy + 4);                                    // [n_bundles + 1][8] the bundles (read one ahead, broadcast)
   double* spill = SPILL ? d.spill + (size_t)blockIdx.x * (d.n_live - d.n_res) * TILE : nullptr;
   // tile t: LDS when resident, else this workgroup's slice of the global spill area (same [state][graph] layout;
   // __syncthreads orders the workgroup's global accesses as it does the LDS ones)
-  // (SPILL is a template parameter so that the all-resident instance keeps plain LDS instructions)
   auto TP = [&](int tile) -> double* {
     if (!SPILL) return tiles + (size_t)tile * TILE;
     return tile < d.n_res ? tiles + (size_t)tile * TILE : spill + (size_t)(tile - d.n_res) * TILE;
   };
-  int32_t* img = reinterpret_cast<int32_t*>(tot + (size_t)d.n_live * 64);
-  const int32_t* lists = img + d.n_ops * 8;
-  const int32_t* ent = lists + d.n_lists;
-  const int32_t* back = ent + d.n_cpw;
-  const int32_t* fill = back + 2 * d.n_back;
-  int32_t* rd = const_cast<int32_t*>(fill) + d.n_fill;           // read-out image
-  int32_t* utab = rd + d.n_readout;                              // [16][U]
-  int32_t* ptab = utab + G * d.U;                                // [P] table of factor p
-  int32_t* preg = ptab + d.P;                                    // [P] register set of factor p
-  int32_t* dist = preg + d.P;                                    // [NTAB] distinct tables, then {count, overflow}
-  int32_t* gflag = dist + NTAB + 2;                              // [16] prologue verdict per graph
-
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, lane_ = lane, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int half = wave >> 2, rb = wave & 3;
   const int gl = lane & 15, cq = lane >> 4;                      // B/D operand: graph column, k-row
   const int g0 = blockIdx.x * G;
   const int gi = g0 + gl;
   const bool gvalid = gi < d.B;
   const int gc = gvalid ? gi : d.B - 1;                          // tail columns replay the last graph, outputs masked
   const double uniform = 1.0 / 64.0;
+  const const_i32p img = as_const(d.image);
+  const const_i32p row0 = as_const(d.pair_tab + (size_t)g0 * d.P);       // the group's table of every pairwise factor
 
   STAMP_DECL
   ABL_DECL
   STAMP_START
-  // ---- phase A: indices (range-checked), program image, uniform tiles ----
-  bool ok = true, same = true;
-  for (int i = t; i < G * d.U; i += WG) {
-    const int gg = i / d.U, u = i - gg * d.U;
-    const int v = d.unary_tab[(size_t)min(g0 + gg, d.B - 1) * d.U + u];
-    ok &= (unsigned)v < (unsigned)d.n_unary_tables;
-    utab[i] = v;
+  // ---- phase A: the group's tables (every graph must name the same ones, at most NTAB distinct), the bundles, and the
+  //      constant products shared_prepare_kernel left as tiles (plain 16-byte copies: every load of the prologue is
+  //      independent of every other, one round of latency) ----
+  // (the flag words of bundle `lane`, for the partition choice below: requested first, used after everything else)
+  const int bundle_fa = lane < d.n_bundles ? d.image[(size_t)lane * 2 * MW] : 0, bundle_fb = lane < d.n_bundles ? d.image[(size_t)lane * 2 * MW + MW] : 0;
+  for (int i = t; i < 2 * MW * (d.n_bundles + 1); i += SWG) limg[i] = d.image[i];
+  if (t < 4) dummy[t] = t == 0 ? make_double2(1.0 / 64.0, 1.0 / 64.0) : (t == 1 ? make_double2(1.0, 1.0) : make_double2(0.25, 0.25));
+  {
+    const double2* src = reinterpret_cast<const double2*>(d.ptiles + (size_t)blockIdx.x * d.n_cprod * TILE);
+    for (int k = 0; k < d.n_cprod; ++k) {
+      const int tile = img[d.off_ptile + k];
+      reinterpret_cast<double2*>(TP(tile))[t] = src[(size_t)k * (TILE / 2) + t];        // SWG threads x 16 bytes = one tile
+      if (t < 64) tot[tile * 64 + t] = 0.25;                     // four partials of a total of 1
+    }
   }
-  for (int i = t; i < G * d.P; i += WG) {
+  bool ok = true, same = true;
+  for (int i = t; i < G * d.P; i += SWG) {
     const int gg = i / d.P, p = i - gg * d.P;
     const int v = d.pair_tab[(size_t)min(g0 + gg, d.B - 1) * d.P + p];
     ok &= (unsigned)v < (unsigned)d.n_pair_tables;
-    same &= v == d.pair_tab[(size_t)g0 * d.P + p];
-    if (gg == 0) ptab[p] = v;
+    same &= v == row0[p];
   }
-  {
-    const int n_img = d.n_ops * 8 + d.n_lists + d.n_cpw + 2 * d.n_back + d.n_fill;
-    for (int i = t; i < n_img; i += WG) img[i] = d.image[i];
-    if (d.marginals)
-      for (int i = t; i < d.n_readout; i += WG) rd[i] = d.readout[i];
-    double2* dst = reinterpret_cast<double2*>(tiles);
-    for (int i = t; i < d.n_res * (TILE / 2); i += WG) dst[i] = make_double2(uniform, uniform);
-    if (SPILL)
-      for (int i = t; i < (d.n_live - d.n_res) * (TILE / 2); i += WG) reinterpret_cast<double2*>(spill)[i] = make_double2(uniform, uniform);
-    for (int i = t; i < d.n_live * 64; i += WG) tot[i] = 0.25;    // four partials of a total of 1
-    if (t < G) gflag[t] = 0;
+  bool bad = d.bail[gc] != 0;                                    // the prepare kernel's verdict on this lane's graph
+  const int d0 = row0[0];
+  int d1 = d0;
+  bool over = false;
+  for (int p = 1; p < d.P; ++p) {
+    const int v = row0[p];
+    if (v != d0) {
+      if (d1 == d0) d1 = v;
+      else if (v != d1) over = true;
+    }
+  }
+  if (NTAB == 1 && d1 != d0) over = true;
+  // bit p = pairwise factor p reads the group's second table
+  int rankmask = 0;
+  for (int p = 0; p < d.P; ++p) rankmask |= (row0[p] != d0 ? 1 : 0) << p;
+  // tiles the program reads before writing them start as the uniform vector (FactorGraph.initialize, LBP.py:211-216)
+  for (int k = 0; k < d.n_init; ++k) {
+    const int tile = img[d.off_init + k];
+    reinterpret_cast<double2*>(TP(tile))[t] = make_double2(uniform, uniform);
+    if (t < 64) tot[tile * 64 + t] = 0.25;
+  }
+  if (d.msgs && !d.vf_only)                                       // slots the sweeps never touch stay uniform
+    for (int i = t; i < d.n_fill * G * 64; i += SWG) {
+      const int x = i & 63, gg = (i >> 6) & (G - 1), k = i >> 10;
+      if (g0 + gg < d.B) d.msgs[((size_t)(g0 + gg) * d.n_msgs + d.image[d.off_fill + k]) * 64 + x] = uniform;
+    }
+  STAMP(0)
+  // ---- phase C: which fragment sets each half keeps, then the fragments (lane: row l & 15, k l >> 4) ----
+  // one table: BOTH halves keep its two orientations (partition 1 with T1 = T0), so any member runs on either half and
+  // a bundle always splits
+  const bool single = d1 == d0;
+  int mode = 1;
+  if (!single) {
+    int c0 = 0, c1 = 0, c2 = 0;
+    for (int base = 0; base < d.n_bundles; base += 64) {
+      const int i = base + lane;
+      bool p0 = false, p1 = false, p2 = false;
+      if (i < d.n_bundles) {
+        const int fa = base == 0 ? bundle_fa : d.image[(size_t)i * 2 * MW], fb = base == 0 ? bundle_fb : d.image[(size_t)i * 2 * MW + MW];
+        if ((fa & 1) && (fb & 1)) {
+          const int sa = 2 * ((rankmask >> ((fa >> 16) & 15)) & 1) + ((fa >> 1) & 1);
+          const int sb = 2 * ((rankmask >> ((fb >> 16) & 15)) & 1) + ((fb >> 1) & 1);
+          p0 = half_of(0, sa) != half_of(0, sb); p1 = half_of(1, sa) != half_of(1, sb); p2 = half_of(2, sa) != half_of(2, sb);
+        }
+      }
+      c0 += __popcll(__ballot(p0)); c1 += __popcll(__ballot(p1)); c2 += __popcll(__ballot(p2));
+    }
+    mode = (c0 >= c1 && c0 >= c2) ? 0 : (c1 >= c2 ? 1 : 2);
+  }
+  mode = __builtin_amdgcn_readfirstlane(mode);
+  double fr0[16], fr1[16];
+#pragma unroll
+  for (int idx = 0; idx < 2; ++idx) {
+    int sel = 0;
+    for (int q = 0; q < 4; ++q)
+      if (half_of(mode, q) == half && index_in_half(mode, q) == idx) sel = q;
+    const int ti = (sel >> 1) ? d1 : d0, mt = sel & 1;
+    double (&fr)[16] = idx ? fr1 : fr0;
+    if (ok && d.tfrag) {
+      // copies in operand order (table_fragments_kernel): one contiguous 512-byte read per fragment
+      const double* F = d.tfrag + ((size_t)ti * 2 + mt) * 4096 + rb * 1024 + lane;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) fr[s] = F[64 * s];
+    } else if (ok) {
+      const double* T = d.pair_tables + (size_t)ti * 4096;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        fr[s] = mt ? T[(4 * s + cq) * 64 + 16 * rb + gl]          // (m^T.T)[x]: A[x][y] = T[y][x]
+                   : T[(16 * rb + gl) * 64 + 4 * s + cq];         // (T.m)[x]  : A[x][y] = T[x][y]
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) fr[s] = 0.0;
+    }
   }
   if (!__syncthreads_and(ok ? 1 : 0)) {
     if (t == 0) atomicExch(d.status, 1);
     return;
   }
-  if (t == 0) {
-    int nd = 0, over = 0;
-    for (int p = 0; p < d.P; ++p) {
-      int r = 0;
-      while (r < nd && dist[r] != ptab[p]) ++r;
-      if (r == nd) {
-        if (nd < NTAB) dist[nd++] = ptab[p];
-        else { over = 1; r = 0; }
-      }
-      preg[p] = r;
-    }
-    dist[NTAB] = nd; dist[NTAB + 1] = over;
-  }
-  if (!__syncthreads_and(same ? 1 : 0) || dist[NTAB + 1]) {      // not a shared-table batch: exact kernel takes all 16
+  if (!__syncthreads_and(same ? 1 : 0) || over) {                // not a shared-table batch: exact kernel takes all 16
     if (t < G && g0 + t < d.B) d.bail[g0 + t] = 4;
     return;
   }
-
-  STAMPV(0)
-  // ---- phase B: A fragments of every distinct table, both orientations (lane: row l&15, k l>>4) ----
-  double aTM[NTAB][16], aMT[NTAB][16];
-  const int nd = __builtin_amdgcn_readfirstlane(dist[NTAB]);
-#pragma unroll
-  for (int r = 0; r < NTAB; ++r) {
-    const int ti = __builtin_amdgcn_readfirstlane(dist[r < nd ? r : 0]);
-    if (d.tfrag) {
-      // copies in operand order (table_fragments_kernel): one contiguous 512-byte read per fragment; read
-      // straight from the row-major table the same fragments are 16 rows x 32 bytes per instruction and kept
-      // the CU's address unit busy for ~20 us per workgroup
-      const double* F = d.tfrag + (size_t)ti * 2 * 4096 + wave * 1024 + lane;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        aTM[r][s] = F[64 * s];
-        aMT[r][s] = F[4096 + 64 * s];
-      }
-    } else {
-      const double* T = d.pair_tables + (size_t)ti * 4096;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        aTM[r][s] = T[(16 * wave + gl) * 64 + 4 * s + cq];       // (T.m)[x]  : A[x][y] = T[x][y]
-        aMT[r][s] = T[(4 * s + cq) * 64 + 16 * wave + gl];       // (m^T.T)[x]: A[x][y] = T[y][x]
-      }
-    }
-  }
-
+  if (SPILL) __syncthreads();                                    // (spilled tiles were written through global memory)
   STAMP(1)
-  // ---- phase C: unary messages (constants) -> one product tile per variable ----
-  // wave w takes graphs 4w..4w+3 with lanes = states.  Loads only (the write-back of these constants is a
-  // separate streaming kernel): every load is unconditional (clamped index) so that the rows of the NEXT
-  // batch stay in flight while the current one is reduced -- the only HBM reads of the kernel that miss L2.
-  {
-    // Four rotating buffers of HB rows: three batches are always in flight behind the one being reduced (a
-    // batch costs ~0.4 us of arithmetic against ~2.5 us of load latency).  Every fetch is unconditional -- the
-    // cursor clamps at the last batch -- so the wait before a batch is a fixed vmcnt and never drains the queue.
-    constexpr int HB = 8;
-    const int E = d.n_cpw / 4;
-    const int cpg = (E + HB - 1) / HB, nb = 4 * cpg;             // batches per graph, batches of this wave
-    double cur = 1.0;
-    unsigned key = 0;                                            // largest high word met in the running product's rows
-    // high word of 1e280: a row entry above it as an unsigned integer is negative, not finite, or too large to multiply on
-    constexpr unsigned KEY_LIMIT = 0x7A11A0FCu;
-    int fj = 0, fe = 0, pj = 0, pe = 0;                          // fetch / process cursors: graph 4w + j, first entry
-    // entry e of the list lives in lane e: the per-row scalars come from v_readlane instead of a chain of
-    // dependent LDS reads per row (three round trips per row were most of this phase)
-    const int el = min(lane, E > 0 ? E - 1 : 0);
-    const int ent_u = E > 0 ? ent[4 * el] : 0, ent_tile = E > 0 ? ent[4 * el + 2] : 0, ent_flags = E > 0 ? ent[4 * el + 3] : 0;
-    int row_of = 0;                                              // table row of entry `lane` of the graph being fetched
-    auto fetch = [&](double (&r)[HB]) {
-      if (fe == 0) row_of = utab[(4 * wave + fj) * d.U + ent_u];
-#pragma unroll
-      for (int j = 0; j < HB; ++j)
-        r[j] = d.unary_tables[(size_t)__builtin_amdgcn_readlane(row_of, min(fe + j, E - 1)) * 64 + lane];
-      if (fe + HB < E) fe += HB;
-      else if (fj < 3) { fe = 0; ++fj; }
-    };
-    auto process = [&](const double (&row)[HB]) {
-      const int gg = 4 * wave + pj;
-#pragma unroll
-      for (int j = 0; j < HB; ++j) {
-        if (pe + j < E) {
-          // The scale of a unary message cancels in everything downstream (only its normalised form is ever
-          // stored, by unary_writeback_kernel), so the raw columns are multiplied and the PRODUCT is
-          // normalised once (hardware reciprocal: only the magnitude matters).  A column Message.renormalize
-          // would replace by the uniform vector (total <= 0, LBP.py:655-657) zeroes the product, and an entry that
-          // is negative, not finite or huge shows in the high words: either sends the graph to the exact kernel,
-          // decided once per product instead of once per row.
-          const int flags = __builtin_amdgcn_readlane(ent_flags, pe + j);
-          if (flags & 1) { cur = 1.0; key = 0; }
-          const double r = row[j];
-          key = max(key, (unsigned)__double2hiint(r));
-          cur *= r;
-          if (flags & 2) {
-            const double s = ABL(2) ? 64.0 : wave_sum(cur);
-            const bool bad = !total_ok(s) || __any(key > KEY_LIMIT);
-            if (!ABL(1)) TP(__builtin_amdgcn_readlane(ent_tile, pe + j))[lane * G + gg] = cur * __builtin_amdgcn_rcp(s);
-            if (bad) gflag[gg] = 1;
-          }
-        }
-      }
-      pe += HB;
-      if (pe >= E) { pe = 0; ++pj; }
-    };
-    if (E > 0) {
-      double r0[HB], r1[HB], r2[HB], r3[HB];
-      fetch(r0); fetch(r1); fetch(r2);
-      for (int i = 0; i < nb; i += 4) {
-        fetch(r3); process(r0);
-        fetch(r0); if (i + 1 < nb) process(r1);
-        fetch(r1); if (i + 2 < nb) process(r2);
-        fetch(r2); if (i + 3 < nb) process(r3);
-      }
-    }
-  }
-  if (d.msgs && !d.vf_only)                                       // slots the sweeps never touch stay uniform
-    for (int i = t; i < d.n_fill * G * 64; i += WG) {
-      const int x = i & 63, gg = (i >> 6) & (G - 1), k = i >> 10;
-      if (g0 + gg < d.B) d.msgs[((size_t)(g0 + gg) * d.n_msgs + fill[k]) * 64 + x] = uniform;
-    }
-  __syncthreads();
-  bool bad = gflag[gl] != 0;
-  STAMPV(2)
 
-  // ---- main loop: the same in all four waves; one barrier per update ----
-  for (int sw = 0; sw < d.n_sweeps; ++sw) {
-    const int op0 = d.fsweeps[2 * sw], op1 = op0 + d.fsweeps[2 * sw + 1];
-    for (int o = op0; o < op1; ++o) {
-      const int4 h0 = reinterpret_cast<const int4*>(img)[2 * o];
-      const int4 h1 = reinterpret_cast<const int4*>(img)[2 * o + 1];
-      const int kind = __builtin_amdgcn_readfirstlane(h0.x);
-      const int k8 = kind & 0xFF;
-      const int pslot = __builtin_amdgcn_readfirstlane(h1.x), dst = __builtin_amdgcn_readfirstlane(h1.y);
-      double b[16];
-      if (k8 >= FOP_VAR) {
-        // variable -> factor (LBP.py:377-389): constant product (or uniform) times the other incoming messages
-        const int a = __builtin_amdgcn_readfirstlane(h0.y), n = __builtin_amdgcn_readfirstlane(h0.z);
-        {
-          const double* src = TP(__builtin_amdgcn_readfirstlane(lists[a])) + lane;
-#pragma unroll
-          for (int s = 0; s < 16; ++s) b[s] = src[64 * s];
-        }
-        for (int q = 1; q < n && !ABL(7); ++q) {
-          const int tl = __builtin_amdgcn_readfirstlane(lists[a + q]);
-          const double* tp = tot + tl * 64 + gl;
-          const double total = (tp[0] + tp[16]) + (tp[32] + tp[48]);
+  // ---- main loop: one barrier per bundle; a bundle's members go to the halves that hold their fragments ----
+  // One member, run by the four waves of a half.  The K = 64 contraction goes in four quarters of four k-steps: a
+  // quarter's tile reads and products issue while the previous quarter's MFMAs run, and only 4 + 4 message registers are
+  // live beside the 64 fragment registers (the budget is 128 at four waves per SIMD).
+  // The next bundle's descriptor is requested (scalar load) once this member's LDS reads are over -- scalar loads
+  // and LDS reads share one counter, so a request in front of them would be waited for with them.
+  // WIDE = false (programs whose variable updates multiply at most two tiles -- a constant product and one message: K2, K3,
+  // chains, rings): every LDS read of a quarter is issued together, and quarter h + 1's reads are issued BEFORE quarter h's
+  // MFMAs, so the only exposed LDS latency of a member is its first one.  WIDE = true: any number of sources, read
+  // one after the other (the straight-line form for three sources does not fit the 128 registers).
+  auto run = [&](const int flags, const int w1, const int w3, const int w4) {
+    // (lane-derived values are formed again per member from a laundered copy of the lane id: kept across the loop they cost
+    // registers the fragments need -- the compiler otherwise spills FRAGMENTS to scratch inside the MFMA sequence)
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));
+    const int gl = lane & 15, cq = lane >> 4;
+    const int nsrc = (flags >> 8) & 15;
+    const bool want = (flags & (4 | 8 | 16)) != 0, mm = (flags & 1) != 0;
+    const int sel = 2 * ((rankmask >> ((flags >> 16) & 15)) & 1) + ((flags >> 1) & 1);
+    const bool second_set = index_in_half(mode, sel) != 0;
+    const int s0 = w3 & 0xFF, s1 = (w3 >> 8) & 0xFF;
+    const bool has0 = s0 != 0xFF && !ABL(2), has1 = nsrc > 1 && !ABL(2);
+    // an absent source reads a 16-byte constant instead (every lane the same address, stride 0): {1/64, 1/64} for a first
+    // source nothing has updated yet (LBP.py:211-216), {1, 1} for a second one -- so that every read below is
+    // unconditional (conditional reads double the live registers)
+    const double2* src0 = has0 ? reinterpret_cast<const double2*>(TP(s0)) + lane : dummy;
+    const double2* src1 = has1 ? reinterpret_cast<const double2*>(TP(s1)) + lane : dummy + 1;
+    const int st0 = has0 ? 128 : 0, of0 = has0 ? 64 : 0, st1 = has1 ? 128 : 0, of1 = has1 ? 64 : 0;
+    double2 r0a, r0b, r1a, r1b;
+    double scale = 1.0;
+    if (!WIDE) {
+      // all first reads of the member at once: the sources' partial totals and their first quarter.  The scale of the
+      // product cancels downstream (every stored message is normalised by its own total); the reciprocals only keep the
+      // magnitudes in range: the hardware reciprocal is enough
+      const double2* tp0 = has0 ? reinterpret_cast<const double2*>(tot + s0 * 64 + gl * 4) : dummy + 2;
+      const double2* tp1 = has1 ? reinterpret_cast<const double2*>(tot + s1 * 64 + gl * 4) : dummy + 2;
+      const double2 ta = tp0[0], tb = tp0[1], tc = tp1[0], td = tp1[1];
+      r0a = src0[0]; r0b = src0[of0];
+      r1a = src1[0]; r1b = src1[of1];
+      const double t0 = (ta.x + ta.y) + (tb.x + tb.y), t1 = (tc.x + tc.y) + (td.x + td.y);
+      bad |= !total_ok(t0) | !total_ok(t1);
+      scale = __builtin_amdgcn_rcp(t0) * __builtin_amdgcn_rcp(t1);
+    } else {
+#pragma unroll 1
+      for (int q = 0; q < nsrc; ++q) {
+        const int tl = ((q < 4 ? w3 : w4) >> (8 * (q & 3))) & 0xFF;
+        if (tl != 0xFF) {
+          const double* tp = tot + tl * 64 + gl * 4;
+          const double total = (tp[0] + tp[1]) + (tp[2] + tp[3]);
           bad |= !total_ok(total);
-          // the scale of this product cancels downstream (every stored message is normalised by its own
-          // total), the factor only keeps the magnitudes in range: the hardware reciprocal is enough
-          const double inv = __builtin_amdgcn_rcp(total);
-          const double* src = TP(tl) + lane;
-#pragma unroll
-          for (int s = 0; s < 16; ++s) b[s] *= src[64 * s] * inv;
+          scale *= __builtin_amdgcn_rcp(total);
         }
-        STAMP(3)
-        const int ct = __builtin_amdgcn_readfirstlane(h0.w);
-        const bool out_now = (kind & 0x200) && d.msgs && !ABL(4);
-        if (ct >= 0 || out_now || k8 == FOP_VAR) {               // the message itself is wanted: its total too
-          const double part = (((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]))) +
-                              (((b[8] + b[9]) + (b[10] + b[11])) + ((b[12] + b[13]) + (b[14] + b[15])));
-          const double tb = ABL(5) ? 4.0 * part : column_sum(part);
-          bad |= !total_ok(tb);
-          if (ct >= 0) {                                         // read again later: keep it as a tile
+      }
+    }
+    STAMP(6)
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    double part = 0.0;
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
-              if ((s >> 2) == wave) TP(ct)[64 * s + lane] = b[s];
-            if (cq == 0) tot[ct * 64 + wave * 16 + gl] = 0.25 * tb;
-          } else if (out_now && gvalid && !bad) {                // last value of this slot: straight to HBM
-            double* out = d.msgs + ((size_t)gc * d.n_msgs + __builtin_amdgcn_readfirstlane(h1.z)) * 64 + cq;
-            const double itb = 1.0 / tb;
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-              if ((s >> 2) == wave) out[4 * s] = b[s] * itb;
-          }
+    for (int h = 0; h < 4; ++h) {                                // quarter h = states 16 h .. 16 h + 15 = k-steps 4 h .. 4 h + 3
+      double b[4];
+      if (!WIDE) {
+        // variable -> factor (LBP.py:377-389): constant product (or uniform) times the other incoming message
+        b[0] = (r0a.x * scale) * r1a.x; b[1] = (r0a.y * scale) * r1a.y; b[2] = (r0b.x * scale) * r1b.x; b[3] = (r0b.y * scale) * r1b.y;
+        __builtin_amdgcn_sched_barrier(0);
+        if (h < 3) {                                             // the next quarter's reads go out ahead of this quarter's MFMAs
+          r0a = src0[st0 * (h + 1)]; r0b = src0[st0 * (h + 1) + of0];
+          r1a = src1[st1 * (h + 1)]; r1b = src1[st1 * (h + 1) + of1];
         }
-        if (k8 == FOP_VAR) {
-          __syncthreads();
-          continue;
-        }
+        __builtin_amdgcn_sched_barrier(0);
       } else {
-        const int tl = __builtin_amdgcn_readfirstlane(h0.y);
-        if (tl >= 0) {
-          const double* tp = tot + tl * 64 + gl;
-          const double total = (tp[0] + tp[16]) + (tp[32] + tp[48]);
-          bad |= !total_ok(total);
-          const double inv = __builtin_amdgcn_rcp(total);
-          const double* src = TP(tl) + lane;
+        {
+          const double2 v0 = src0[st0 * h], v1 = src0[st0 * h + of0];
+          b[0] = v0.x * scale; b[1] = v0.y * scale; b[2] = v1.x * scale; b[3] = v1.y * scale;
+        }
+#pragma unroll 1
+        for (int q = 1; q < nsrc && !ABL(2); ++q) {
+          const int tl = ((q < 4 ? w3 : w4) >> (8 * (q & 3))) & 0xFF;
+          const double2* sq = reinterpret_cast<const double2*>(TP(tl)) + lane + 128 * h;
+          const double2 u0 = sq[0], u1 = sq[64];
+          b[0] *= u0.x; b[1] *= u0.y; b[2] *= u1.x; b[3] *= u1.y;
+        }
+      }
+      if (want) {                                                // the message itself is wanted: its total, and this wave's quarter
+        part += (b[0] + b[1]) + (b[2] + b[3]);
+        if (rb == h && (flags & 4)) {                            // read again later: keep it as a tile
+          double2* o = reinterpret_cast<double2*>(TP((w1 >> 8) & 0xFF)) + 128 * rb + lane;
+          o[0] = make_double2(b[0], b[1]); o[64] = make_double2(b[2], b[3]);
+        }
+      }
+      STAMP(2)
+      // factor -> variable (LBP.py:500-524): v_mfma_f64_16x16x4_f64 against the resident fragments
+      if (mm && ABL(1)) { acc.x += b[0]; acc.y += b[1]; acc.z += b[2]; acc.w += b[3]; }
+      else if (mm) {
+        if (!second_set) {
 #pragma unroll
-          for (int s = 0; s < 16; ++s) b[s] = src[64 * s] * inv;
-        } else {                                                 // a message nothing has updated yet (LBP.py:211-216)
+          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr0[4 * h + i], b[i], acc, 0, 0, 0);
+        } else {
 #pragma unroll
-          for (int s = 0; s < 16; ++s) b[s] = uniform;
+          for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr1[4 * h + i], b[i], acc, 0, 0, 0);
         }
       }
       STAMP(7)
-      // factor -> variable (LBP.py:500-524): 16 x v_mfma_f64_16x16x4_f64 against the resident fragments
-      const bool mt = (k8 == FOP_PAIR_MT || k8 == FOP_VAR_PAIR_MT);
-      const int sel = __builtin_amdgcn_readfirstlane(preg[pslot]) * 2 + (mt ? 1 : 0);
-      double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-      if (ABL(6)) { acc0.x = b[0]; acc0.y = b[5]; acc1.z = b[10]; acc1.w = b[15]; }
-      else if (sel == 0) { MLBP_MFMA16(aTM[0]) }
-      else if (sel == 1) { MLBP_MFMA16(aMT[0]) }
-      else if (NTAB > 1 && sel == 2) { MLBP_MFMA16(aTM[NTAB > 1 ? 1 : 0]) }
-      else if (NTAB > 1 && sel == 3) { MLBP_MFMA16(aMT[NTAB > 1 ? 1 : 0]) }
-      else if (NTAB > 2 && sel == 4) { MLBP_MFMA16(aTM[NTAB > 2 ? 2 : 0]) }
-      else if (NTAB > 2) { MLBP_MFMA16(aMT[NTAB > 2 ? 2 : 0]) }
-      const double4_t acc = acc0 + acc1;
-      double* out = TP(dst) + (16 * wave + cq) * G + gl;             // D: state 16w + (l>>4) + 4r
-      out[0] = acc.x; out[4 * G] = acc.y; out[8 * G] = acc.z; out[12 * G] = acc.w;
-      const double part = column_sum((acc.x + acc.y) + (acc.z + acc.w));
-      if (cq == 0) tot[dst * 64 + wave * 16 + gl] = part;
-      STAMP(4)
-      __syncthreads();
-      STAMP(5)
     }
+    if (want) {
+      const double tb = column_sum(part);
+      bad |= !total_ok(tb);
+      if (flags & 4) {
+        if (cq == 0) tot[((w1 >> 8) & 0xFF) * 64 + gl * 4 + rb] = 0.25 * tb;
+      } else if ((flags & 8) && d.msgs && g0 + gl < d.B && !bad) {      // last value of this slot: straight to HBM, normalised --
+        double kq[4];                                            // this wave's quarter is formed once more now that the total is known
+        {
+          const double2 v0 = src0[st0 * rb], v1 = src0[st0 * rb + of0];
+          kq[0] = v0.x * scale; kq[1] = v0.y * scale; kq[2] = v1.x * scale; kq[3] = v1.y * scale;
+        }
+#pragma unroll 1
+        for (int q = 1; q < nsrc; ++q) {
+          const double2* sq = reinterpret_cast<const double2*>(TP(((q < 4 ? w3 : w4) >> (8 * (q & 3))) & 0xFF)) + lane + 128 * rb;
+          const double2 v0 = sq[0], v1 = sq[64];
+          kq[0] *= v0.x; kq[1] *= v0.y; kq[2] *= v1.x; kq[3] *= v1.y;
+        }
+        const int gcv = g0 + gl;
+        double* out = d.msgs + ((size_t)gcv * d.n_msgs + ((w1 >> 16) & 0xFFFF)) * 64 + 16 * rb + cq;
+        const double itb = 1.0 / tb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[4 * j] = kq[j] * itb;
+      }
+    }
+    if (!mm) return;
+    const int dst = w1 & 0xFF;
+    double2* out = reinterpret_cast<double2*>(TP(dst)) + 128 * rb + lane;        // D: state 16 rb + (l >> 4) + 4 r = k-step 4 rb + r
+    if (!ABL(4)) { out[0] = make_double2(acc.x, acc.y); out[64] = make_double2(acc.z, acc.w); }
+    const double colsum = column_sum((acc.x + acc.y) + (acc.z + acc.w));
+    if (cq == 0) tot[dst * 64 + gl * 4 + rb] = colsum;
+    STAMP(3)
+  };
+  // the bundles sit in LDS; a bundle's 16 words are read (broadcast) one bundle ahead -- LDS reads return in order, so they
+  // cost the tile reads behind them nothing (a scalar load from memory would be waited for with them: one counter)
+  const int4* li = reinterpret_cast<const int4*>(limg);
+  int4 nA = li[0], nB = li[1];
+  for (int k = 0; k < d.n_bundles; ++k) {
+    const int a0 = __builtin_amdgcn_readfirstlane(nA.x), a1 = __builtin_amdgcn_readfirstlane(nA.y), a2 = __builtin_amdgcn_readfirstlane(nA.z),
+              a3 = __builtin_amdgcn_readfirstlane(nA.w);
+    const int b0 = __builtin_amdgcn_readfirstlane(nB.x), b1 = __builtin_amdgcn_readfirstlane(nB.y), b2 = __builtin_amdgcn_readfirstlane(nB.z),
+              b3 = __builtin_amdgcn_readfirstlane(nB.w);
+    int hA = ((a0 & 1) && !single) ? half_of(mode, 2 * ((rankmask >> ((a0 >> 16) & 15)) & 1) + ((a0 >> 1) & 1)) : -1;
+    int hB = ((b0 & 1) && !single) ? half_of(mode, 2 * ((rankmask >> ((b0 >> 16) & 15)) & 1) + ((b0 >> 1) & 1)) : -1;
+    if (hA < 0) hA = hB >= 0 ? 1 - hB : 0;                       // a member that can run anywhere goes to the idle half
+    if (hB < 0) hB = 1 - hA;
+#pragma unroll 1
+    for (int mi = 0; mi < 2; ++mi) {                             // (one copy of the member code)
+      const bool second = mi != 0;
+      const int f = second ? b0 : a0;
+      if ((f & 0xFF) != 0 && (second ? hB : hA) == half) run(f, second ? b1 : a1, second ? b2 : a2, second ? b3 : a3);
+    }
+    // the next bundle's words are requested here, behind the member (its registers are free again) and in front of the
+    // barrier (they arrive while the workgroup meets)
+    __builtin_amdgcn_sched_barrier(0);
+    nA = li[2 * k + 2]; nB = li[2 * k + 3];                      // the image is padded by one bundle
+    __syncthreads();
+    STAMP(4)
   }
 
   // ---- epilogue: marginals, message write-back, verdicts ----
   // a bad total met only here (the last update's result) must reach the verdict of every wave
   if (d.marginals) {
-    for (int v = wave; v < d.n_vars; v += 4) {
+    const const_i32p rd = as_const(d.readout);
+    for (int v = wave; v < d.n_vars; v += SWG / 64) {
       const int at = rd[v];
       const int base = rd[at], n = rd[at + 1];
       double m[16];
       if (base >= 0) {
-        const double* src = TP(base) + lane;
+        const double2* src = reinterpret_cast<const double2*>(TP(base)) + lane;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) m[s] = src[64 * s];
+        for (int sp = 0; sp < 8; ++sp) { const double2 v = src[64 * sp]; m[2 * sp] = v.x; m[2 * sp + 1] = v.y; }
       } else {
 #pragma unroll
         for (int s = 0; s < 16; ++s) m[s] = uniform;
       }
       for (int q = 0; q < n; ++q) {
         const int tl = rd[at + 2 + q];
-        const double* tp = tot + tl * 64 + gl;
-        const double total = (tp[0] + tp[16]) + (tp[32] + tp[48]);
+        const double* tp = tot + tl * 64 + gl * 4;
+        const double total = (tp[0] + tp[1]) + (tp[2] + tp[3]);
         bad |= !total_ok(total);
         const double inv = 1.0 / total;
-        const double* src = TP(tl) + lane;
+        const double2* src = reinterpret_cast<const double2*>(TP(tl)) + lane;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) m[s] *= src[64 * s] * inv;
+        for (int sp = 0; sp < 8; ++sp) { const double2 v = src[64 * sp]; m[2 * sp] *= v.x * inv; m[2 * sp + 1] *= v.y * inv; }
       }
       double part = 0.0;
 #pragma unroll
@@ -655,21 +850,22 @@ __global__ __launch_bounds__(WG, 2) void sweep_x64_shared_kernel(SharedDev d) {
       }
     }
   }
-  for (int i = wave; i < d.n_back; i += 4) {
-    const int tl = back[2 * i], slot = back[2 * i + 1] & 0x3FFFFFFF;
-    const bool is_vf = (back[2 * i + 1] & 0x40000000) != 0;
-    const double* tp = tot + tl * 64 + gl;
-    const double total = (tp[0] + tp[16]) + (tp[32] + tp[48]);
+  for (int i = wave; i < d.n_back; i += SWG / 64) {
+    const int tl = img[d.off_back + 2 * i], sl = img[d.off_back + 2 * i + 1];
+    const int slot = sl & 0x3FFFFFFF;
+    const bool is_vf = (sl & 0x40000000) != 0;
+    const double* tp = tot + tl * 64 + gl * 4;
+    const double total = (tp[0] + tp[1]) + (tp[2] + tp[3]);
     bad |= !total_ok(total);
     if (d.msgs && (!d.vf_only || is_vf) && gvalid && !bad) {
-      const double* src = TP(tl) + lane;
+      const double2* src = reinterpret_cast<const double2*>(TP(tl)) + lane;
       double* out = d.msgs + ((size_t)gc * d.n_msgs + slot) * 64 + cq;
       const double inv = 1.0 / total;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) out[4 * s] = src[64 * s] * inv;
+      for (int sp = 0; sp < 8; ++sp) { const double2 v = src[64 * sp]; out[8 * sp] = v.x * inv; out[8 * sp + 4] = v.y * inv; }
     }
   }
-  STAMPV(6)
+  STAMP(5)
   STAMP_FLUSH
   if (bad && gvalid) d.bail[gi] = 2;                             // any wave that saw it says so (idempotent)
 }
@@ -873,21 +1069,21 @@ __global__ __launch_bounds__(WG) void gradient_shared_pairs_kernel(PairGradDev d
 
 std::mutex g_attr_mutex;
 
-template <int NTAB, bool SPILL>
+template <int NTAB, bool SPILL, bool WIDE>
 int launch(const SharedDev& d, size_t lds, hipStream_t st) {
   static size_t granted = 0;
   {
     std::lock_guard<std::mutex> lock(g_attr_mutex);
     if (lds > granted) {
-      hipError_t e = hipFuncSetAttribute((const void*)sweep_x64_shared_kernel<NTAB, SPILL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute((const void*)sweep_x64_shared_kernel<NTAB, SPILL, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return fail(MLBP_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       granted = lds;
       int per_cu = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sweep_x64_shared_kernel<NTAB, SPILL>, WG, lds) == hipSuccess)
-        fail(MLBP_OK, "shared-table kernel <%d%s>: %zu bytes of LDS per workgroup, %d workgroups per CU", NTAB, SPILL ? ", spilling" : "", lds, per_cu);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sweep_x64_shared_kernel<NTAB, SPILL, WIDE>, SWG, lds) == hipSuccess)
+        fail(MLBP_OK, "shared-table kernel <%d%s%s>: %zu bytes of LDS per workgroup, %d workgroups per CU", NTAB, SPILL ? ", spilling" : "", WIDE ? ", wide" : "", lds, per_cu);
     }
   }
-  hipLaunchKernelGGL((sweep_x64_shared_kernel<NTAB, SPILL>), dim3((d.B + G - 1) / G), dim3(WG), lds, st, d);
+  hipLaunchKernelGGL((sweep_x64_shared_kernel<NTAB, SPILL, WIDE>), dim3((d.B + G - 1) / G), dim3(SWG), lds, st, d);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed: %s", hipGetErrorString(e));
   return MLBP_OK;
@@ -904,41 +1100,50 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   if (!sp.ok || !prog->d_simage) return fail(MLBP_OK, "shared-table kernel not used: %s", sp.why);
   if (a->marginals && !prog->d_sreadout)
     return fail(MLBP_OK, "shared-table kernel not used: a variable's constant messages match no folded product");
-  const int n_readout = a->marginals ? prog->n_sreadout : 0;
   const int ntab = prog->P >= 2 ? 2 : 1;
-  const size_t words = (size_t)sp.off_sweeps + 1 + n_readout + (size_t)G * prog->U + 2 * prog->P + 2 * ntab + 3 + G + 8;
   // resident tiles: as many as fit HALF the CU's LDS, so that two workgroups share a CU (constant products and
   // factor->variable messages come first in the numbering); the rest spill to global memory.  Measured on K4 user
   // graphs (21 tiles): 8 resident + 13 spilled with two workgroups per CU 0.216 ms, 16 resident + 5 spilled with
   // one 0.266 ms.
-  const size_t fixed = (size_t)sp.n_live * 64 * sizeof(double) + words * sizeof(int32_t);
+  const size_t fixed = (size_t)sp.n_live * 64 * sizeof(double) + 64 + 8 * (size_t)(sp.n_bundles + 1) * sizeof(int32_t) + 64;
   int n_res = sp.n_live;
   while (n_res > 0 && fixed + (size_t)n_res * TILE * sizeof(double) > 80 * 1024) --n_res;
   const size_t lds = fixed + (size_t)n_res * TILE * sizeof(double);
+  const int n_cprod = (int)sp.cprods.size();
   if (n_res < 1 || sp.n_live - n_res > 16 || lds > 160 * 1024)   // too much would spill: the per-graph kernels do better
     return fail(MLBP_OK, "shared-table kernel not used: %d live message tiles, %d fit LDS", sp.n_live, n_res);
+  if (n_cprod < 1 || n_cprod > 8) return fail(MLBP_OK, "shared-table kernel not used: %d constant products (1..8)", n_cprod);
   mlbp_program* mp = const_cast<mlbp_program*>(prog);
-  const size_t spill_doubles = (size_t)((a->B + G - 1) / G) * (sp.n_live - n_res) * TILE;
+  const int n_groups = (a->B + G - 1) / G;
+  const size_t spill_doubles = (size_t)n_groups * (sp.n_live - n_res) * TILE;
   if (spill_doubles > mp->spill_cap) {             // first use at this size (a stream-capturing caller warms up first)
     (void)hipFree(mp->d_spill);
     mp->d_spill = nullptr; mp->spill_cap = 0;
     if (hipMalloc(&mp->d_spill, spill_doubles * sizeof(double)) != hipSuccess) return fail(MLBP_EHIP, "tile spill allocation failed");
     mp->spill_cap = spill_doubles;
   }
+  const size_t ptile_doubles = (size_t)n_groups * n_cprod * TILE;
+  if (ptile_doubles > mp->ptiles_cap) {
+    (void)hipFree(mp->d_ptiles);
+    mp->d_ptiles = nullptr; mp->ptiles_cap = 0;
+    if (hipMalloc(&mp->d_ptiles, ptile_doubles * sizeof(double)) != hipSuccess) return fail(MLBP_EHIP, "product tile allocation failed");
+    mp->ptiles_cap = ptile_doubles;
+  }
   if (mp->bail_cap < a->B)
     if (int e = mlbp_program_reserve(mp, a->B)) return e;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(mp->d_bail, 0, (size_t)a->B, st) != hipSuccess) return fail(MLBP_EHIP, "hipMemsetAsync failed");
   SharedDev d;
   d.pair_tables = a->pair_tables; d.pair_tab = a->pair_tab; d.unary_tables = a->unary_tables; d.unary_tab = a->unary_tab;
   d.msgs = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && !a->gradient) ? nullptr : a->msgs;
   d.vf_only = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && a->gradient) ? 1 : 0;
   d.marginals = a->marginals; d.status = prog->d_status; d.bail = mp->d_bail;
-  d.image = prog->d_simage; d.fsweeps = prog->d_simage + sp.off_sweeps; d.readout = prog->d_sreadout;
-  d.B = a->B; d.n_sweeps = (int)sp.sweeps.size() / 2; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U;
+  d.image = prog->d_simage; d.readout = prog->d_sreadout;
+  d.B = a->B; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U;
   d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables; d.n_vars = prog->n_vars;
-  d.n_ops = sp.n_ops; d.n_live = sp.n_live; d.n_lists = sp.n_lists; d.n_cpw = sp.n_cpw; d.n_back = sp.n_back;
-  d.n_fill = sp.n_fill; d.n_readout = n_readout;
+  d.n_bundles = sp.n_bundles; d.n_live = sp.n_live; d.n_cprod = n_cprod; d.n_back = sp.n_back;
+  d.n_fill = sp.n_fill; d.n_init = sp.n_init;
+  d.off_back = sp.off_back; d.off_fill = sp.off_fill; d.off_init = sp.off_init; d.off_ptile = sp.off_ptile;
+  d.ptiles = mp->d_ptiles;
   d.n_res = n_res; d.spill = n_res < sp.n_live ? mp->d_spill : nullptr;
   d.tfrag = nullptr;
   if (a->n_pair_tables <= FRAG_TABLES) {
@@ -947,16 +1152,34 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
         return fail(MLBP_EHIP, "fragment scratch allocation failed");
     }
     d.tfrag = mp->d_tfrag;
-    hipLaunchKernelGGL(table_fragments_kernel, dim3(a->n_pair_tables * 2), dim3(WG), 0, st, a->pair_tables, mp->d_tfrag);
   }
-  int e = d.spill ? (ntab == 2 ? launch<2, true>(d, lds, st) : launch<1, true>(d, lds, st))
-                  : (ntab == 2 ? launch<2, false>(d, lds, st) : launch<1, false>(d, lds, st));
+  {
+    // one launch in front of the sweeps: constant products as tiles, the per-graph flags (cleared or raised), table fragments
+    PrepareDev q;
+    q.pair_tables = a->pair_tables; q.tfrag = d.tfrag ? mp->d_tfrag : nullptr; q.n_frag_tables = d.tfrag ? a->n_pair_tables : 0;
+    q.unary_tables = a->unary_tables; q.unary_tab = a->unary_tab; q.ent = prog->d_simage + sp.off_ent;
+    q.ptiles = mp->d_ptiles; q.bail = mp->d_bail; q.status = prog->d_status;
+    q.B = a->B; q.U = prog->U; q.n_unary_tables = a->n_unary_tables; q.E = sp.n_cpw / 4; q.n_cprod = n_cprod; q.n_groups = n_groups;
+    hipLaunchKernelGGL(shared_prepare_kernel, dim3((a->B + PGB - 1) / PGB), dim3(PWG), 0, st, q);
+    if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
+  }
+  const bool wide = sp.max_sources > 2;
+#ifdef MLBP_STAMPS      // the diagnostic build instantiates the all-resident two-source kernels only
+  if (d.spill || wide) return fail(MLBP_EUNSUPPORTED, "stamps build: no spilling / wide instance");
+  int e = ntab == 2 ? launch<2, false, false>(d, lds, st) : launch<1, false, false>(d, lds, st);
+#else
+  int e;
+  if (wide) e = d.spill ? (ntab == 2 ? launch<2, true, true>(d, lds, st) : launch<1, true, true>(d, lds, st))
+                        : (ntab == 2 ? launch<2, false, true>(d, lds, st) : launch<1, false, true>(d, lds, st));
+  else e = d.spill ? (ntab == 2 ? launch<2, true, false>(d, lds, st) : launch<1, true, false>(d, lds, st))
+                   : (ntab == 2 ? launch<2, false, false>(d, lds, st) : launch<1, false, false>(d, lds, st));
+#endif
   if (e) return e;
   if (d.msgs && !d.vf_only && sp.n_cpw > 0) {
     const int E = sp.n_cpw / 4;
     const long long rows = (long long)a->B * E;
     hipLaunchKernelGGL(unary_writeback_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(WG), 0, st, a->unary_tables, a->unary_tab,
-                       prog->d_simage + sp.n_ops * 8 + sp.n_lists, E, a->B, prog->U, a->n_unary_tables, prog->n_msgs, a->msgs);
+                       prog->d_simage + sp.off_ent, E, a->B, prog->U, a->n_unary_tables, prog->n_msgs, a->msgs);
     if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "unary write-back launch failed");
   }
   *launched = true;

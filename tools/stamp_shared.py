@@ -41,14 +41,14 @@ if '--shared-unary' in sys.argv:      # the trainer's layout: every unary table 
 else:
     fb.set_unary_tables(torch.rand(B * topo.U, X, dtype=torch.float64, device=dev) + 0.01)
 marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)
-names = ['A: indices/image/init', 'B: table fragment loads issued', 'C: unary -> products + barrier', 'loop: tile reads + products',
-         'loop: mfma + store', 'loop: barrier', 'epilogue', 'loop: column sum + v->f stores']
-ABL = ['unary write-back stores', 'transposed tile writes', 'wave_sum', 'unary loads', 'v->f stores', 'column_sum', 'mfma',
-       'second source tiles']
+names = ['A: tables, bundles, product tiles', 'C: partition choice, fragment loads, barriers', 'loop: quarters: tile reads + products',
+         'loop: totals of the product, result store, column sum', 'loop: waiting at the barrier (incl. bundles this wave sits out)', 'epilogue',
+         'loop: bundle decode + source totals -> scale', 'loop: quarters: MFMA issue (4 dependent per quarter)']
 KEEP = '--no-writeback' not in sys.argv
-masks = [0] + [1 << i for i in range(8)] if '--ablate' in sys.argv else [0]
-for mask in masks:
-    buf = torch.zeros(64 * 8, dtype=torch.int64, device=dev)
+for mask, what in ((0, 'nothing removed'), (1, 'WITHOUT the MFMAs'), (2, 'WITHOUT the tile reads'), (3, 'WITHOUT MFMAs and tile reads'), (4, 'WITHOUT the result stores'), (8, 'prepare kernel WITHOUT its row loads'), (16, 'prepare kernel WITHOUT its copy-out'), (24, 'prepare kernel WITHOUT both')):
+    if mask and '--ablate' not in sys.argv:
+        break
+    buf = torch.zeros(64 * 8 * 8, dtype=torch.int64, device=dev)
     assert ffi.lib.mlbp_debug_set_shared_stamp_buffer(buf.data_ptr(), mask) == 0
     for _ in range(3):
         fb.sweep(roots, init=True, marginals=marg, keep_messages=KEEP)
@@ -61,9 +61,11 @@ for mask in masks:
     assert ffi.lib.mlbp_last_sweep_kernel() == 3
     if mask == 0:
         print(ffi.lib.mlbp_last_error().decode())
-    t = buf.cpu().numpy().reshape(64, 8).astype(float)
-    tot = t.sum(1).mean()
-    what = 'nothing removed' if mask == 0 else 'WITHOUT ' + ABL[mask.bit_length() - 1]
+    t = buf.cpu().numpy().reshape(64, 8, 8).astype(float)          # [workgroup][wave][phase]
     us = s.elapsed_time(e) / 5 * 1e3
-    print('B=%d %s: %.1f us per launch (stamped build); ticks per workgroup %.0f (min %.0f, max %.0f) = %.2f ticks per ns of the launch' % (B, what, us, tot, t.sum(1).min(), t.sum(1).max(), tot / (us * 1e3)))
-    print('   ' + '  '.join('%s %.0f' % (n.split(':')[0] if i < 3 else n[6:], t[:, i].mean()) for i, n in enumerate(names)))
+    tot = t.sum(2)
+    print('B=%d %s: %.1f us per launch sequence (stamped build); ticks per wave lifetime: mean %.0f, min %.0f, max %.0f = %.2f ticks per ns of the sequence'
+          % (B, what, us, tot.mean(), tot.min(), tot.max(), tot.mean() / (us * 1e3)))
+    for w in range(8):
+        print('  wave %d (half %d, rows %2d..): ' % (w, w >> 2, 16 * (w & 3)) + '  '.join('%.0f' % t[:, w, i].mean() for i in range(8)))
+print('  phases: ' + ' | '.join(names))

@@ -352,6 +352,9 @@ typedef struct mlbp_gradient_args {
   const double* unary_expect;   /* optional [n_unary_tables][8] from mlbp_unary_expectations_f64: with
                                    MLBP_GRADIENT_SHARED_PAIR_TABLES the unary factors then cost one
                                    gather per factor instead of a reduction over the states           */
+  const int32_t* pair_slots_host; /* HOST int32 [3][P] or NULL: the contents of pair_c_slot | pair_r_slot | pair_phi.  The X >= 128
+                                   path walks the factors on the host; given this copy it only enqueues (and can be captured
+                                   into a HIP graph), without it the call reads the three device arrays back and synchronises */
 } mlbp_gradient_args;
 /* flags: pair_tab[b][p] is the same for every graph b (see MLBP_SWEEP_SHARED_PAIR_TABLES).  With X = 64,
  * F_ee = 3 and the planar feature copies given, the pairwise factors of 16 graphs at a time are then

@@ -13,7 +13,7 @@ runs ALL sweeps in one fused launch; `graph.messages` is a lazy dict view over t
 There is no CPU fallback.
 """
 import ctypes as C
-import zlib
+import hashlib
 import random
 import sys
 import time
@@ -99,11 +99,12 @@ class _Engine:
 
     # ---- tables: the reference reads PotentialTable.table afresh on every update, so edits made between two calls
     #      must be seen -- but re-sending every table for one message update is O(P X^2) bytes over PCIe.  The device
-    #      copies are kept; each call fingerprints the host arrays (address, shape, CRC of the bytes) and re-sends
+    #      copies are kept; each call fingerprints the host arrays (shape and a 128-bit BLAKE2 digest of the bytes) and re-sends
     #      only the tables that changed.  An unchanged graph moves no table bytes at all.
     @staticmethod
     def _fingerprint(arr):
-        return (arr.ctypes.data, arr.shape, zlib.crc32(arr))
+        # content only: an in-place edit keeps the address, and a converted copy's address means nothing
+        return (arr.shape, hashlib.blake2b(arr, digest_size=16).digest())
 
     def upload_tables(self):
         t, X = self.topo, self.X
@@ -286,14 +287,15 @@ class FactorGraph():
         return '\n'.join(rows)
 
     def add_factor(self, fac):
-        """LBP.py:145-153."""
-        if __debug__: assert fac not in self.factors
-        self.factors.append(fac)
+        """LBP.py:145-153: the factor joins the list; variables it brings are registered by id, first come first kept."""
+        if __debug__:
+            assert fac not in self.factors
         fac.graph = self
-        for v in fac.varset:
-            if v.id not in self.variables:
-                self.variables[v.id] = v
-                v.graph = self
+        self.factors.append(fac)
+        newcomers = [v for v in fac.varset if v.id not in self.variables]
+        for v in newcomers:
+            v.graph = self
+            self.variables.setdefault(v.id, v)
 
     def _topology(self):
         if self._engine is None:
@@ -390,16 +392,12 @@ class FactorGraph():
 
     def get_unregularized_gradeint(self):
         """LBP.py:301-320 -> (grad_en_en, grad_en_de)."""
-        grad_en_de = np.zeros_like(self.theta_en_de, dtype=DTYPE)
-        grad_en_en = np.zeros_like(self.theta_en_en, dtype=DTYPE)
+        total = {'en_en': np.zeros_like(self.theta_en_en, dtype=DTYPE), 'en_de': np.zeros_like(self.theta_en_de, dtype=DTYPE)}
         for f in self.factors:
-            if f.factor_type == 'en_en':
-                grad_en_en += f.get_gradient()
-            elif f.factor_type == 'en_de':
-                grad_en_de += f.get_gradient()
-            else:
+            if f.factor_type not in total:
                 raise BaseException('only 2 kinds of factors allowed...')
-        return grad_en_en, grad_en_de
+            total[f.factor_type] += f.get_gradient()
+        return total['en_en'], total['en_de']
 
     def return_gradient(self):
         """LBP.py:322-327 -> (g_en_en, g_en_de) scaled by the learning rate."""
@@ -408,9 +406,9 @@ class FactorGraph():
 
     def update_theta(self):
         """LBP.py:329-333."""
-        grad_en_de, grad_en_en = self.get_gradient()
-        self.theta_en_en += (self.learning_rate * grad_en_en)
-        self.theta_en_de += (self.learning_rate * grad_en_de)
+        step_en_en, step_en_de = self.return_gradient()          # learning rate x regularised gradient
+        np.add(self.theta_en_en, step_en_en, out=self.theta_en_en)      # in place: callers hold references to theta
+        np.add(self.theta_en_de, step_en_de, out=self.theta_en_de)
         return self.theta_en_en, self.theta_en_de
 
 
@@ -513,18 +511,19 @@ class FactorNode():
 
     def add_varset_with_potentials(self, varset, ptable):
         """LBP.py:441-454."""
-        if __debug__: assert isinstance(ptable, PotentialTable)
-        if len(varset) == 2:
-            if __debug__: assert varset[0] != varset[1]
-        if __debug__: assert len(varset) == len(ptable.var_id2dim)
-        if len(varset) > 2:
+        arity = len(varset)
+        if __debug__:
+            assert isinstance(ptable, PotentialTable) and arity == len(ptable.var_id2dim)
+            assert arity != 2 or varset[0] != varset[1]
+        if arity > 2:
             raise NotImplementedError("Currently supporting unary and pairwise factors...")
         for v in varset:
-            if __debug__: assert v not in self.varset
-            self.varset.append(v)
+            if __debug__:
+                assert v not in self.varset
             v.add_factor(self)
-        ptable.add_factor(self)
+            self.varset.append(v)
         self.potential_table = ptable
+        ptable.add_factor(self)
 
     def _graph_level(self, prefix, distance_error, type_error):
         """Which graph-level array this factor uses: en_en by word distance (gap > 1 / gap == 1),
@@ -571,15 +570,13 @@ class FactorNode():
             kind = _ffi.OP_PAIR_TM if o_var_dim == 1 else _ffi.OP_PAIR_MT
             e.run_op((kind, int(e.topo.pair_slot[e.topo.factor_index[self.id]]), e.slot[str(o_var), str(self)], dst))
             return
-        msg = self.graph.messages[str(o_var), str(self)]
-        if o_var_dim == 1:
-            marginalized = au.sparse_vec_mat_dot(msg.m, self.potential_table.table)
-        else:
-            marginalized = au.sparse_vec_mat_dot(msg.m.T, self.potential_table.table)
-        new_m = Message(marginalized)
+        # top-K form (LBP.py:506-507, 515-516): the other variable on axis 1 -> column vector against the table's columns,
+        # on axis 0 -> row vector against its rows
+        incoming = self.graph.messages[str(o_var), str(self)].m
+        out = Message(au.sparse_vec_mat_dot(incoming if o_var_dim == 1 else incoming.T, self.potential_table.table))
         if self.graph.normalize_messages:
-            new_m.renormalize()
-        self.graph.messages[str(self), str(var)] = new_m
+            out.renormalize()
+        self.graph.messages[str(self), str(var)] = out
 
     def get_factor_beliefs(self):
         """LBP.py:528-574."""
@@ -658,21 +655,16 @@ class ObservedFactor(FactorNode):
     """LBP.py:630-634."""
 
     def __init__(self, id, observed_domain_type, observed_value):
-        FactorNode.__init__(self, id, factor_type=UNARY_FACTOR)
-        self.observed_domain_type = observed_domain_type
-        self.observed_value = observed_value
+        super().__init__(id, factor_type=UNARY_FACTOR, observed_domain_type=observed_domain_type, observed_value=observed_value)
 
 
 class Message():
     """LBP.py:637-667: an (X,1) float64 column."""
 
     def __init__(self, m):
-        if __debug__: assert isinstance(m, np.ndarray)
-        if __debug__: assert np.size(m[m < 0.0]) == 0
-        if np.shape(m) != (np.size(m), 1):
-            self.m = np.reshape(m, (np.size(m), 1))
-        else:
-            self.m = m
+        if __debug__:
+            assert isinstance(m, np.ndarray) and not (m < 0.0).any()
+        self.m = m if m.shape == (m.size, 1) else m.reshape(m.size, 1)      # anything becomes a column (LBP.py:641-644)
 
     def __str__(self):
         return np.array_str(self.m)
@@ -690,11 +682,7 @@ class Message():
 
     @staticmethod
     def new_message(domain, init):
-        m = np.empty((len(domain), 1))
-        m.fill(init)
-        if m.dtype != DTYPE:
-            m = m.astype(DTYPE)
-        return Message(m)
+        return Message(np.full((len(domain), 1), init, dtype=DTYPE))
 
 
 class PotentialTable():
@@ -748,16 +736,12 @@ class PhiWrapper:
     """LBP.py:732-736."""
 
     def __init__(self, phi_en_en, phi_en_en_w1, phi_en_de):
-        self.phi_en_en = phi_en_en
-        self.phi_en_en_w1 = phi_en_en_w1
-        self.phi_en_de = phi_en_de
+        self.phi_en_en, self.phi_en_en_w1, self.phi_en_de = phi_en_en, phi_en_en_w1, phi_en_de
 
 
 class ThetaWrapper(object):
     """LBP.py:739-745."""
 
     def __init__(self, theta_en_en_names, theta_en_en, theta_en_de_names, theta_en_de):
-        self.theta_en_en_names = theta_en_en_names
-        self.theta_en_de_names = theta_en_de_names
-        self.theta_en_en = theta_en_en
-        self.theta_en_de = theta_en_de
+        self.theta_en_en_names, self.theta_en_en = theta_en_en_names, theta_en_en
+        self.theta_en_de_names, self.theta_en_de = theta_en_de_names, theta_en_de

@@ -37,7 +37,8 @@ class GradientArgs(C.Structure):
                 ('unary_label', C.c_void_p), ('phi_en_en', C.c_void_p), ('phi_en_en_w1', C.c_void_p),
                 ('phi_en_de', C.c_void_p), ('phi_en_en_t', C.c_void_p), ('phi_en_en_w1_t', C.c_void_p),
                 ('phi_en_de_t', C.c_void_p), ('phi_en_en_p', C.c_void_p), ('phi_en_en_w1_p', C.c_void_p),
-                ('grad_en_en', C.c_void_p), ('grad_en_de', C.c_void_p), ('flags', C.c_int32), ('pair_tab_host', C.c_void_p), ('unary_expect', C.c_void_p)]
+                ('grad_en_en', C.c_void_p), ('grad_en_de', C.c_void_p), ('flags', C.c_int32), ('pair_tab_host', C.c_void_p), ('unary_expect', C.c_void_p),
+                ('pair_slots_host', C.c_void_p)]
 
 
 class PotentialsJob(C.Structure):

@@ -404,6 +404,10 @@ class FactorGraphBatch:
             a.flags |= _ffi.GRADIENT_SHARED_PAIR_TABLES
             if getattr(self, '_pair_row_host', None) is not None:
                 a.pair_tab_host = self._pair_row_host.ctypes.data
+                if not hasattr(self, '_pair_slots_host'):      # host copy of the slot arrays: the X >= 128 gradient then only enqueues
+                    self._pair_slots_host = np.ascontiguousarray(np.concatenate([
+                        c.cpu().numpy(), r.cpu().numpy(), self._pair_phi.cpu().numpy()]).astype(np.int32))
+                a.pair_slots_host = self._pair_slots_host.ctypes.data
             self._derive_unary_rows()
             if getattr(self, '_row_kind', None) is not None and self._row_kind is not False and F_ee == 3 and F_ed == 6:
                 _ffi.check(_ffi.lib.mlbp_unary_expectations_f64(

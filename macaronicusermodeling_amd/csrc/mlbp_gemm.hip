@@ -516,11 +516,15 @@ int launch_gemm_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void
   double* W = (double*)scratch; double* Y = W + (size_t)X * X; double* S = Y + (size_t)B * X;
   // slots come from DEVICE arrays in the ABI (pair_c_slot / pair_r_slot / pair_phi): fetch the few ints once
   int32_t h_c[16], h_r[16], h_phi[16];
-  if (hipMemcpyAsync(h_c, a->pair_c_slot, sizeof(int32_t) * a->P, hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipMemcpyAsync(h_r, a->pair_r_slot, sizeof(int32_t) * a->P, hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipMemcpyAsync(h_phi, a->pair_phi, sizeof(int32_t) * a->P, hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipStreamSynchronize(st) != hipSuccess)
+  if (a->P > 16) return fail(MLBP_EUNSUPPORTED, "shared-table gradient: at most 16 pairwise factors (got %d)", a->P);
+  if (a->pair_slots_host) {                       // the caller's host copy: nothing to read back, the call only enqueues
+    for (int p = 0; p < a->P; ++p) { h_c[p] = a->pair_slots_host[p]; h_r[p] = a->pair_slots_host[a->P + p]; h_phi[p] = a->pair_slots_host[2 * a->P + p]; }
+  } else if (hipMemcpyAsync(h_c, a->pair_c_slot, sizeof(int32_t) * a->P, hipMemcpyDeviceToHost, st) != hipSuccess ||
+             hipMemcpyAsync(h_r, a->pair_r_slot, sizeof(int32_t) * a->P, hipMemcpyDeviceToHost, st) != hipSuccess ||
+             hipMemcpyAsync(h_phi, a->pair_phi, sizeof(int32_t) * a->P, hipMemcpyDeviceToHost, st) != hipSuccess ||
+             hipStreamSynchronize(st) != hipSuccess) {
     return fail(MLBP_EHIP, "shared-table gradient: reading the slot tables failed");
+  }
   for (int p = 0; p < a->P; ++p) {
     if ((unsigned)h_c[p] >= (unsigned)a->n_msgs || (unsigned)h_r[p] >= (unsigned)a->n_msgs ||
         (unsigned)a->pair_tab_host[p] >= (unsigned)a->n_pair_tables)

@@ -124,9 +124,14 @@ def instance_shape(ti, en2id, de2id):
     for ig in ti['past_guesses_for_current_sent']:                       # train_mp.py:208-212
         if not ig['revealed']:
             planes['hit_history'].append((en2id[ig['guess']], de2id[ig['l2_word']], -1.0))
+    # what the prediction text needs beside the numbers (LBP.py:109-143): per position the word a line starts with -- the l2
+    # word under a predicted variable (FactorNode.word_label, train_mp.py:264), the label of a given one (train_mp.py:298) --
+    # and a predicted variable's truth (SimpleNode.l1_parent, train_mp.py:108, 128)
+    words = [n['l2_word'] if i in predicted else None for i, n in enumerate(sent)]
+    truth = [n['l1_parent'] if i in predicted else None for i, n in enumerate(sent)]
     return (len(sent), tuple(predicted)), dict(label=label, de_obs=de_obs, planes=planes,
-                                               sent_id=sent[0]['sent_id'], user_id=ti['user_id'],
-                                               n_seen=len(ti['past_sentences_seen']))
+                                               sent_id=ti['current_sent'][0]['sent_id'], user_id=ti['user_id'],
+                                               n_seen=len(ti['past_sentences_seen']), words=words, truth=truth)
 
 
 def shape_spec(sent_len, predicted, X, Vde, name=None):
@@ -161,8 +166,9 @@ def bucket_instances(instances, en_domain, de_domain):
     en2id = {w: i for i, w in enumerate(en_domain)}
     de2id = {w: i for i, w in enumerate(de_domain)}
     buckets = {}
-    for ti in instances:
+    for index, ti in enumerate(instances):
         key, rec = instance_shape(ti, en2id, de2id)
+        rec['index'] = index                                             # position in the list handed in (file order)
         if not key[1]:
             continue
         b = buckets.setdefault(key, dict(spec=shape_spec(key[0], key[1], len(en_domain), len(de_domain)), rows=[]))
@@ -221,6 +227,26 @@ def prediction_block(sent_id, fg):
     """The text batch_predictions emits per instance (train_mp.py:337): '*SENT_ID:<id>' then the lines
     of FactorGraph.to_string() (LBP.py:109-123) -- what eval.py / get_acc.py parse."""
     return '\n'.join(['*SENT_ID:' + str(sent_id)] + fg.to_string())
+
+
+def prediction_text(row, predicted, en_domain, top_idx, top_logs, label_logs, log_marginals):
+    """The two texts `batch_predictions` returns for one instance (train_mp.py:337-338) from batched read-outs instead of a
+    FactorGraph: ('*SENT_ID:' block = FactorGraph.to_string, LBP.py:109-123; .dist lines = to_dist, LBP.py:125-143).
+    row: the instance record of bucket_instances; predicted: its predicted positions (= variable order of the batch);
+    top_idx / top_logs [n_pred][top]: words of get_max_vocab(50) in descending probability and their log-probabilities;
+    label_logs [n_pred]: log p(user's guess); log_marginals [n_pred][X]."""
+    lines, dist = ['*SENT_ID:' + str(row['sent_id'])], []
+    for pos in range(len(row['label'])):
+        if pos in predicted:
+            v = predicted.index(pos)
+            guess = en_domain[row['label'][pos]]
+            pred = ' '.join('%s %0.4f' % (en_domain[int(i)], l) for i, l in zip(top_idx[v], top_logs[v]))
+            lines.append(' '.join([row['words'][pos], guess, '%0.4f' % label_logs[v], pred]))
+            truth = row['truth'][pos] if row['truth'][pos] is not None else 'None'
+            dist.append(' ||| '.join([truth, guess, ' '.join('%0.6f' % x for x in log_marginals[v])]))
+        else:
+            lines.append(' '.join(['', en_domain[row['label'][pos]], '']))          # a given word: its en_en factors' label
+    return '\n'.join(lines), '\n'.join(dist)
 
 
 # ---- synthetic TI_DIR ---------------------------------------------------------------------------------

@@ -30,7 +30,7 @@ from .topology import GraphTopology
 class UserGraphTrainer:
     def __init__(self, spec, var_labels, unary_obs, phi_en_en, phi_en_en_w1, phi_en_de, theta_en_en, theta_en_de,
                  device='cuda:0', sweeps=3, roots=None, planes=None, domains=None, theta_dom_en_en=None,
-                 theta_dom_en_de=None, skip_unchanged=True):
+                 theta_dom_en_de=None, skip_unchanged=False):
         """spec: a 'trainmp'-style spec (tests/golden/cases.py: factors carry factor_type / gap);
         var_labels [B][n_vars], unary_obs [B][U]: this rank's shard of instances.
         planes: optional per-instance sparse feature planes, a list (one entry per instance) of
@@ -40,9 +40,10 @@ class UserGraphTrainer:
         (train_mp.py:162-171, 226-247): instance i builds its potentials from theta_dom[domains[i]] INSTEAD of the
         global theta; the global theta still receives every instance's step.  Instances of one domain should be
         contiguous (groups of 16 consecutive graphs that share their tables run on the matrix cores).
-        skip_unchanged (default on): the sweeps drop the updates of the root sequence that would recompute a message from
-        unchanged inputs (MLBP_SWEEP_SKIP_UNCHANGED, include/mlbp.h) -- a third of a three-root user graph's contractions;
-        statistics equal the full schedule's to rounding (tests/test_gpu_gradient.py)."""
+        skip_unchanged (off by default, like the C ABI: the default executes every update of the reference's schedule): the
+        sweeps drop the updates of the root sequence that would recompute a message from unchanged inputs
+        (MLBP_SWEEP_SKIP_UNCHANGED, include/mlbp.h) -- a third of a three-root user graph's contractions; statistics equal
+        the full schedule's to rounding (tests/test_gpu_gradient.py)."""
         self.spec = spec
         self.topo = topo = GraphTopology.from_spec(spec)
         by_id = {f['id']: f for f in spec['factors']}
@@ -267,7 +268,7 @@ class UserGraphTrainer:
                                 self.F_ee, self.F_ed, learning_rate, reg_param * reg_param_ua_scale)
         return float(stats[n_stat - 2].item() / stats[n_stat - 1].item()), self.theta_en_en, self.theta_en_de
 
-    def predict(self, top=50):
+    def predict(self, top=50, with_logs=False):
         """batch_predictions for the shard (train_mp.py:310-343): runs inference and returns
         (log-posterior per instance [B] (host), top-`top` word indices per predicted variable
         [B][n_vars][top] in descending probability (device top-K), their log-probabilities, and the
@@ -291,6 +292,9 @@ class UserGraphTrainer:
         hit = idx_h[:, ed_vars, :] == labels[:, ed_vars, None]
         rank = np.where(hit.any(-1), hit.argmax(-1), 10 ** 6)
         counts = (int((rank == 0).sum()), int((rank < 26).sum()), int((rank < 51).sum()), int(rank.size))
+        if with_logs:       # + every variable's log-marginal vector and the log-probability of the user's label (the text formats)
+            logm_h = logm.cpu().numpy()
+            return self._lp.cpu().numpy(), idx_h, logs, counts, logm_h, np.take_along_axis(logm_h, labels[:, :, None], axis=2)[:, :, 0]
         return self._lp.cpu().numpy(), idx_h, logs, counts
 
 
@@ -313,33 +317,102 @@ def apply_domain_update(theta_dom_en_en, theta_dom_en_de, stats_dom, F_ee, F_ed,
     return theta_dom_en_en, theta_dom_en_de
 
 
+class _BucketSet:
+    """The bucket trainers (one UserGraphTrainer per sentence shape) of a list of instances, sharing the owner's thetas."""
+
+    def __init__(self, owner, instances):
+        from . import tidir
+        self.buckets = tidir.bucket_instances(instances, owner.en, owner.de)
+        self.trainers = {}
+        o = owner
+        dom_of = (lambda r: str(r['user_id'])) if o.adapt == 'user' else (lambda r: str(r['n_seen']))
+        dom_index = {d: i for i, d in enumerate(o.domains)}
+        for key, b in sorted(self.buckets.items()):
+            roots = [key[1][i % len(key[1])] for i in range(o.sweeps)]
+            extra = {}
+            if o.adapt:   # group the bucket's instances by domain: groups of 16 graphs then share their tables
+                dom = np.array([dom_index[dom_of(r)] for r in b['rows']], dtype=np.int64)
+                order = np.argsort(dom, kind='stable')
+                b['rows'] = [b['rows'][i] for i in order]
+                b['var_labels'], b['unary_obs'] = b['var_labels'][order], b['unary_obs'][order]
+                extra = dict(domains=dom[order], theta_dom_en_en=o.theta_dom_en_en, theta_dom_en_de=o.theta_dom_en_de)
+            planes = None
+            if o.use_planes:
+                planes = []
+                for r in b['rows']:
+                    cells = {}
+                    for name, k in o.plane_features.items():
+                        for i, j, v in r['planes'][name]:
+                            cells[(i, j, k)] = cells.get((i, j, k), 0.0) + v      # the reference accumulates (+=)
+                    planes.append(cells)
+            self.trainers[key] = UserGraphTrainer(b['spec'], b['var_labels'], b['unary_obs'], o.phi_ee, o.phi_w1, o.phi_ed_t,
+                                                  o.theta_en_en, o.theta_en_de, device=o.device, sweeps=o.sweeps, roots=roots,
+                                                  planes=planes, skip_unchanged=o.skip_unchanged, **extra)
+
+    def statistics_into(self, stats, grouped_sweeps):
+        """Adds the buckets' statistics to `stats`.  grouped_sweeps: the sweeps of ALL sentence shapes in one launch
+        (batch.sweep_groups -> mlbp_sweep_groups_f64: every bucket its own topology and roots) instead of one
+        launch sequence per bucket -- what a minibatch of many small buckets wants; large buckets are better off on
+        their own shared-table launches (the default 'auto' switches at 1024 instances per bucket on average)."""
+        trs = list(self.trainers.values())
+        if not trs:
+            return
+        n_inst = sum(tr.batch.B for tr in trs)
+        grouped = grouped_sweeps is True or (grouped_sweeps == 'auto' and len(trs) > 1 and n_inst < 1024 * len(trs))
+        grouped = grouped and all(tr.topo.P >= 1 and tr.batch.X == 64 for tr in trs)
+        if not grouped:
+            for tr in trs:
+                stats += tr.local_statistics()
+            return
+        from .batch import sweep_groups
+        for tr in trs:
+            tr.build_potentials()
+        sweep_groups([tr.batch for tr in trs], [tr.roots[:tr.n_sweeps_run] for tr in trs], init=True,
+                     marginals=[tr._marg for tr in trs])
+        for tr in trs:
+            stats += tr._statistics_after_sweep(gradient_from_messages=True)
+
+
 class TiDirTrainer:
     """The outer loop of train_mp.py's __main__ (train_mp.py:560-690) over files in the reference's
     formats: vocabularies, feature matrices, JSON training instances -> one UserGraphTrainer per
-    sentence shape sharing theta; per epoch one fused statistics buffer, one all-reduce, one update;
-    params written in the reference's text format."""
+    sentence shape sharing theta; one fused statistics buffer, one all-reduce and one update per epoch -- or, with
+    `minibatch`, per minibatch of a shuffled epoch (the reference updates once per instance, train_mp.py:631-649 + 405-424:
+    minibatch=1 in the limit); params written in the reference's text format, read back for a resumed run, predictions
+    written in the reference's two text formats."""
 
     def __init__(self, ti_path, en_vocab, de_vocab, phi_pmi, phi_pmi_w1, phi_ed, phi_ped, device='cuda:0', sweeps=3,
                  rank=0, world=1, use_planes=True, adapt=None, domains=None, reg_param_ua_scale=1.0,
-                 use_correct_feat=True, history=True, session_history=True, grouped_sweeps='auto', skip_unchanged=True):
+                 use_correct_feat=True, history=True, session_history=True, grouped_sweeps='auto', skip_unchanged=False,
+                 minibatch=None, shuffle_seed=None, load_params=None):
         """use_planes switches the three per-instance feature planes on as a whole; use_correct_feat / history /
         session_history gate them one by one as the reference's options of the same names do (train_mp.py:178, 192,
         206: the 'correct', 'full_history' and 'hit_history' planes).
         adapt: None, 'user' (--user_adapt: domain = ti.user_id) or 'experience' (--experience_adapt: domain =
         len(ti.past_sentences_seen)), train_mp.py:162-171; `domains`: the domain names in file order (the
-        reference reads <ti>.users / <ti>.experience, train_mp.py:504-516) -- default: the names that occur."""
+        reference reads <ti>.users / <ti>.experience, train_mp.py:504-516) -- default: the names that occur.
+        minibatch: instances per update (None = the whole file: one update per epoch).  Every epoch walks the instances in
+        a shuffled order (`random.shuffle(training_instances)`, train_mp.py:631) -- a permutation seeded by (shuffle_seed,
+        epoch), the same on every rank; shuffle_seed=None keeps the file order -- and cuts it into minibatches; a minibatch is
+        sharded contiguously over the ranks, its statistics all-reduced once, theta updated once.
+        load_params: a params file (tidir.save_params / the reference's save_params) to start from instead of zeros
+        (--load_params, train_mp.py:528-542: the adapt mode's extension is tried first, then the bare name).
+        skip_unchanged: the sweeps drop updates that would recompute a message from unchanged inputs (include/mlbp.h
+        MLBP_SWEEP_SKIP_UNCHANGED; equal to the full schedule to rounding, off by default like the C ABI)."""
         from . import tidir
         if adapt not in (None, 'user', 'experience'):
             raise ValueError("adapt is None, 'user' or 'experience'")
         self.adapt, self.reg_param_ua_scale = adapt, float(reg_param_ua_scale)
-        self.grouped_sweeps = grouped_sweeps
+        self.grouped_sweeps, self.sweeps, self.skip_unchanged = grouped_sweeps, int(sweeps), bool(skip_unchanged)
+        self.rank, self.world = int(rank), int(world)
+        self.device = dev = torch.device(device)
         self.en, self.de = tidir.read_vocab(en_vocab), tidir.read_vocab(de_vocab)
-        phi_ee, phi_w1, phi_ed_t = tidir.load_features(phi_pmi, phi_pmi_w1, phi_ed, phi_ped)
-        instances = tidir.read_instances(ti_path)
-        self.n_total = len(instances)
-        lo, hi = mdist.shard_range(len(instances), rank, world)
-        self.buckets = tidir.bucket_instances(instances[lo:hi], self.en, self.de)
-        dev = torch.device(device)
+        self.phi_ee, self.phi_w1, self.phi_ed_t = tidir.load_features(phi_pmi, phi_pmi_w1, phi_ed, phi_ped)
+        self.instances = tidir.read_instances(ti_path)
+        self.n_total = len(self.instances)
+        self.use_planes = bool(use_planes)
+        self.plane_features = {name: tidir.ED_NAMES.index(name)
+                               for name, on in (('correct', use_correct_feat), ('full_history', history), ('hit_history', session_history)) if on}
         self.theta_en_en = torch.zeros(len(tidir.EE_NAMES), dtype=torch.float64, device=dev)   # train_mp.py:519-523
         self.theta_en_de = torch.zeros(len(tidir.ED_NAMES), dtype=torch.float64, device=dev)
         dom_of = (lambda r: str(r['user_id'])) if adapt == 'user' else (lambda r: str(r['n_seen']))
@@ -347,37 +420,43 @@ class TiDirTrainer:
         if adapt:       # every rank needs the same list: it comes from ALL instances, not only this rank's shard
             if domains is None:
                 en2id, de2id = {w: i for i, w in enumerate(self.en)}, {w: i for i, w in enumerate(self.de)}
-                domains = sorted({dom_of(tidir.instance_shape(ti, en2id, de2id)[1]) for ti in instances})
+                domains = sorted({dom_of(tidir.instance_shape(ti, en2id, de2id)[1]) for ti in self.instances})
             self.domains = [str(d) for d in domains]
             self.theta_dom_en_en = torch.zeros(len(self.domains), len(tidir.EE_NAMES), dtype=torch.float64, device=dev)  # train_mp.py:524-527
             self.theta_dom_en_de = torch.zeros(len(self.domains), len(tidir.ED_NAMES), dtype=torch.float64, device=dev)
-        dom_index = {d: i for i, d in enumerate(self.domains)}
-        self.trainers = {}
-        for key, b in sorted(self.buckets.items()):
-            roots = [key[1][i % len(key[1])] for i in range(sweeps)]
-            extra = {}
-            if adapt:   # group the bucket's instances by domain: groups of 16 graphs then share their tables
-                dom = np.array([dom_index[dom_of(r)] for r in b['rows']], dtype=np.int64)
-                order = np.argsort(dom, kind='stable')
-                b['rows'] = [b['rows'][i] for i in order]
-                b['var_labels'], b['unary_obs'] = b['var_labels'][order], b['unary_obs'][order]
-                extra = dict(domains=dom[order], theta_dom_en_en=self.theta_dom_en_en, theta_dom_en_de=self.theta_dom_en_de)
-            planes = None
-            if use_planes:
-                feat = {name: tidir.ED_NAMES.index(name)
-                        for name, on in (('correct', use_correct_feat), ('full_history', history), ('hit_history', session_history)) if on}
-                planes = []
-                for r in b['rows']:
-                    cells = {}
-                    for name, k in feat.items():
-                        for i, j, v in r['planes'][name]:
-                            cells[(i, j, k)] = cells.get((i, j, k), 0.0) + v      # the reference accumulates (+=)
-                    planes.append(cells)
-            self.trainers[key] = UserGraphTrainer(b['spec'], b['var_labels'], b['unary_obs'], phi_ee, phi_w1, phi_ed_t,
-                                                  self.theta_en_en, self.theta_en_de, device=device, sweeps=sweeps, roots=roots,
-                                                  planes=planes, skip_unchanged=skip_unchanged, **extra)
+        if load_params:
+            self.load_params(load_params)
+        self.minibatch = None if minibatch is None else max(1, int(minibatch))
+        self.shuffle_seed = shuffle_seed
         self.n_stat = len(tidir.EE_NAMES) + len(tidir.ED_NAMES) + 2
         self.stats = torch.zeros(self.n_stat * (1 + len(self.domains)), dtype=torch.float64, device=dev)
+        self._epochs_done = 0
+        # the whole shard as one set of buckets: full-batch epochs and the prediction pass
+        lo, hi = mdist.shard_range(self.n_total, self.rank, self.world)
+        self._shard = (lo, hi)
+        self._full = _BucketSet(self, self.instances[lo:hi])
+        self.buckets, self.trainers = self._full.buckets, self._full.trainers
+        self._mini_sets = {}
+
+    # ---- parameters -----------------------------------------------------------------------------
+    def load_params(self, path):
+        """Starts from a params file (train_mp.py:528-542): '<path><ext>' with the adapt mode's extension first, then
+        '<path>'.  Global thetas, and every adapted domain's thetas the file holds for a domain this run knows."""
+        from . import tidir
+        ext = {'user': '.user_adapt', 'experience': '.exp_adapt', None: ''}[self.adapt]
+        import os
+        chosen = path + ext if os.path.exists(path + ext) else path
+        een, eet, edn, edt, d2t = tidir.read_params(chosen)
+        if list(een) != list(tidir.EE_NAMES) or list(edn) != list(tidir.ED_NAMES):
+            raise ValueError('params file %s names other features than this build' % chosen)
+        self.theta_en_en.copy_(torch.from_numpy(np.asarray(eet, dtype=np.float64).reshape(-1)))
+        self.theta_en_de.copy_(torch.from_numpy(np.asarray(edt, dtype=np.float64).reshape(-1)))
+        for i, d in enumerate(self.domains):
+            if ('en_en', d) in d2t:
+                self.theta_dom_en_en[i].copy_(torch.from_numpy(np.asarray(d2t['en_en', d], dtype=np.float64).reshape(-1)))
+            if ('en_de', d) in d2t:
+                self.theta_dom_en_de[i].copy_(torch.from_numpy(np.asarray(d2t['en_de', d], dtype=np.float64).reshape(-1)))
+        return chosen
 
     def domain_thetas(self):
         """{('en_en' | 'en_de', domain name): (1, F) array} as train_mp's domain2theta / the params file."""
@@ -387,38 +466,74 @@ class TiDirTrainer:
             d2t['en_de', d] = self.theta_dom_en_de[i].cpu().numpy().reshape(1, -1)
         return d2t
 
+    # ---- statistics -----------------------------------------------------------------------------
+    def capture(self):
+        """Records local_statistics() -- every bucket's potentials, sweeps (grouped or not), gradients and sums -- into one
+        HIP graph; later calls replay it.  theta is read from the same device tensors at every replay.  One eager pass
+        first: first-use allocations, attribute calls and the group table's upload must not be captured."""
+        self._graph = None
+        self._local_statistics_eager()
+        torch.cuda.synchronize(self.theta_en_en.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._local_statistics_eager()
+        self._graph = g
+        return self
+
     def local_statistics(self):
-        """Sum of the buckets' statistics.  grouped_sweeps: the sweeps of ALL sentence shapes in one launch
-        (batch.sweep_groups -> mlbp_sweep_groups_f64: every bucket its own topology and roots) instead of one
-        launch sequence per bucket -- what a minibatch of many small buckets wants; large buckets are better off on
-        their own shared-table launches (the default 'auto' switches at 1024 instances per bucket on average)."""
-        self.stats.zero_()
-        trs = list(self.trainers.values())
-        n_inst = sum(tr.batch.B for tr in trs)
-        grouped = self.grouped_sweeps is True or (self.grouped_sweeps == 'auto' and len(trs) > 1 and n_inst < 1024 * len(trs))
-        grouped = grouped and all(tr.topo.P >= 1 and tr.batch.X == 64 for tr in trs)
-        if not grouped:
-            for tr in trs:
-                self.stats += tr.local_statistics()
+        """Sum of this rank's buckets' statistics over its whole shard."""
+        if getattr(self, '_graph', None) is not None:
+            self._graph.replay()
             return self.stats
-        from .batch import sweep_groups
-        for tr in trs:
-            tr.build_potentials()
-        sweep_groups([tr.batch for tr in trs], [tr.roots[:tr.n_sweeps_run] for tr in trs], init=True,
-                     marginals=[tr._marg for tr in trs])
-        for tr in trs:
-            self.stats += tr._statistics_after_sweep(gradient_from_messages=True)
+        return self._local_statistics_eager()
+
+    def _local_statistics_eager(self, bucket_set=None):
+        self.stats.zero_()
+        (bucket_set or self._full).statistics_into(self.stats, self.grouped_sweeps)
         return self.stats
 
-    def epoch(self, learning_rate, reg_param):
-        self.local_statistics()
-        mdist.all_reduce_sum_(self.stats)                   # global and per-domain statistics in ONE reduction
+    def _update(self, learning_rate, reg_param):
+        """One all-reduce of the fused buffer (global and per-domain statistics), one update of every theta."""
+        mdist.all_reduce_sum_(self.stats)
         n, F_ee, F_ed = self.n_stat, len(self.theta_en_en), len(self.theta_en_de)
         apply_update(self.theta_en_en, self.theta_en_de, self.stats[:n], F_ee, F_ed, learning_rate, reg_param)
         if self.domains:
             apply_domain_update(self.theta_dom_en_en, self.theta_dom_en_de, self.stats[n:].view(len(self.domains), n), F_ee, F_ed,
                                 learning_rate, reg_param * self.reg_param_ua_scale)
-        return float(self.stats[n - 2].item() / max(self.stats[n - 1].item(), 1.0))
+        return float(self.stats[n - 2].item()), float(self.stats[n - 1].item())
+
+    def epoch_order(self, epoch):
+        """The order in which epoch `epoch` walks ALL instances (every rank computes the same one)."""
+        if self.shuffle_seed is None:
+            return np.arange(self.n_total)
+        return np.random.RandomState([int(self.shuffle_seed) & 0x7FFFFFFF, int(epoch)]).permutation(self.n_total)
+
+    def _minibatch_set(self, epoch, m, ids):
+        """The bucket trainers of this rank's share of one minibatch (built once per (order, minibatch): a fixed order reuses
+        them every epoch)."""
+        key = (epoch if self.shuffle_seed is not None else 0, m)
+        if key not in self._mini_sets:
+            if self.shuffle_seed is not None:
+                self._mini_sets = {k: v for k, v in self._mini_sets.items() if k[0] == key[0]}      # last epoch's sets go
+            lo, hi = mdist.shard_range(len(ids), self.rank, self.world)
+            self._mini_sets[key] = _BucketSet(self, [self.instances[int(i)] for i in ids[lo:hi]])
+        return self._mini_sets[key]
+
+    def epoch(self, learning_rate, reg_param):
+        """One pass over the instances; returns the mean log-posterior (at the thetas each instance was evaluated under)."""
+        epoch = self._epochs_done
+        self._epochs_done += 1
+        if self.minibatch is None:
+            self.local_statistics()
+            lp, n = self._update(learning_rate, reg_param)
+            return lp / max(n, 1.0)
+        order = self.epoch_order(epoch)
+        lp_sum, n_sum = 0.0, 0.0
+        for m, m0 in enumerate(range(0, self.n_total, self.minibatch)):
+            self._local_statistics_eager(self._minibatch_set(epoch, m, order[m0:m0 + self.minibatch]))
+            lp, n = self._update(learning_rate, reg_param)
+            lp_sum += lp; n_sum += n
+        return lp_sum / max(n_sum, 1.0)
 
     def train(self, epochs=3, reg_param=0.2, save_params=None):
         """lr = 0.1 / (1 + 0.3 epoch) (train_mp.py:627-630); regularisation reg_param / N (train_mp.py:160);
@@ -430,18 +545,40 @@ class TiDirTrainer:
         history = []
         for epoch in range(epochs):
             history.append(self.epoch(0.1 / (1.0 + 0.3 * epoch), float(reg_param) / float(self.n_total)))
-            if save_params:
+            if save_params and self.rank == 0:
                 tidir.save_params('%s.iter%d' % (save_params, epoch), self.theta_en_en.cpu().numpy().reshape(1, -1),
                                   self.theta_en_de.cpu().numpy().reshape(1, -1), d2t=self.domain_thetas())
-        if save_params:
+        if save_params and self.rank == 0:
             tidir.save_params(save_params, self.theta_en_en.cpu().numpy().reshape(1, -1),
                               self.theta_en_de.cpu().numpy().reshape(1, -1), d2t=self.domain_thetas())
         return history
 
-    def predict(self):
-        """-> (mean log-posterior, (p@0, p@25, p@50, total)) over this rank's instances (train_mp.py:666-684)."""
+    # ---- prediction pass (train_mp.py:310-343, 692-770) -------------------------------------------
+    def predict(self, save_predictions=None):
+        """-> (mean log-posterior, (p@0, p@25, p@50, total)) over ALL ranks' instances (train_mp.py:666-684: sums reduced once).
+        save_predictions: every rank writes its shard's '*SENT_ID:' blocks to '<path><ext>' and '.dist' lines to
+        '<path><ext>.dist' ('.rank<r>' appended when there are several ranks), one block per instance in file order, exactly
+        the text `batch_predictions` returns (train_mp.py:337-338, 752-757) -- formed from the batched top-50 indices and
+        log-marginals, no per-instance graph."""
+        from . import tidir
         lp, counts, n = 0.0, np.zeros(4, dtype=np.int64), 0
-        for tr in self.trainers.values():
-            l, _, _, c = tr.predict(top=min(50, tr.batch.X))
+        blocks = {}
+        for key, tr in self.trainers.items():
+            l, idx, logs, c, logm, label_logs = tr.predict(top=min(50, tr.batch.X), with_logs=True)
             lp += float(l.sum()); counts += np.array(c); n += len(l)
-        return lp / max(n, 1), tuple(int(v) for v in counts)
+            if save_predictions:
+                rows = self.buckets[key]['rows']
+                for b, row in enumerate(rows):
+                    blocks[row['index']] = tidir.prediction_text(row, list(key[1]), self.en, idx[b], logs[b], label_logs[b], logm[b])
+        if save_predictions:
+            import codecs
+            ext = {'user': '.user_adapt', 'experience': '.exp_adapt', None: ''}[self.adapt]
+            tail = '.rank%d' % self.rank if self.world > 1 else ''
+            with codecs.open(save_predictions + ext + tail, 'w', 'utf8') as w, codecs.open(save_predictions + ext + '.dist' + tail, 'w', 'utf8') as wd:
+                for i in sorted(blocks):
+                    w.write(blocks[i][0] + '\n')
+                    wd.write(blocks[i][1] + '\n')
+        tot = torch.tensor([lp, float(n)] + [float(v) for v in counts], dtype=torch.float64, device=self.device)
+        mdist.all_reduce_sum_(tot)
+        tot = tot.cpu().numpy()
+        return float(tot[0] / max(tot[1], 1.0)), tuple(int(v) for v in tot[2:])

@@ -241,3 +241,45 @@ def test_graphs_of_one_shape_share_their_programs_and_messages_are_copies(L):
     m2 = L.Message(np.full_like(before, 0.25))
     graphs[0].messages[k] = m2
     np.testing.assert_array_equal(graphs[0].messages[k].m.reshape(-1), np.full(before.size, 0.25))
+
+
+def test_update_theta_and_the_toy_test_flow(L):
+    """BASELINE config 1's flow through the drop-in (toy_test.py:143-154 with today's constructor): per instance
+    initialize -> treelike_inference(3) -> get_gradient -> theta += 0.05 grad, the thetas carried to the next instance; and
+    FactorGraph.update_theta (LBP.py:329-333), which does the same step with the graph's own learning rate, in place.
+    Both against the reference's fixtures (grad_reg_* / grad_ret_* of user_k3_x64, learning rate 0.05)."""
+    case = [c for c in C.inference_cases() if c['name'] == 'user_k3_x64'][0]
+    spec, gold = case['spec'], load_golden(case['name'])
+    inputs = C.make_inputs(spec, case['seed'], case['kind'] or 'uniform')
+    theta_ee, theta_ed = inputs['theta_en_en'].copy(), inputs['theta_en_de'].copy()
+    roots = Roots(L)
+    for instance in range(2):                              # two instances of one shape, theta carried over (toy_test.py:151-152)
+        ins = dict(inputs, theta_en_en=theta_ee, theta_en_de=theta_ed)
+        fg = C.build_graph(L, spec, ins)
+        fg.learning_rate, fg.regularization_param = 0.05, 0.2 / 17.0
+        roots.queue = [case['roots'][0]]
+        fg.initialize()
+        roots.queue = list(case['roots'][:3])
+        fg.treelike_inference(3)
+        before_ee, before_ed = fg.theta_en_en.copy(), fg.theta_en_de.copy()
+        grad_en_de, grad_en_en = fg.get_gradient()
+        if instance == 0:
+            np.testing.assert_allclose(grad_en_en, gold['grad_reg_en_en'], rtol=1e-8, atol=1e-12)
+            np.testing.assert_allclose(grad_en_de, gold['grad_reg_en_de'], rtol=1e-8, atol=1e-12)
+        fg.theta_en_en += 0.05 * grad_en_en
+        fg.theta_en_de += 0.05 * grad_en_de
+        np.testing.assert_allclose(fg.theta_en_en, before_ee + 0.05 * grad_en_en, rtol=0, atol=0)
+        theta_ee, theta_ed = fg.theta_en_en, fg.theta_en_de
+    # update_theta: the same step through the method, on the arrays the graph holds (callers keep references)
+    fg = C.build_graph(L, spec, inputs)
+    fg.learning_rate, fg.regularization_param = 0.05, 0.2 / 17.0
+    roots.queue = [case['roots'][0]]
+    fg.initialize()
+    roots.queue = list(case['roots'][:3])
+    fg.treelike_inference(3)
+    held_ee, held_ed = fg.theta_en_en, fg.theta_en_de
+    start_ee, start_ed = held_ee.copy(), held_ed.copy()
+    out_ee, out_ed = fg.update_theta()
+    assert out_ee is held_ee and out_ed is held_ed and fg.theta_en_en is held_ee
+    np.testing.assert_allclose(held_ee - start_ee, gold['grad_ret_en_en'], rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(held_ed - start_ed, gold['grad_ret_en_de'], rtol=1e-7, atol=1e-12)

@@ -601,3 +601,149 @@ def test_gradient_fused_into_a_sweep_that_skips_unchanged_updates(shared):
         assert _ffi.lib.mlbp_last_sweep_kernel() == (3 if shared else 7)
         outs.append(stats.cpu().numpy())
     np.testing.assert_allclose(outs[1], outs[0], rtol=1e-11, atol=1e-13)
+
+
+def test_grouped_statistics_and_the_large_state_step_replay_from_a_hip_graph(tmp_path):
+    """Every hot-path entry only enqueues (after one eager pass that makes the first-use allocations): the trainer's grouped
+    sweeps (mlbp_sweep_groups_f64: group table owned by the first program, uploaded only when it changes) and the X = 128
+    step (update-by-update MFMA contractions; the gradient's slot arrays come from the caller's host copy) are captured into
+    HIP graphs and replayed -- same bits as the eager launches, also after theta has moved."""
+    from macaronicusermodeling_amd import tidir
+    from macaronicusermodeling_amd.train import TiDirTrainer, UserGraphTrainer
+    from macaronicusermodeling_amd.topology import GraphTopology
+    paths = tidir.synthesize(str(tmp_path), n_instances=40, X=64, Vde=64, sent_len=(4, 7), n_predicted=(2, 3), seed=21)
+    tr = TiDirTrainer(paths['ti'], paths['end'], paths['ded'], paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'],
+                      paths['phi_ped'], sweeps=3, grouped_sweeps=True)
+    bump_ee = torch.tensor([0.3, -0.2, 0.1], dtype=torch.float64, device=tr.theta_en_en.device)
+    bump_ed = torch.tensor([0.2, 0.1, -0.3, 0.05, 0.0, 0.1], dtype=torch.float64, device=tr.theta_en_de.device)
+    tr.theta_en_en += bump_ee; tr.theta_en_de += bump_ed
+    eager1 = tr.local_statistics().clone()
+    tr.capture()
+    assert torch.equal(tr.local_statistics(), eager1)
+    tr.theta_en_en += 0.5 * bump_ee; tr.theta_en_de -= 0.25 * bump_ed          # the graph reads theta from the same tensors
+    replay2 = tr.local_statistics().clone()
+    tr._graph = None
+    assert torch.equal(tr.local_statistics(), replay2) and not torch.equal(replay2, eager1)
+    # X = 128: shared pots, sweeps and pairwise gradient as batched contractions
+    spec = C.user_spec(8, [1, 3, 6], 128, 40, seed=2)
+    topo = GraphTopology.from_spec(spec)
+    inputs = C.make_inputs(spec, 78)
+    labels, obs = _instances(spec, topo, 6, 6)
+    ut = UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],
+                          inputs['theta_en_en'], inputs['theta_en_de'], roots=[3, 1, 6])
+    e1 = ut.local_statistics().clone()
+    ut.capture()
+    assert torch.equal(ut.local_statistics(), e1)
+    ut.theta_en_en *= 0.5
+    r2 = ut.local_statistics().clone()
+    ut._graph = None
+    assert torch.equal(ut.local_statistics(), r2) and not torch.equal(r2, e1)
+
+
+def _write_tidir(gold, d):
+    import os
+    paths = {k: os.path.join(d, k) for k in ('ti', 'vocab.en', 'vocab.de', 'phi.pmi', 'phi.pmi_w1', 'phi.ed', 'phi.ped')}
+    open(paths['ti'], 'w', encoding='utf8').write('\n'.join(gold['instances']) + '\n')
+    open(paths['vocab.en'], 'w', encoding='utf8').write('\n'.join(gold['vocab_en']) + '\n')
+    open(paths['vocab.de'], 'w', encoding='utf8').write('\n'.join(gold['vocab_de']) + '\n')
+    for k, name in (('phi.pmi', 'phi_pmi'), ('phi.pmi_w1', 'phi_pmi_w1'), ('phi.ed', 'phi_ed'), ('phi.ped', 'phi_ped')):
+        np.savetxt(paths[k], np.array(gold[name]))
+    return paths
+
+
+def _batch_gold():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tidir_batch_reference.json'), encoding='utf8'))
+
+
+def _trainer(paths, gold, **kw):
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    tt = TiDirTrainer(paths['ti'], paths['vocab.en'], paths['vocab.de'], paths['phi.pmi'], paths['phi.pmi_w1'], paths['phi.ed'],
+                      paths['phi.ped'], sweeps=3, **kw)
+    if gold is not None:
+        tt.theta_en_en.copy_(torch.tensor(gold['theta_en_en'], dtype=torch.float64).reshape(-1))
+        tt.theta_en_de.copy_(torch.tensor(gold['theta_en_de'], dtype=torch.float64).reshape(-1))
+    return tt
+
+
+def test_minibatched_shuffled_epoch_equals_the_reference_sequence(tmp_path):
+    """train_mp.py:631-649 + 405-424 shuffles the instances and updates theta as results come back.  tidir_batch_reference.json
+    ['minibatch'] holds the REFERENCE's own batch_sgd run minibatch by minibatch (4 instances each, a fixed shuffled order,
+    every instance of a minibatch at the theta the minibatch starts from, steps added as batch_sgd_accumulate adds them;
+    make_batch_golden.py).  TiDirTrainer(minibatch=4) walking the same order must land on the same theta after every
+    minibatch -- shapes are mixed inside a minibatch (grouped sweeps and per-bucket launches both), one update per minibatch."""
+    gold = _batch_gold()
+    mb = gold['minibatch']
+    paths = _write_tidir(gold, str(tmp_path))
+    for grouped in (True, False):
+        tt = _trainer(paths, gold, minibatch=mb['size'], shuffle_seed=3, grouped_sweeps=grouped)
+        tt.epoch_order = lambda epoch: np.array(mb['order'])
+        seen = []
+        update = tt._update
+
+        def recording(lr, reg):
+            out = update(lr, reg)
+            seen.append((tt.theta_en_en.cpu().numpy().copy(), tt.theta_en_de.cpu().numpy().copy(), out))
+            return out
+        tt._update = recording
+        mean_lp = tt.epoch(mb['learning_rate'], gold['options']['reg_param'] / len(gold['instances']))
+        assert len(seen) == len(mb['steps']) == 3
+        for (ee, ed, (lp, n)), step in zip(seen, mb['steps']):
+            np.testing.assert_allclose(ee, step['theta_en_en'], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(ed, step['theta_en_de'], rtol=1e-9, atol=1e-12)
+            assert n == len(step['instances'])
+            np.testing.assert_allclose(lp, sum(step['log_posteriors']), rtol=1e-9)
+        np.testing.assert_allclose(mean_lp, np.mean([l for s in mb['steps'] for l in s['log_posteriors']]), rtol=1e-9)
+    # a seeded shuffle: every epoch another order, the same on every rank, each a permutation of all instances
+    o0, o1 = tt.__class__.epoch_order(tt, 0), tt.__class__.epoch_order(tt, 1)
+    assert sorted(o0) == sorted(o1) == list(range(12)) and list(o0) != list(o1)
+    assert list(tt.__class__.epoch_order(_trainer(paths, gold, minibatch=4, shuffle_seed=3), 0)) == list(o0)
+
+
+def test_batched_prediction_files_equal_the_reference_text(tmp_path):
+    """--save_predictions (train_mp.py:740-760): per instance the '*SENT_ID:' block (FactorGraph.to_string, LBP.py:109-123) and
+    the .dist lines (to_dist, LBP.py:125-143).  TiDirTrainer.predict(save_predictions=...) writes both files from the batched
+    top-50 indices and log-marginals; they must equal, character for character, what the reference's batch_predictions
+    returned for the same 12 instances (tidir_batch_reference.json['predictions']), and the precision counts and mean
+    log-posterior the sums of its per-instance values."""
+    gold = _batch_gold()
+    paths = _write_tidir(gold, str(tmp_path))
+    tt = _trainer(paths, gold)
+    out = str(tmp_path / 'pred')
+    mean_lp, counts = tt.predict(save_predictions=out)
+    want = gold['predictions']
+    assert open(out, encoding='utf8').read() == ''.join(p['block'] + '\n' for p in want)
+    assert open(out + '.dist', encoding='utf8').read() == ''.join(p['dist'] + '\n' for p in want)
+    assert counts == tuple(int(sum(p['precision'][k] for p in want)) for k in range(4))
+    np.testing.assert_allclose(mean_lp, np.mean([p['log_posterior'] for p in want]), rtol=1e-9)
+
+
+@pytest.mark.parametrize('adapt', [None, 'user'])
+def test_resume_from_a_params_file(tmp_path, adapt):
+    """--load_params (train_mp.py:528-542): a run that starts from the file another run saved continues from its thetas --
+    global and, with --user_adapt, every user's -- and the adapt mode's extension is tried before the bare name."""
+    gold = _batch_gold()
+    paths = _write_tidir(gold, str(tmp_path))
+    a = _trainer(paths, gold, adapt=adapt, minibatch=5, shuffle_seed=1)
+    a.train(epochs=2, reg_param=0.2, save_params=str(tmp_path / 'params'))
+    ext = '.user_adapt' if adapt else ''
+    import os
+    assert os.path.exists(str(tmp_path / 'params') + ext) and os.path.exists(str(tmp_path / 'params') + ext + '.iter1')
+    b = _trainer(paths, None, adapt=adapt, minibatch=5, shuffle_seed=1, load_params=str(tmp_path / 'params'))
+    b._epochs_done = 2                                   # (walks the third epoch's order, as the first run does next)
+    # the file keeps six decimals (save_params, train_mp.py:80-102: '%0.6f'): that is what a resumed run starts from
+    r6 = lambda t: np.round(t.cpu().numpy(), 6)
+    np.testing.assert_allclose(b.theta_en_en.cpu().numpy(), r6(a.theta_en_en), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b.theta_en_de.cpu().numpy(), r6(a.theta_en_de), rtol=0, atol=1e-12)
+    b2 = _trainer(paths, None, adapt=adapt)
+    b2.load_params(str(tmp_path / 'params'))
+    np.testing.assert_array_equal(b2.theta_en_de.cpu().numpy(), b.theta_en_de.cpu().numpy())
+    if adapt:
+        assert b.domains == a.domains and len(a.domains) > 1
+        np.testing.assert_allclose(b.theta_dom_en_en.cpu().numpy(), r6(a.theta_dom_en_en), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(b.theta_dom_en_de.cpu().numpy(), r6(a.theta_dom_en_de), rtol=0, atol=1e-12)
+        assert float(a.theta_dom_en_de.abs().sum()) > 0
+    # the resumed run moves on from there as the first one would (to the file's precision)
+    la, lb = a.epoch(0.05, 0.2 / 12), b.epoch(0.05, 0.2 / 12)
+    np.testing.assert_allclose(lb, la, rtol=1e-4)

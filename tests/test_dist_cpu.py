@@ -44,12 +44,23 @@ def _worker(rank, world, port, n_items, q):
     spec = C.user_spec(6, [0, 2, 3], 8, 8, seed=3)
     inputs = C.make_inputs(spec, 11)
     lo, hi = mdist.shard_range(n_items, rank, world)
-    stats = torch.from_numpy(_stats_for(spec, inputs, range(100 + lo, 100 + hi), [0, 2]))
-    mdist.all_reduce_sum_(stats)
+    # the trainer's fused buffer (train.UserGraphTrainer.stats_all): [global statistics | per-domain statistics [D][n_stat]],
+    # ONE all-reduce for both halves; item i belongs to domain i % D
+    n_stat, D = C.F_EE + C.F_ED + 2, 3
+    fused = torch.zeros(n_stat * (1 + D), dtype=torch.float64)
+    for i in range(lo, hi):
+        s_i = torch.from_numpy(_stats_for(spec, inputs, [100 + i], [0, 2]))
+        fused[:n_stat] += s_i
+        fused[n_stat * (1 + i % D):n_stat * (2 + i % D)] += s_i
+    mdist.all_reduce_sum_(fused)
+    stats = fused[:n_stat]
     t_ee = torch.from_numpy(inputs['theta_en_en'].reshape(-1).copy())
     t_ed = torch.from_numpy(inputs['theta_en_de'].reshape(-1).copy())
     apply_update(t_ee, t_ed, stats, C.F_EE, C.F_ED, 0.1, 0.01)
-    q.put((rank, lo, hi, stats.numpy().copy(), t_ee.numpy().copy(), t_ed.numpy().copy()))
+    from macaronicusermodeling_amd.train import apply_domain_update
+    d_ee, d_ed = torch.zeros(D, C.F_EE, dtype=torch.float64) + 0.25, torch.zeros(D, C.F_ED, dtype=torch.float64) - 0.5
+    apply_domain_update(d_ee, d_ed, fused[n_stat:].view(D, n_stat), C.F_EE, C.F_ED, 0.1, 0.01 * 0.5)
+    q.put((rank, lo, hi, stats.numpy().copy(), t_ee.numpy().copy(), t_ed.numpy().copy(), d_ee.numpy().copy(), d_ed.numpy().copy()))
     torch.distributed.destroy_process_group()
 
 
@@ -76,6 +87,12 @@ def test_two_rank_gloo_step_equals_single_process():
     n = want[-1]
     np.testing.assert_allclose(res[0][4], inputs['theta_en_en'].reshape(-1) +
                                0.1 * (want[:C.F_EE] - n * 0.01 * inputs['theta_en_en'].reshape(-1)), rtol=1e-12)
+    # the per-domain half of the same buffer: domain d = the items i with i % 3 == d, wherever they were sharded
+    for d in range(3):
+        w_d = _stats_for(spec, inputs, [100 + i for i in range(n_items) if i % 3 == d], [0, 2])
+        for r in res:
+            np.testing.assert_allclose(r[6][d], 0.25 + 0.1 * (w_d[:C.F_EE] - w_d[-1] * 0.005 * 0.25), rtol=1e-12)
+            np.testing.assert_allclose(r[7][d], -0.5 + 0.1 * (w_d[C.F_EE:C.F_EE + C.F_ED] - w_d[-1] * 0.005 * -0.5), rtol=1e-12)
 
 
 def test_shard_range_covers_everything_once():

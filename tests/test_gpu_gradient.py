@@ -747,3 +747,90 @@ def test_resume_from_a_params_file(tmp_path, adapt):
     # the resumed run moves on from there as the first one would (to the file's precision)
     la, lb = a.epoch(0.05, 0.2 / 12), b.epoch(0.05, 0.2 / 12)
     np.testing.assert_allclose(lb, la, rtol=1e-4)
+
+
+def _rank_worker(rank, world, port, paths, gold_path, q):
+    """One fresh rank process of the two-rank trainer test: gloo group, both ranks on cuda:0."""
+    import json
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    import torch as th
+    from macaronicusermodeling_amd import dist as mdist
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    r, w, _ = mdist.init_from_env(backend='gloo')
+    th.cuda.set_device(0)
+    gold = json.load(open(gold_path, encoding='utf8'))
+    ua = gold['user_adapt']
+    tt = TiDirTrainer(paths['ti'], paths['vocab.en'], paths['vocab.de'], paths['phi.pmi'], paths['phi.pmi_w1'], paths['phi.ed'],
+                      paths['phi.ped'], sweeps=3, adapt='user', domains=ua['users'], reg_param_ua_scale=ua['reg_param_ua_scale'],
+                      rank=r, world=w)
+    tt.theta_en_en.copy_(th.tensor(gold['theta_en_en'], dtype=th.float64).reshape(-1))
+    tt.theta_en_de.copy_(th.tensor(gold['theta_en_de'], dtype=th.float64).reshape(-1))
+    for i, u in enumerate(ua['users']):
+        tt.theta_dom_en_en[i].copy_(th.tensor(ua['theta_dom'][u][0], dtype=th.float64))
+        tt.theta_dom_en_de[i].copy_(th.tensor(ua['theta_dom'][u][1], dtype=th.float64))
+    shapes = sorted(str(k) for k in tt.trainers)
+    o = gold['options']
+    mean_lp = tt.epoch(o['learning_rate'], o['reg_param'] / len(gold['instances']))
+    pred_lp, counts = tt.predict()
+    q.put((rank, shapes, mean_lp, tt.theta_en_en.cpu().numpy(), tt.theta_en_de.cpu().numpy(), tt.theta_dom_en_en.cpu().numpy(),
+           tt.theta_dom_en_de.cpu().numpy(), pred_lp, counts, sum(t.batch.B for t in tt.trainers.values())))
+    th.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_trainer_epoch_equals_one_process_and_the_reference(tmp_path):
+    """The multi-rank path of the trainer itself (train_mp.py:634-649 + 405-424 as contiguous shards + ONE all-reduce of the
+    fused [global | per-domain] statistics buffer): two FRESH rank processes (gloo, both on cuda:0 -- the one-GPU box's
+    rehearsal of two GPUs) run TiDirTrainer.epoch with --user_adapt on the 12-instance golden TI_DIR.  The shards hold
+    different sentence shapes.  Every rank must end with the thetas -- global and every user's -- of the single-process run
+    and of the reference's summed batch_sgd steps (tidir_reference.json), and predict() must return the all-instance totals
+    on every rank."""
+    import json
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    gold_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tidir_reference.json')
+    gold = json.load(open(gold_path, encoding='utf8'))
+    paths = _write_tidir(gold, str(tmp_path))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, paths, gold_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] != res[1][1] and res[0][9] + res[1][9] == 12          # different shape buckets, all instances covered
+    ua, inst = gold['user_adapt'], gold['user_adapt']['instances']
+    want_ee = np.array(gold['theta_en_en']).reshape(-1) + sum(np.array(r['step'][0]) for r in inst)
+    want_ed = np.array(gold['theta_en_de']).reshape(-1) + sum(np.array(r['step'][1]) for r in inst)
+    for r in res:
+        np.testing.assert_allclose(r[3], want_ee, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(r[4], want_ed, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(r[2], np.mean([x['log_posterior'] for x in inst]), rtol=1e-9)
+        for i, u in enumerate(ua['users']):
+            mine = [x for x in inst if x['user'] == u]
+            np.testing.assert_allclose(r[5][i], np.array(ua['theta_dom'][u][0]) + sum(np.array(x['step_domain'][0]) for x in mine), rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(r[6][i], np.array(ua['theta_dom'][u][1]) + sum(np.array(x['step_domain'][1]) for x in mine), rtol=1e-9, atol=1e-12)
+    for k in (3, 4, 5, 6):
+        np.testing.assert_array_equal(res[0][k], res[1][k])                 # every rank holds the same parameters
+    assert res[0][7] == res[1][7] and res[0][8] == res[1][8] and res[0][8][3] > 0      # prediction totals reduced
+    # ... and the single-process trainer gets there too (same numbers to rounding: other summation order)
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    one = TiDirTrainer(paths['ti'], paths['vocab.en'], paths['vocab.de'], paths['phi.pmi'], paths['phi.pmi_w1'], paths['phi.ed'],
+                       paths['phi.ped'], sweeps=3, adapt='user', domains=ua['users'], reg_param_ua_scale=ua['reg_param_ua_scale'])
+    one.theta_en_en.copy_(torch.tensor(gold['theta_en_en'], dtype=torch.float64).reshape(-1))
+    one.theta_en_de.copy_(torch.tensor(gold['theta_en_de'], dtype=torch.float64).reshape(-1))
+    for i, u in enumerate(ua['users']):
+        one.theta_dom_en_en[i].copy_(torch.tensor(ua['theta_dom'][u][0], dtype=torch.float64))
+        one.theta_dom_en_de[i].copy_(torch.tensor(ua['theta_dom'][u][1], dtype=torch.float64))
+    o = gold['options']
+    one.epoch(o['learning_rate'], o['reg_param'] / len(gold['instances']))
+    np.testing.assert_allclose(res[0][3], one.theta_en_en.cpu().numpy(), rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(res[0][6], one.theta_dom_en_de.cpu().numpy(), rtol=1e-11, atol=1e-13)
+    lp1, c1 = one.predict()
+    assert c1 == res[0][8]
+    np.testing.assert_allclose(res[0][7], lp1, rtol=1e-11)

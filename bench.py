@@ -348,6 +348,7 @@ def main():
     fb.initialize()
     fb.is_loopy = True          # chain workloads: run real sweeps, tree short-circuit overridden (LBP.py:219)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    submit = [0.0] * (a.steps + 1)
 
     def step(i=None):
         if i is not None:
@@ -397,8 +398,9 @@ def main():
     def timed_window():
         """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; returns
         (seconds, max over ranks), and the HIP events of its K sweep launches."""
-        nonlocal ev
+        nonlocal ev, submit
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        submit = [0.0] * (a.steps + 1)
         for _ in range(a.warmup):
             step()
         torch.cuda.synchronize()
@@ -407,7 +409,9 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(a.steps):
+            submit[i] = time.perf_counter()      # host clock at the launch's submission: tells a host stall from a device one
             step(i)
+        submit[a.steps] = time.perf_counter()
         for w in pending:
             if w is not None:
                 w.wait()                    # every step's reduction completes inside the timed region
@@ -420,7 +424,7 @@ def main():
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el, ev
+        return el, ev, list(submit)
 
     # Three windows of exactly K steps each; the MEDIAN window is the one reported (value, ms_per_step, and the launch
     # times behind roofline): a single stalled launch (host pre-emption, a device power event) then cannot decide the
@@ -428,7 +432,7 @@ def main():
     windows = [timed_window() for _ in range(3)]
     gc.enable()
     order = sorted(range(3), key=lambda i: windows[i][0])
-    elapsed, ev = windows[order[1]]
+    elapsed, ev, submit = windows[order[1]]
     assert fb.program(roots).status() == 0
 
     # Secondary figure, never `value`: the same launch under MLBP_SWEEP_SKIP_UNCHANGED (include/mlbp.h), which drops the
@@ -560,6 +564,22 @@ def main():
                 roof['note'] = 'fraction above 1: the re-read tables of this small batch were served by the Infinity Cache, not HBM'
         roof.update({'avg_launch_ms': avg_ms, 'min_launch_ms': sweep_ms[0], 'max_launch_ms': sweep_ms[-1],
                      'kernel_sources_sha': sha})
+        # Where would a stall have come from?  Every window keeps, per step, the host time between two submissions and the
+        # device time of the sweep launch (HIP events).  A step whose HOST gap is far above the median while its launch is
+        # not is the host's (a pre-empted thread: the device idles, the events of the NEXT launch are unaffected); a launch
+        # whose DEVICE time is far above the median is the device's (clock / power event) whatever the host did.
+        def attribution(win):
+            el, evs, sub = win
+            gaps = [(sub[i + 1] - sub[i]) * 1e3 for i in range(a.steps)]
+            devs = [s.elapsed_time(e) for s, e in evs]
+            med_g, med_d = sorted(gaps)[len(gaps) // 2], sorted(devs)[len(devs) // 2]
+            slow_host = [i for i in range(a.steps) if gaps[i] > 5 * med_g and gaps[i] > med_g + 1.0]
+            slow_dev = [i for i in range(a.steps) if devs[i] > 5 * med_d and devs[i] > med_d + 1.0]
+            return {'ms_per_step': el / a.steps * 1e3, 'median_host_submit_gap_ms': med_g, 'max_host_submit_gap_ms': max(gaps),
+                    'median_launch_ms': med_d, 'max_launch_ms': max(devs),
+                    'host_side_stalls': [{'step': i, 'gap_ms': gaps[i], 'launch_ms': devs[i]} for i in slow_host if i not in slow_dev],
+                    'device_side_stalls': [{'step': i, 'gap_ms': gaps[i], 'launch_ms': devs[i]} for i in slow_dev]}
+        stalls = [attribution(w) for w in windows]
         out = {
             'metric': 'LBP sweep iters/sec (whole node), batch=8192 graphs |X|=64',
             'value': iters_per_s, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -577,6 +597,7 @@ def main():
             'cpu_baseline': cpu,
             'skip_unchanged': skip,
             'train_step': train,
+            'stall_attribution': stalls,
         }
         if cpu is not None:
             out['parity'] = parity_sample(spec, topo, roots, fb, marg)

@@ -64,18 +64,23 @@ __device__ __forceinline__ double block_sum(double v, double* scratch /*[4]*/) {
 // plane (the gradient's T (.) phi_k).  MFMA 16x16x4 lane map: lane l holds A[i = l & 15][k = l >> 4].
 //   float64: frag[rt][kp][l][e]  = Aop[16 rt + (l & 15)][8 kp + 4 e + (l >> 4)],  e = 0, 1      (one double2 per lane)
 //   float32: frag[rt][kq][l][e]  = Aop[16 rt + (l & 15)][16 kq + 4 e + (l >> 4)], e = 0 .. 3    (one float4 per lane)
+// XA >= X is the padded size the contraction runs at (a multiple of 128): rows and columns past X are zero, so that any
+// vocabulary size (X = len(en_domain), train_mp.py:591-594) takes the matrix-core path.
 template <typename TT, int E>
-__global__ void table_frag_kernel(const TT* T, const double* plane, int X, int transpose, TT* frag) {
+__global__ void table_frag_kernel(const TT* T, const double* plane, int X, int XA, int transpose, TT* frag) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // one output element
-  if (idx >= (size_t)X * X) return;
+  if (idx >= (size_t)XA * XA) return;
   const int e = idx % E, l = (idx / E) % 64;
   const size_t blk = idx / (E * 64);
-  const int KB = X / (4 * E);
+  const int KB = XA / (4 * E);
   const int kb = blk % KB, rt = blk / KB;
   const int i = 16 * rt + (l & 15), k = 4 * E * kb + 4 * e + (l >> 4);
-  const size_t at = transpose ? (size_t)k * X + i : (size_t)i * X + k;
-  double v = (double)T[at];
-  if (plane) v *= plane[at];
+  double v = 0.0;
+  if (i < X && k < X) {
+    const size_t at = transpose ? (size_t)k * X + i : (size_t)i * X + k;
+    v = (double)T[at];
+    if (plane) v *= plane[at];
+  }
   frag[idx] = (TT)v;
 }
 
@@ -88,6 +93,7 @@ struct ContractDev {
   int32_t n_src;             // 0: the input is slot in_slot as it stands
   int32_t in_slot, vf_slot, dst_slot;      // vf_slot: where the variable->factor message itself is stored, or -1
   int32_t B, normalize;
+  int32_t X;                 // states (<= the 64 RT the kernel instance runs at; smaller: zero-padded operands, PADDED instances)
 };
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -105,13 +111,15 @@ template <> struct Frag<float> {
   typedef float lds_t;
 };
 
-// X = 64 * RT states; N_T = 16 * NCT graphs per workgroup.
-template <typename TT, int RT, int NCT, int DEPTH, int NW>
+// The contraction runs at XA = 64 * RT states; N_T = 16 * NCT graphs per workgroup.  PADDED: the messages have d.X <= XA
+// states (rows of d.X doubles in memory, any parity: 8-byte accesses), the operands are zero beyond.
+template <typename TT, int RT, int NCT, int DEPTH, int NW, bool PADDED>
 __global__ __launch_bounds__(64 * NW) void contract_kernel(ContractDev d) {
-  constexpr int X = 64 * RT, NT_G = 16 * NCT, XP = X + 2;
+  constexpr int XA = 64 * RT, NT_G = 16 * NCT, XP = XA + 2;
+  const int X = PADDED ? d.X : XA;
   constexpr int RTW = 4 * RT / NW;                               // 16-row tiles per wave (wave w owns tiles w, w + NW, ...)
   static_assert((4 * RT) % NW == 0 && NT_G % NW == 0, "");
-  constexpr int KS = Frag<TT>::KSTEPS, KB = X / (4 * KS);       // 16-byte fragment blocks along k
+  constexpr int KS = Frag<TT>::KSTEPS, KB = XA / (4 * KS);      // 16-byte fragment blocks along k
   typedef typename Frag<TT>::vec avec;
   typedef typename Frag<TT>::lds_t mt_t;
   extern __shared__ double lds_raw[];
@@ -136,23 +144,39 @@ __global__ __launch_bounds__(64 * NW) void contract_kernel(ContractDev d) {
       live[u] = b < d.B;
       gin[u] = d.in + (size_t)(live[u] ? b : 0) * d.in_ld;
     }
+    // states 2 (lane + 64 j), + 1 of a row of X doubles; beyond X: zero
+    auto load2 = [&](const double* row, int j) {
+      if (!PADDED) return reinterpret_cast<const double2*>(row)[lane + 64 * j];
+      const int x0 = 2 * (lane + 64 * j);
+      return make_double2(x0 < X ? row[x0] : 0.0, x0 + 1 < X ? row[x0 + 1] : 0.0);
+    };
+    auto uniform2 = [&](int j) {
+      const int x0 = 2 * (lane + 64 * j);
+      return (!PADDED) ? make_double2(uniform, uniform) : make_double2(x0 < X ? uniform : 0.0, x0 + 1 < X ? uniform : 0.0);
+    };
+    auto store2 = [&](double* row, int j, double2 val) {
+      if (!PADDED) { reinterpret_cast<double2*>(row)[lane + 64 * j] = val; return; }
+      const int x0 = 2 * (lane + 64 * j);
+      if (x0 < X) row[x0] = val.x;
+      if (x0 + 1 < X) row[x0 + 1] = val.y;
+    };
     if (d.n_src == 0) {
 #pragma unroll
       for (int u = 0; u < GU; ++u)
 #pragma unroll
-        for (int j = 0; j < H; ++j) v[u][j] = reinterpret_cast<const double2*>(gin[u] + (size_t)d.in_slot * X)[lane + 64 * j];
+        for (int j = 0; j < H; ++j) v[u][j] = load2(gin[u] + (size_t)d.in_slot * X, j);
     } else {
 #pragma unroll
       for (int u = 0; u < GU; ++u)
 #pragma unroll
-        for (int j = 0; j < H; ++j) v[u][j] = make_double2(uniform, uniform);
+        for (int j = 0; j < H; ++j) v[u][j] = uniform2(j);
       for (int q = 0; q < d.n_src; ++q) {
         const size_t so = (size_t)d.src[q] * X;
         double2 m[GU][H];
 #pragma unroll
         for (int u = 0; u < GU; ++u)
 #pragma unroll
-          for (int j = 0; j < H; ++j) m[u][j] = reinterpret_cast<const double2*>(gin[u] + so)[lane + 64 * j];
+          for (int j = 0; j < H; ++j) m[u][j] = load2(gin[u] + so, j);
 #pragma unroll
         for (int u = 0; u < GU; ++u)
 #pragma unroll
@@ -175,15 +199,15 @@ __global__ __launch_bounds__(64 * NW) void contract_kernel(ContractDev d) {
         for (int u = 0; u < GU; ++u)
 #pragma unroll
           for (int j = 0; j < H; ++j)
-            v[u][j] = tot[u] > 0.0 ? make_double2(v[u][j].x / tot[u], v[u][j].y / tot[u]) : make_double2(uniform, uniform);
+            v[u][j] = tot[u] > 0.0 ? make_double2(v[u][j].x / tot[u], v[u][j].y / tot[u]) : uniform2(j);
       }
       if (d.vf_slot >= 0) {
 #pragma unroll
         for (int u = 0; u < GU; ++u)
           if (live[u]) {
-            double2* o = reinterpret_cast<double2*>(d.out + (size_t)(b0 + wave * GPW + g4 + u) * d.out_ld + (size_t)d.vf_slot * X);
+            double* o = d.out + (size_t)(b0 + wave * GPW + g4 + u) * d.out_ld + (size_t)d.vf_slot * X;
 #pragma unroll
-            for (int j = 0; j < H; ++j) o[lane + 64 * j] = v[u][j];
+            for (int j = 0; j < H; ++j) store2(o, j, v[u][j]);
           }
       }
     }
@@ -340,11 +364,17 @@ __global__ __launch_bounds__(64 * NW) void contract_kernel(ContractDev d) {
     for (int u = 0; u < GU; ++u) {
       const int b = b0 + wave * GPW + g4 + u;
       if (b < d.B) {
-        double2* o = reinterpret_cast<double2*>(d.out + (size_t)b * d.out_ld + (size_t)d.dst_slot * X);
+        double* o = d.out + (size_t)b * d.out_ld + (size_t)d.dst_slot * X;
 #pragma unroll
         for (int j = 0; j < H; ++j) {
-          if (!d.normalize) o[lane + 64 * j] = v[u][j];
-          else o[lane + 64 * j] = tot[u] > 0.0 ? make_double2(v[u][j].x / tot[u], v[u][j].y / tot[u]) : make_double2(uniform, uniform);
+          const int x0 = 2 * (lane + 64 * j);
+          double2 val = v[u][j];
+          if (d.normalize) val = tot[u] > 0.0 ? make_double2(val.x / tot[u], val.y / tot[u]) : make_double2(uniform, uniform);
+          if (!PADDED) reinterpret_cast<double2*>(o)[lane + 64 * j] = val;
+          else {
+            if (x0 < X) o[x0] = val.x;
+            if (x0 + 1 < X) o[x0 + 1] = val.y;
+          }
         }
       }
     }
@@ -358,18 +388,18 @@ size_t contract_lds_bytes(int X, int nct) {
   return (size_t)16 * nct * (X + 2) * sizeof(double);
 }
 
-template <typename TT, int RT>
+template <typename TT, int RT, bool PADDED>
 int launch_contract_rt(const ContractDev& d, int nct, hipStream_t st) {
-  const int X = 64 * RT;
+  const int XA = 64 * RT;
   const int ntg = 16 * nct;
-  const size_t lds = contract_lds_bytes<TT>(X, nct);
-  // 32 graphs per workgroup: one workgroup per CU, deep fragment prefetch; 16: two per CU hide each other's stalls
-  // 16 graphs per workgroup: 8 waves (two workgroups = 4 waves per SIMD hide each other's stalls; measured 3-5 % over 4 waves)
-  constexpr int nw = 8;
-  void (*k)(ContractDev) = nct == 2 ? contract_kernel<TT, RT, 2, 4, 4>
-                                    : (sizeof(TT) == 8 ? (nw == 8 ? contract_kernel<TT, RT, 1, 2, 8> : contract_kernel<TT, RT, 1, 2, 4>)
-                                                       : (nw == 8 ? contract_kernel<TT, RT, 1, 4, 8> : contract_kernel<TT, RT, 1, 4, 4>));
-  const int threads = (nct == 2 || nw != 8) ? WG : 512;
+  const size_t lds = contract_lds_bytes<TT>(XA, nct);
+  // 32 graphs per workgroup (float64, small tables, big batches): 4 waves, deep fragment prefetch; else 16 graphs per
+  // workgroup and 8 waves (two workgroups = 4 waves per SIMD hide each other's stalls; measured 3-7 % over 4 waves)
+  void (*k)(ContractDev) = nullptr;
+  if constexpr (PADDED) k = contract_kernel<TT, RT, 1, 2, 8, true>;
+  else k = nct == 2 ? contract_kernel<TT, RT, 2, 4, 4, false>
+                    : (sizeof(TT) == 8 ? contract_kernel<TT, RT, 1, 2, 8, false> : contract_kernel<TT, RT, 1, 4, 8, false>);
+  const int threads = nct == 2 ? WG : 512;
   static std::mutex mu;
   static std::vector<const void*> granted;
   {
@@ -386,18 +416,34 @@ int launch_contract_rt(const ContractDev& d, int nct, hipStream_t st) {
   return MLBP_OK;
 }
 
+// the size the contraction of X states runs at: the next multiple of 128
+int padded_states(int X) { return (X + 127) / 128 * 128; }
+
 // graphs per workgroup: 32 when the batch still fills the chip twice over and the accumulators fit, else 16
 template <typename TT>
-int launch_contract(const ContractDev& d, int X, hipStream_t st) {
+int launch_contract(ContractDev d, int X, hipStream_t st) {
   const bool f32 = sizeof(TT) == 4;
+  const int XA = padded_states(X);
+  d.X = X;
+  if (XA != X) {
+    if constexpr (sizeof(TT) == 8) {
+      switch (XA) {
+        case 128: return launch_contract_rt<TT, 2, true>(d, 1, st);
+        case 256: return launch_contract_rt<TT, 4, true>(d, 1, st);
+        case 384: return launch_contract_rt<TT, 6, true>(d, 1, st);
+        case 512: return launch_contract_rt<TT, 8, true>(d, 1, st);
+      }
+    }
+    return fail(MLBP_EUNSUPPORTED, "shared-table contraction: X = %d with float32 tables (256 or 512)", X);
+  }
   int nct = (!f32 && X <= 256 && d.B >= 32 * 512) ? 2 : 1;     // small tables: fewer passes over the table per graph
   switch (X) {
-    case 128: return launch_contract_rt<TT, 2>(d, nct, st);
-    case 256: return launch_contract_rt<TT, 4>(d, nct, st);
-    case 384: return launch_contract_rt<TT, 6>(d, nct, st);
-    case 512: return launch_contract_rt<TT, 8>(d, nct, st);
+    case 128: return launch_contract_rt<TT, 2, false>(d, nct, st);
+    case 256: return launch_contract_rt<TT, 4, false>(d, nct, st);
+    case 384: return launch_contract_rt<TT, 6, false>(d, nct, st);
+    case 512: return launch_contract_rt<TT, 8, false>(d, nct, st);
   }
-  return fail(MLBP_EUNSUPPORTED, "shared-table contraction: X = %d (128, 256, 384 or 512)", X);
+  return fail(MLBP_EUNSUPPORTED, "shared-table contraction: X = %d (65 .. 512)", X);
 }
 
 // ---- the small kernels around the contraction --------------------------------------------------------------------
@@ -494,10 +540,11 @@ int ensure_scratch(void** p, size_t* cap, size_t need) {
 template <typename TT>
 void launch_table_frag(const TT* T, const double* plane, int X, int transpose, TT* frag, hipStream_t st) {
   constexpr int E = sizeof(TT) == 8 ? 2 : 4;
-  hipLaunchKernelGGL((table_frag_kernel<TT, E>), dim3((X * X + 255) / 256), dim3(256), 0, st, T, plane, X, transpose, frag);
+  const int XA = padded_states(X);
+  hipLaunchKernelGGL((table_frag_kernel<TT, E>), dim3((XA * XA + 255) / 256), dim3(256), 0, st, T, plane, X, XA, transpose, frag);
 }
 
-bool contract_supports(int X) { return X >= 128 && X <= 512 && X % 128 == 0; }
+bool contract_supports(int X) { return X > 64 && X <= 512; }
 
 }  // namespace
 
@@ -512,8 +559,9 @@ int launch_gemm_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void
   static void* scratch = nullptr;
   static size_t cap = 0;
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
-  if (int e = ensure_scratch(&scratch, &cap, ((size_t)X * X + (size_t)B * X + 4 * (size_t)B) * sizeof(double))) return e;
-  double* W = (double*)scratch; double* Y = W + (size_t)X * X; double* S = Y + (size_t)B * X;
+  const size_t XA = (size_t)padded_states(X);
+  if (int e = ensure_scratch(&scratch, &cap, (XA * XA + (size_t)B * X + 4 * (size_t)B) * sizeof(double))) return e;
+  double* W = (double*)scratch; double* Y = W + XA * XA; double* S = Y + (size_t)B * X;
   // slots come from DEVICE arrays in the ABI (pair_c_slot / pair_r_slot / pair_phi): fetch the few ints once
   int32_t h_c[16], h_r[16], h_phi[16];
   if (a->P > 16) return fail(MLBP_EUNSUPPORTED, "shared-table gradient: at most 16 pairwise factors (got %d)", a->P);
@@ -563,7 +611,10 @@ int launch_gemm_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* 
   static void* frag = nullptr;
   static size_t frag_cap = 0;
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
-  if (int e = ensure_scratch(&frag, &frag_cap, (size_t)prog->P * 2 * X * X * elem)) return e;
+  const size_t XA = (size_t)padded_states(X);
+  if ((a->flags & MLBP_SWEEP_PAIR_TABLES_F32) && XA != (size_t)X)
+    return fail(MLBP_EUNSUPPORTED, "shared-table contraction path: float32 tables need X = 256 or 512");
+  if (int e = ensure_scratch(&frag, &frag_cap, (size_t)prog->P * 2 * XA * XA * elem)) return e;
   {
     HostRow row = {};
     for (int p = 0; p < prog->P; ++p) row.v[p] = a->pair_tab_host[p];
@@ -572,7 +623,7 @@ int launch_gemm_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* 
   }
   for (int p = 0; p < prog->P; ++p)
     for (int tr = 0; tr < 2; ++tr) {
-      const size_t off = ((size_t)p * 2 + tr) * X * X;
+      const size_t off = ((size_t)p * 2 + tr) * XA * XA;
       if (f32) launch_table_frag<float>(a->pair_tables_f32 + (size_t)a->pair_tab_host[p] * X * X, nullptr, X, tr, (float*)frag + off, st);
       else launch_table_frag<double>(a->pair_tables + (size_t)a->pair_tab_host[p] * X * X, nullptr, X, tr, (double*)frag + off, st);
     }
@@ -638,7 +689,7 @@ int launch_gemm_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* 
       }
     }
     // out = T . m contracts over the table's columns: A = T; out = m^T . T over its rows: A = T^T
-    const size_t off = ((size_t)pslot * 2 + (tm ? 0 : 1)) * X * X;
+    const size_t off = ((size_t)pslot * 2 + (tm ? 0 : 1)) * XA * XA;
     d.frag = f32 ? (const void*)((const float*)frag + off) : (const void*)((const double*)frag + off);
     if (int e = f32 ? launch_contract<float>(d, X, st) : launch_contract<double>(d, X, st)) return e;
   }

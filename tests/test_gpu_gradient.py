@@ -258,13 +258,15 @@ def test_tidir_trainer_epochs_and_predictions(tmp_path):
     assert counts == tuple(int(v) for v in want_counts)
 
 
-def test_train_step_at_a_large_state_space_uses_batched_gemms():
-    """X = 128: the trainer's shared pots make every factor->variable update of the shard one DGEMM; same step as the
-    oracle's per-instance loop."""
+@pytest.mark.parametrize('X', [128, 203])
+def test_train_step_at_a_large_state_space_uses_batched_gemms(X):
+    """X = 128 / 203 (a vocabulary size that is no multiple of anything: zero-padded to 256): the trainer's shared pots make
+    every factor->variable update of the shard one MFMA contraction over the batch; same step as the oracle's per-instance
+    loop."""
     from macaronicusermodeling_amd import _ffi
     from macaronicusermodeling_amd.train import UserGraphTrainer
     from macaronicusermodeling_amd.topology import GraphTopology
-    spec = C.user_spec(8, [1, 3, 6], 128, 40, seed=2)
+    spec = C.user_spec(8, [1, 3, 6], X, 40, seed=2)
     topo = GraphTopology.from_spec(spec)
     inputs = C.make_inputs(spec, 78)
     B, roots, lr, reg = 5, [3, 1, 6], 0.1, 0.2 / 5

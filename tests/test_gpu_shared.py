@@ -216,9 +216,10 @@ def test_full_size_properties_of_the_shared_kernel():
     np.testing.assert_allclose(g1.cpu().numpy(), marg[:64].cpu().numpy(), rtol=1e-11, atol=1e-300)
 
 
-@pytest.mark.parametrize('X', [128, 384, 512])
+@pytest.mark.parametrize('X', [96, 128, 200, 333, 384, 512])
 def test_large_state_shared_tables_run_as_batched_gemms(X):
-    """X = 128 .. 512 with shared pairwise tables: the sweeps run update by update over the whole batch, every
+    """X = 65 .. 512 with shared pairwise tables (any vocabulary size, X = len(en_domain) in train_mp.py:591-594: sizes that are
+    no multiple of 128 run zero-padded, odd ones with 8-byte accesses): the sweeps run update by update over the whole batch, every
     factor->variable update one launch of the hand-written float64 MFMA contraction (mlbp_gemm.hip; the variable
     product fused into its prologue, Message.renormalize into its epilogue).  Against the oracle per graph and against the per-graph wide kernel on the
     same inputs (same updates, only the summation order inside the contraction differs)."""

@@ -249,9 +249,18 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
 /* A minibatch of mixed graphs in one go: n_groups (program, arguments) pairs -- every group its own topology, root
  * sequence (the reference draws a fresh root per instance and sweep, LBP.py:223-225, and builds a different K_n per
  * instance, train_mp.py:257-299), tables and message buffer.  Equivalent to calling mlbp_sweep_f64 on the groups one
- * after the other; when every group qualifies for the fast X = 64 kernel (float64 tables, normalised messages, at most
- * 8 pairwise factors, no gradient, the same init / write-back / read-out choices, distinct programs) that kernel runs
- * ALL groups in a single launch, followed by one small fix-up launch per group.  progs / args are HOST arrays. */
+ * after the other, in fewer launches:
+ *   - every group states MLBP_SWEEP_SHARED_PAIR_TABLES and qualifies for the shared-table kernel (X = 64, normalised and
+ *     initialised messages, distinct programs): ONE prepare launch and ONE sweep launch (MLBP_KERNEL_SHARED_MFMA behind a
+ *     group table: a workgroup looks its group up by block index) cover ALL groups; what follows per group is its fix-up
+ *     pass over flagged graphs, its unary write-back when messages are kept, and its gradient when args[k].gradient is
+ *     set -- a minibatch of mixed sentence shapes over the two shared pots (train_mp.py:220-299);
+ *   - otherwise, when every group qualifies for the lean X = 64 kernel (float64 tables, normalised messages, at most 8
+ *     pairwise factors, the same init / write-back / read-out choices, distinct programs) that kernel runs ALL groups in
+ *     a single launch, followed by one small fix-up launch (and the gradient, if any) per group;
+ *   - otherwise group by group.
+ * progs / args are HOST arrays.  The group table is device memory owned by progs[0], uploaded only when its contents
+ * differ from the previous call's (a stream capture of a repeated call records no copy). */
 int mlbp_sweep_groups_f64(const mlbp_program* const* progs, const mlbp_sweep_args* args, int32_t n_groups, void* stream);
 
 /* Kernel selector for the parity tests (process-wide; not needed in normal use):

@@ -440,12 +440,13 @@ class FactorGraphBatch:
         return out
 
 
-def sweep_groups(batches, roots, init=False, marginals=None, keep_messages=True):
+def sweep_groups(batches, roots, init=False, marginals=None, keep_messages=True, gradients=None):
     """One minibatch of mixed graphs: batches[k] (a FactorGraphBatch: one topology, its tables and messages) is swept
     with its own root sequence roots[k] -- the reference draws roots per instance (LBP.py:223-225) and builds a
     different K_n per instance (train_mp.py:257-299).  Same results as batches[k].sweep(roots[k], ...) one by one; when
     every group qualifies, the fast kernel runs them all in ONE launch (mlbp_sweep_groups_f64).
-    marginals: None or one [B_k][n_vars_k][X] tensor per group."""
+    marginals: None or one [B_k][n_vars_k][X] tensor per group; gradients: None or one (g_en_en, g_en_de) pair per group
+    (each group's gradient launch follows its sweeps, as in FactorGraphBatch.sweep(gradient=...))."""
     if len(batches) != len(roots) or not batches:
         raise ValueError('one root sequence per batch')
     dev = batches[0].device
@@ -453,7 +454,8 @@ def sweep_groups(batches, roots, init=False, marginals=None, keep_messages=True)
     for k, fb in enumerate(batches):
         if fb.device != dev:
             raise ValueError('all groups live on one device')
-        fb.sweep(roots[k], init=init, marginals=None if marginals is None else marginals[k], keep_messages=keep_messages, _collect=got)
+        fb.sweep(roots[k], init=init, marginals=None if marginals is None else marginals[k], keep_messages=keep_messages,
+                 gradient=None if gradients is None else gradients[k], _collect=got)
     n = len(got)
     handles = (C.c_void_p * n)(*[p.handle for p, _, _ in got])
     args = (_ffi.SweepArgs * n)(*[a for _, a, _ in got])

@@ -482,19 +482,25 @@ __global__ __launch_bounds__(64) void patch_tables_kernel(const double* base_tab
 __global__ __launch_bounds__(64) void patch_gradient_kernel(const double* priv_tables, const int32_t* item_off,
                                                             const int32_t* item_x, const int32_t* item_k,
                                                             const double* item_val, const int32_t* row_graph,
-                                                            const int32_t* row_label, int X, int F, double* grad) {
-  const int r = blockIdx.x, lane = threadIdx.x;
-  const double* t = priv_tables + (size_t)r * X;
-  double part = 0.0;
-  for (int x = lane; x < X; x += 64) part += t[x];
-  const double Z = wave_sum(part);
-  if (lane == 0) {
-    const int lab = row_label[r];
-    double* g = grad + (size_t)row_graph[r] * F;
-    for (int q = item_off[r]; q < item_off[r + 1]; ++q) {
-      const int x = item_x[q];
-      const double belief = Z > 0.0 ? t[x] / Z : 0.0;
-      atomicAdd(&g[item_k[q]], item_val[q] * ((x == lab ? 1.0 : 0.0) - belief));
+                                                            const int32_t* row_label, int n_rows, int X, int F, double* grad) {
+  // One wave per RUN of consecutive rows of one graph (the wave of the run's first row walks it, the others leave): a
+  // graph whose rows are contiguous -- the trainer's are -- is added to by one lane in row order, the same bits every launch.
+  int r = blockIdx.x;
+  const int lane = threadIdx.x, graph = row_graph[r];
+  if (r > 0 && row_graph[r - 1] == graph) return;
+  double* g = grad + (size_t)graph * F;
+  for (; r < n_rows && row_graph[r] == graph; ++r) {
+    const double* t = priv_tables + (size_t)r * X;
+    double part = 0.0;
+    for (int x = lane; x < X; x += 64) part += t[x];
+    const double Z = wave_sum(part);
+    if (lane == 0) {
+      const int lab = row_label[r];
+      for (int q = item_off[r]; q < item_off[r + 1]; ++q) {
+        const int x = item_x[q];
+        const double belief = Z > 0.0 ? t[x] / Z : 0.0;
+        atomicAdd(&g[item_k[q]], item_val[q] * ((x == lab ? 1.0 : 0.0) - belief));   // (atomic: a graph split into several runs)
+      }
     }
   }
 }
@@ -653,7 +659,7 @@ int mlbp_patch_gradient_f64(const double* priv_tables, const int32_t* item_off, 
     return fail(MLBP_EINVAL, "mlbp_patch_gradient_f64: bad arguments");
   if (int e = need_device()) return e;
   hipLaunchKernelGGL(patch_gradient_kernel, dim3(n_rows), dim3(64), 0, (hipStream_t)stream, priv_tables, item_off, item_x,
-                     item_k, item_val, row_graph, row_label, X, F, grad);
+                     item_k, item_val, row_graph, row_label, n_rows, X, F, grad);
   HIP_TRY(hipGetLastError());
   return MLBP_OK;
 }

@@ -65,6 +65,8 @@ bool build_shared_readout(const SharedProgram& sp, int n_msgs, int n_vars, const
 // Enqueues the shared-table kernel when it applies (sets *launched); flagged graphs are left in
 // prog->d_bail for the exact kernel.
 int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched);
+// The same for several (program, arguments) groups in one launch sequence; *launched false = some group does not qualify.
+int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args* args, int n_groups, void* stream, bool* launched);
 // Pairwise part of the gradient for shared tables (X = 64, F_ee = 3), ADDED to a->grad_en_en.
 int launch_shared_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void* stream);
 // Shared tables at X = 128 .. 512: the sweeps update by update over the whole batch, every contraction one launch of the
@@ -109,6 +111,9 @@ struct mlbp_program {
   int32_t* d_gtable = nullptr;   // group table of mlbp_sweep_groups_f64 calls that name this program first (launch_lean_groups)
   size_t gtable_cap = 0;         // in words
   std::vector<int32_t> h_gtable; // what d_gtable holds (a call uploads only when its table differs)
+  int32_t* d_stable = nullptr;   // the same for the shared-table kernels (launch_shared_groups)
+  size_t stable_cap = 0;
+  std::vector<int32_t> h_stable;
   // shared-table form (mlbp_shared.hip)
   mlbp::SharedProgram shared;
   int32_t* d_simage;      // SharedProgram::image

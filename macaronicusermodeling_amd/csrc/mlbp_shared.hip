@@ -25,8 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <cstdio>
-#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -227,15 +226,6 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
     }
   }
   out.n_bundles = (int)bundles.size() / 8;
-  if (getenv("MLBP_DEBUG_BUNDLES")) {
-    for (int i = 0; i < n_ops; ++i) {
-      const int32_t* m = &mem[(size_t)i * MW];
-      fprintf(stderr, "op %2d flags %03x pslot %d dst %2d ct %2d gslot %2d src", i, m[0], m[1], m[2], m[3], m[4]);
-      for (int q = 0; q < ((m[0] >> 8) & 15); ++q) fprintf(stderr, " %d", m[8 + q]);
-      fprintf(stderr, "\n");
-    }
-    for (int b = 0; b < out.n_bundles; ++b) fprintf(stderr, "bundle %d: %08x %08x\n", b, bundles[8 * b], bundles[8 * b + 4]);
-  }
   pack_member(nop); pack_member(nop);                            // the kernel prefetches one bundle past the end
   // constant products, flattened: {unary factor, message slot, tile, 1 = first | 2 = last of its product}
   std::vector<int32_t> ent;
@@ -421,10 +411,24 @@ struct PrepareDev {
   double* ptiles; uint8_t* bail; int32_t* status;
   int32_t B, U, n_unary_tables, E, n_cprod, n_groups;
 };
-__global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d) {
+// MULTI: several groups of graphs (mlbp_sweep_groups_f64: every group its own program, tables, messages) in one launch;
+// gtab[k] = the group's PrepareDev, gstart[k] = its first block (ascending; gstart[n_groups] = the grid size).
+template <bool MULTI>
+__global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d, const PrepareDev* gtab, const int32_t* gstart, int n_groups) {
   ABL_DECL
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  for (int q = blockIdx.x; q < 2 * d.n_frag_tables; q += gridDim.x) {
+  int block = blockIdx.x, n_blocks = gridDim.x;
+  if (MULTI) {
+    int lo = 0, hi = n_groups - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (gstart[mid] <= block) lo = mid; else hi = mid - 1;
+    }
+    d = gtab[lo];
+    block -= gstart[lo];
+    n_blocks = gstart[lo + 1] - gstart[lo];
+  }
+  for (int q = block; q < 2 * d.n_frag_tables; q += n_blocks) {
     const int ti = q >> 1, mt = q & 1;
     const double* T = d.pair_tables + (size_t)ti * 4096;
     double* o = d.tfrag + ((size_t)ti * 2 + mt) * 4096;
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d) {
       o[e] = mt ? T[k * 64 + i] : T[i * 64 + k];
     }
   }
-  const int g = blockIdx.x * PGB + wave;
+  const int g = block * PGB + wave;
   if (g >= d.B) return;
   double* tiles_out = d.ptiles + (size_t)(g >> 4) * d.n_cprod * TILE;       // this graph is column g & 15 of its group's tiles
   const int col = g & 15;
@@ -514,14 +518,26 @@ __device__ __forceinline__ int index_in_half(int mode, int sel) { return ((mode 
 // three-sweep K3 program is 9 bundles instead of 18 updates, and every SIMD has four waves to interleave matrix work
 // with tile reads.  Which sets a half holds (one of three partitions) is chosen on the device from the program and the
 // batch's table indices so that as many bundles as possible split.
-template <int NTAB, bool SPILL, bool WIDE>
-__global__ __launch_bounds__(SWG, 4) void sweep_x64_shared_kernel(SharedDev d) {
+// MULTI: the launch holds several GROUPS of graphs, each with its own program and buffers (mlbp_sweep_groups_f64): gtab[k] is
+// group k's SharedDev, gstart[k] its first workgroup; the workgroup looks its group up and runs as if launched for it alone.
+template <int NTAB, bool SPILL, bool WIDE, bool MULTI>
+__global__ __launch_bounds__(SWG, 4) void sweep_x64_shared_kernel(SharedDev d, const SharedDev* gtab, const int32_t* gstart, int n_groups) {
+  int wg = blockIdx.x;
+  if (MULTI) {
+    int lo = 0, hi = n_groups - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (gstart[mid] <= wg) lo = mid; else hi = mid - 1;
+    }
+    d = gtab[lo];
+    wg -= gstart[lo];
+  }
   extern __shared__ double lds[];
   double* tiles = lds;                                           // [n_res][64 states][16 graphs]
   double* tot = tiles + (size_t)d.n_res * TILE;                  // [n_live][16 graphs][4 row blocks] partial column sums
   double2* dummy = reinterpret_cast<double2*>(tot + (size_t)d.n_live * 64);          // {1/64, 1/64}, {1, 1}, {0.25, 0.25} x 2: absent sources
   int32_t* limg = reinterpret_cast<int32_t*>(dummy + 4);                                    // [n_bundles + 1][8] the bundles (read one ahead, broadcast)
-  double* spill = SPILL ? d.spill + (size_t)blockIdx.x * (d.n_live - d.n_res) * TILE : nullptr;
+  double* spill = (SPILL && d.spill) ? d.spill + (size_t)wg * (d.n_live - d.n_res) * TILE : nullptr;
   // tile t: LDS when resident, else this workgroup's slice of the global spill area (same [state][graph] layout;
   // __syncthreads orders the workgroup's global accesses as it does the LDS ones)
   auto TP = [&](int tile) -> double* {
@@ -531,7 +547,7 @@ __global__ __launch_bounds__(SWG, 4) void sweep_x64_shared_kernel(SharedDev d) {
   const int t = threadIdx.x, lane = t & 63, lane_ = lane, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int half = wave >> 2, rb = wave & 3;
   const int gl = lane & 15, cq = lane >> 4;                      // B/D operand: graph column, k-row
-  const int g0 = blockIdx.x * G;
+  const int g0 = wg * G;
   const int gi = g0 + gl;
   const bool gvalid = gi < d.B;
   const int gc = gvalid ? gi : d.B - 1;                          // tail columns replay the last graph, outputs masked
@@ -550,7 +566,7 @@ __global__ __launch_bounds__(SWG, 4) void sweep_x64_shared_kernel(SharedDev d) {
   for (int i = t; i < 2 * MW * (d.n_bundles + 1); i += SWG) limg[i] = d.image[i];
   if (t < 4) dummy[t] = t == 0 ? make_double2(1.0 / 64.0, 1.0 / 64.0) : (t == 1 ? make_double2(1.0, 1.0) : make_double2(0.25, 0.25));
   {
-    const double2* src = reinterpret_cast<const double2*>(d.ptiles + (size_t)blockIdx.x * d.n_cprod * TILE);
+    const double2* src = reinterpret_cast<const double2*>(d.ptiles + (size_t)wg * d.n_cprod * TILE);
     for (int k = 0; k < d.n_cprod; ++k) {
       const int tile = img[d.off_ptile + k];
       reinterpret_cast<double2*>(TP(tile))[t] = src[(size_t)k * (TILE / 2) + t];        // SWG threads x 16 bytes = one tile
@@ -689,7 +705,7 @@ __global__ __launch_bounds__(SWG, 4) void sweep_x64_shared_kernel(SharedDev d) {
       r0a = src0[0]; r0b = src0[of0];
       r1a = src1[0]; r1b = src1[of1];
       const double t0 = (ta.x + ta.y) + (tb.x + tb.y), t1 = (tc.x + tc.y) + (td.x + td.y);
-      bad |= !total_ok(t0) | !total_ok(t1);
+      bad |= (int)!total_ok(t0) | (int)!total_ok(t1);
       scale = __builtin_amdgcn_rcp(t0) * __builtin_amdgcn_rcp(t1);
     } else {
 #pragma unroll 1
@@ -1069,30 +1085,49 @@ __global__ __launch_bounds__(WG) void gradient_shared_pairs_kernel(PairGradDev d
 
 std::mutex g_attr_mutex;
 
-template <int NTAB, bool SPILL, bool WIDE>
-int launch(const SharedDev& d, size_t lds, hipStream_t st) {
-  static size_t granted = 0;
+typedef void (*sweep_fn)(SharedDev, const SharedDev*, const int32_t*, int);
+
+// the instance for (two tables?, spilled tiles?, more than two sources?, groups?); raises its dynamic LDS limit once
+int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, size_t lds, sweep_fn* out) {
+  sweep_fn k = nullptr;
+#ifdef MLBP_STAMPS      // the diagnostic build instantiates the all-resident two-source kernels only
+  if (spill || wide || multi) return fail(MLBP_EUNSUPPORTED, "stamps build: no spilling / wide / grouped instance");
+  k = two ? sweep_x64_shared_kernel<2, false, false, false> : sweep_x64_shared_kernel<1, false, false, false>;
+#else
+#define MLBP_SK(T, S, W, M) sweep_x64_shared_kernel<T, S, W, M>
+#define MLBP_SK_M(T, S, W) (multi ? MLBP_SK(T, S, W, true) : MLBP_SK(T, S, W, false))
+#define MLBP_SK_W(T, S) (wide ? MLBP_SK_M(T, S, true) : MLBP_SK_M(T, S, false))
+#define MLBP_SK_S(T) (spill ? MLBP_SK_W(T, true) : MLBP_SK_W(T, false))
+  k = two ? MLBP_SK_S(2) : MLBP_SK_S(1);
+#undef MLBP_SK_S
+#undef MLBP_SK_W
+#undef MLBP_SK_M
+#undef MLBP_SK
+#endif
+  static std::vector<std::pair<const void*, size_t>> granted;
   {
     std::lock_guard<std::mutex> lock(g_attr_mutex);
-    if (lds > granted) {
-      hipError_t e = hipFuncSetAttribute((const void*)sweep_x64_shared_kernel<NTAB, SPILL, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    bool have = false;
+    for (auto& g : granted) have |= g.first == (const void*)k && g.second >= lds;
+    if (!have) {
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return fail(MLBP_EHIP, "hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      granted = lds;
+      granted.push_back({(const void*)k, lds});
       int per_cu = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sweep_x64_shared_kernel<NTAB, SPILL, WIDE>, SWG, lds) == hipSuccess)
-        fail(MLBP_OK, "shared-table kernel <%d%s%s>: %zu bytes of LDS per workgroup, %d workgroups per CU", NTAB, SPILL ? ", spilling" : "", WIDE ? ", wide" : "", lds, per_cu);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, SWG, lds) == hipSuccess)
+        fail(MLBP_OK, "shared-table kernel <%d%s%s%s>: %zu bytes of LDS per workgroup, %d workgroups per CU", two ? 2 : 1,
+             spill ? ", spilling" : "", wide ? ", wide" : "", multi ? ", groups" : "", lds, per_cu);
     }
   }
-  hipLaunchKernelGGL((sweep_x64_shared_kernel<NTAB, SPILL, WIDE>), dim3((d.B + G - 1) / G), dim3(SWG), lds, st, d);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed: %s", hipGetErrorString(e));
+  *out = k;
   return MLBP_OK;
 }
 
-}  // namespace
-
-int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched) {
-  *launched = false;
+// What a shared-table sweep of (prog, a) needs: the two device descriptions, the LDS size, the grid sizes.  *ok false: the
+// kernel does not apply (mlbp_last_error says why).  Allocates the program's scratch on first use.
+struct SharedPlan { SharedDev d; PrepareDev q; size_t lds; int n_wg, n_prep_blocks; bool wide, spill; };
+int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, SharedPlan* out) {
+  *ok = false;
   const SharedProgram& sp = prog->shared;
   if (!(a->flags & MLBP_SWEEP_SHARED_PAIR_TABLES)) return MLBP_OK;
   if (a->X != 64 || !a->normalize_messages || !a->init_messages)
@@ -1100,7 +1135,6 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   if (!sp.ok || !prog->d_simage) return fail(MLBP_OK, "shared-table kernel not used: %s", sp.why);
   if (a->marginals && !prog->d_sreadout)
     return fail(MLBP_OK, "shared-table kernel not used: a variable's constant messages match no folded product");
-  const int ntab = prog->P >= 2 ? 2 : 1;
   // resident tiles: as many as fit HALF the CU's LDS, so that two workgroups share a CU (constant products and
   // factor->variable messages come first in the numbering); the rest spill to global memory.  Measured on K4 user
   // graphs (21 tiles): 8 resident + 13 spilled with two workgroups per CU 0.216 ms, 16 resident + 5 spilled with
@@ -1131,8 +1165,7 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   }
   if (mp->bail_cap < a->B)
     if (int e = mlbp_program_reserve(mp, a->B)) return e;
-  hipStream_t st = (hipStream_t)stream;
-  SharedDev d;
+  SharedDev& d = out->d;
   d.pair_tables = a->pair_tables; d.pair_tab = a->pair_tab; d.unary_tables = a->unary_tables; d.unary_tab = a->unary_tab;
   d.msgs = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && !a->gradient) ? nullptr : a->msgs;
   d.vf_only = ((a->flags & MLBP_SWEEP_NO_MESSAGE_WRITEBACK) && a->gradient) ? 1 : 0;
@@ -1153,35 +1186,107 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
     }
     d.tfrag = mp->d_tfrag;
   }
-  {
-    // one launch in front of the sweeps: constant products as tiles, the per-graph flags (cleared or raised), table fragments
-    PrepareDev q;
-    q.pair_tables = a->pair_tables; q.tfrag = d.tfrag ? mp->d_tfrag : nullptr; q.n_frag_tables = d.tfrag ? a->n_pair_tables : 0;
-    q.unary_tables = a->unary_tables; q.unary_tab = a->unary_tab; q.ent = prog->d_simage + sp.off_ent;
-    q.ptiles = mp->d_ptiles; q.bail = mp->d_bail; q.status = prog->d_status;
-    q.B = a->B; q.U = prog->U; q.n_unary_tables = a->n_unary_tables; q.E = sp.n_cpw / 4; q.n_cprod = n_cprod; q.n_groups = n_groups;
-    hipLaunchKernelGGL(shared_prepare_kernel, dim3((a->B + PGB - 1) / PGB), dim3(PWG), 0, st, q);
-    if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
+  // one launch in front of the sweeps: constant products as tiles, the per-graph flags (cleared or raised), table fragments
+  PrepareDev& q = out->q;
+  q.pair_tables = a->pair_tables; q.tfrag = d.tfrag ? mp->d_tfrag : nullptr; q.n_frag_tables = d.tfrag ? a->n_pair_tables : 0;
+  q.unary_tables = a->unary_tables; q.unary_tab = a->unary_tab; q.ent = prog->d_simage + sp.off_ent;
+  q.ptiles = mp->d_ptiles; q.bail = mp->d_bail; q.status = prog->d_status;
+  q.B = a->B; q.U = prog->U; q.n_unary_tables = a->n_unary_tables; q.E = sp.n_cpw / 4; q.n_cprod = n_cprod; q.n_groups = n_groups;
+  out->lds = lds; out->n_wg = n_groups; out->n_prep_blocks = (a->B + PGB - 1) / PGB;
+  out->wide = sp.max_sources > 2; out->spill = d.spill != nullptr;
+  *ok = true;
+  return MLBP_OK;
+}
+
+// unary factor -> variable messages of the call, written back behind the sweeps when the caller wants the message buffer
+int enqueue_unary_writeback(const mlbp_program* prog, const mlbp_sweep_args* a, const SharedDev& d, hipStream_t st) {
+  const SharedProgram& sp = prog->shared;
+  if (!(d.msgs && !d.vf_only && sp.n_cpw > 0)) return MLBP_OK;
+  const int E = sp.n_cpw / 4;
+  const long long rows = (long long)a->B * E;
+  hipLaunchKernelGGL(unary_writeback_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(WG), 0, st, a->unary_tables, a->unary_tab,
+                     prog->d_simage + sp.off_ent, E, a->B, prog->U, a->n_unary_tables, prog->n_msgs, a->msgs);
+  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "unary write-back launch failed");
+  return MLBP_OK;
+}
+
+}  // namespace
+
+int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched) {
+  *launched = false;
+  SharedPlan pl;
+  bool ok = false;
+  if (int e = shared_plan(prog, a, &ok, &pl)) return e;
+  if (!ok) return MLBP_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(shared_prepare_kernel<false>, dim3(pl.n_prep_blocks), dim3(PWG), 0, st, pl.q, nullptr, nullptr, 0);
+  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
+  sweep_fn k = nullptr;
+  if (int e = pick_sweep_kernel(prog->P >= 2, pl.spill, pl.wide, false, pl.lds, &k)) return e;
+  hipLaunchKernelGGL(k, dim3(pl.n_wg), dim3(SWG), pl.lds, st, pl.d, nullptr, nullptr, 0);
+  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed");
+  if (int e = enqueue_unary_writeback(prog, a, pl.d, st)) return e;
+  *launched = true;
+  return MLBP_OK;
+}
+
+// Several (program, arguments) groups in ONE launch sequence (prepare + sweeps) of the shared-table kernels -- a minibatch of
+// mixed sentence shapes whose pairwise factors all read the two shared pots (train_mp.py:220-255, 257-299).  *launched stays
+// false when some group does not qualify.  The group tables live in a device buffer owned by the first program and are
+// uploaded only when their contents change (like the lean kernel's).
+int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args* args, int n_groups, void* stream, bool* launched) {
+  *launched = false;
+  if (n_groups < 1) return MLBP_OK;
+  std::vector<SharedPlan> plans(n_groups);
+  size_t lds = 0;
+  bool wide = false, spill = false, two = false;
+  for (int k = 0; k < n_groups; ++k) {
+    if (!progs[k]) return MLBP_OK;
+    for (int j = 0; j < k; ++j)
+      if (progs[j] == progs[k]) return MLBP_OK;      // two groups would share one set of redo flags and scratch
+    bool ok = false;
+    if (int e = shared_plan(progs[k], &args[k], &ok, &plans[k])) return e;
+    if (!ok) return MLBP_OK;
+    lds = std::max(lds, plans[k].lds);
+    wide |= plans[k].wide; spill |= plans[k].spill; two |= progs[k]->P >= 2;
   }
-  const bool wide = sp.max_sources > 2;
-#ifdef MLBP_STAMPS      // the diagnostic build instantiates the all-resident two-source kernels only
-  if (d.spill || wide) return fail(MLBP_EUNSUPPORTED, "stamps build: no spilling / wide instance");
-  int e = ntab == 2 ? launch<2, false, false>(d, lds, st) : launch<1, false, false>(d, lds, st);
-#else
-  int e;
-  if (wide) e = d.spill ? (ntab == 2 ? launch<2, true, true>(d, lds, st) : launch<1, true, true>(d, lds, st))
-                        : (ntab == 2 ? launch<2, false, true>(d, lds, st) : launch<1, false, true>(d, lds, st));
-  else e = d.spill ? (ntab == 2 ? launch<2, true, false>(d, lds, st) : launch<1, true, false>(d, lds, st))
-                   : (ntab == 2 ? launch<2, false, false>(d, lds, st) : launch<1, false, false>(d, lds, st));
-#endif
-  if (e) return e;
-  if (d.msgs && !d.vf_only && sp.n_cpw > 0) {
-    const int E = sp.n_cpw / 4;
-    const long long rows = (long long)a->B * E;
-    hipLaunchKernelGGL(unary_writeback_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(WG), 0, st, a->unary_tables, a->unary_tab,
-                       prog->d_simage + sp.off_ent, E, a->B, prog->U, a->n_unary_tables, prog->n_msgs, a->msgs);
-    if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "unary write-back launch failed");
+  // table image: [SharedDev x n][PrepareDev x n][sweep starts n + 1][prepare starts n + 1], as 32-bit words
+  const size_t w_sd = sizeof(SharedDev) / 4, w_pd = sizeof(PrepareDev) / 4;
+  static_assert(sizeof(SharedDev) % 8 == 0 && sizeof(PrepareDev) % 8 == 0, "group tables are copied as words");
+  std::vector<int32_t> table((w_sd + w_pd) * n_groups + 2 * (n_groups + 1));
+  int wg = 0, pb = 0;
+  int32_t* starts = table.data() + (w_sd + w_pd) * n_groups;
+  for (int k = 0; k < n_groups; ++k) {
+    memcpy(table.data() + w_sd * k, &plans[k].d, sizeof(SharedDev));
+    memcpy(table.data() + w_sd * n_groups + w_pd * k, &plans[k].q, sizeof(PrepareDev));
+    starts[k] = wg; starts[n_groups + 1 + k] = pb;
+    wg += plans[k].n_wg; pb += plans[k].n_prep_blocks;
   }
+  starts[n_groups] = wg; starts[2 * n_groups + 1] = pb;
+  mlbp_program* owner = const_cast<mlbp_program*>(progs[0]);
+  if (table.size() > owner->stable_cap) {
+    (void)hipFree(owner->d_stable);
+    owner->d_stable = nullptr; owner->stable_cap = 0; owner->h_stable.clear();
+    if (hipMalloc(&owner->d_stable, table.size() * sizeof(int32_t)) != hipSuccess) return fail(MLBP_EHIP, "group table allocation failed");
+    owner->stable_cap = table.size();
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (owner->h_stable != table) {
+    owner->h_stable = table;
+    if (hipMemcpyAsync(owner->d_stable, owner->h_stable.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess)
+      return fail(MLBP_EHIP, "group table upload failed");
+  }
+  const SharedDev* d_sd = reinterpret_cast<const SharedDev*>(owner->d_stable);
+  const PrepareDev* d_pd = reinterpret_cast<const PrepareDev*>(owner->d_stable + w_sd * n_groups);
+  const int32_t* d_starts = owner->d_stable + (w_sd + w_pd) * n_groups;
+  hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), 0, st, plans[0].q, d_pd, d_starts + n_groups + 1, n_groups);
+  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
+  sweep_fn k = nullptr;
+  if (int e = pick_sweep_kernel(two, spill, wide, true, lds, &k)) return e;
+  hipLaunchKernelGGL(k, dim3(wg), dim3(SWG), lds, st, plans[0].d, d_sd, d_starts, n_groups);
+  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed");
+  for (int g = 0; g < n_groups; ++g)
+    if (int e = enqueue_unary_writeback(progs[g], &args[g], plans[g].d, st)) return e;
   *launched = true;
   return MLBP_OK;
 }

@@ -1157,6 +1157,7 @@ void build_fused_program(const int32_t* ops_in, const int32_t* srcs, const int32
 int g_sweep_variant = 1;
 thread_local int g_last_kernel = -1;       // mlbp_last_sweep_kernel()
 thread_local bool g_lean_predone = false;  // set by mlbp_sweep_groups_f64 around the per-group fix-up calls
+thread_local bool g_shared_predone = false;   // the same when the shared-table kernels ran the groups
 int sweep_variant() { return g_sweep_variant; }
 
 // hipFuncSetAttribute is a slow host call (~0.1 ms); remember the largest dynamic-LDS size already
@@ -1421,7 +1422,7 @@ int mlbp_program_destroy(mlbp_program* p) {
   (void)hipFree(p->d_ops); (void)hipFree(p->d_srcs); (void)hipFree(p->d_sweeps);
   (void)hipFree(p->d_pairseq); (void)hipFree(p->d_status);
   (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq); (void)hipFree(p->d_bail); (void)hipFree(p->d_readout);
-  (void)hipFree(p->d_limage); (void)hipFree(p->d_lreadout); (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout); (void)hipFree(p->d_tfrag); (void)hipFree(p->d_spill); (void)hipFree(p->d_gtable); (void)hipFree(p->d_ptiles);
+  (void)hipFree(p->d_limage); (void)hipFree(p->d_lreadout); (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout); (void)hipFree(p->d_tfrag); (void)hipFree(p->d_spill); (void)hipFree(p->d_gtable); (void)hipFree(p->d_ptiles); (void)hipFree(p->d_stable);
   delete p;
   return MLBP_OK;
 }
@@ -1486,7 +1487,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
           return fail(MLBP_EINVAL, "mlbp_sweep_f64: gradient arguments do not describe the same batch");
         grad_fused = norm && ga->F_ee == 3 && ga->F_ed == 6 && nt >= 1 && prog->n_hoist == prog->U && prog->U <= WG &&
                      ga->phi_en_en_t && ga->phi_en_en_w1_t && ga->phi_en_de_t && !(ga->flags & MLBP_GRADIENT_APPROX_BELIEFS) &&
-                     !g_lean_predone;
+                     !g_lean_predone && !g_shared_predone;
         if (grad_fused) {
           gf.pair_c_slot = ga->pair_c_slot; gf.pair_r_slot = ga->pair_r_slot; gf.pair_phi = ga->pair_phi; gf.pair_label = ga->pair_label;
           gf.unary_kind = ga->unary_kind; gf.unary_obs = ga->unary_obs; gf.unary_label = ga->unary_label;
@@ -1496,7 +1497,8 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
         }
       }
       bool shared_done = false;                // shared-table batches: 16 graphs per workgroup on the matrix cores
-      if (fast && !g_lean_predone)
+      if (g_shared_predone) shared_done = true;  // mlbp_sweep_groups_f64 ran the shared-table kernels for this group already
+      else if (fast && !g_lean_predone)
         if (int e = mlbp::launch_shared_sweep(prog, a, stream, &shared_done)) return e;
       if (shared_done) { grad_fused = false; gf = GradFusedDev{}; }
       bool lean_done = false;                  // default path: the lean scale-free kernel (mlbp_lean.hip), up to 8 resident tables
@@ -1635,14 +1637,19 @@ int mlbp_sweep_groups_f64(const mlbp_program* const* progs, const mlbp_sweep_arg
     eff[k] = effective_program(progs[k], &args[k]);
   }
   progs = eff.data();
+  bool shared_launch = false;
   if (sweep_variant() == 1)
+    if (int e = mlbp::launch_shared_groups(progs, args, n_groups, stream, &shared_launch)) return e;
+  if (sweep_variant() == 1 && !shared_launch)
     if (int e = mlbp::launch_lean_groups(progs, args, n_groups, stream, &one_launch)) return e;
   // the fast kernel has run every group (one_launch): what is left per group is the fix-up pass over the graphs it
   // flagged; otherwise the groups run one after the other exactly as separate calls would
   int rc = MLBP_OK;
   g_lean_predone = one_launch;
+  g_shared_predone = shared_launch;
   for (int k = 0; k < n_groups && rc == MLBP_OK; ++k) rc = mlbp_sweep_f64(progs[k], &args[k], stream);
   g_lean_predone = false;
+  g_shared_predone = false;
   return rc;
 }
 

@@ -350,27 +350,29 @@ class _BucketSet:
                                                   planes=planes, skip_unchanged=o.skip_unchanged, **extra)
 
     def statistics_into(self, stats, grouped_sweeps):
-        """Adds the buckets' statistics to `stats`.  grouped_sweeps: the sweeps of ALL sentence shapes in one launch
-        (batch.sweep_groups -> mlbp_sweep_groups_f64: every bucket its own topology and roots) instead of one
-        launch sequence per bucket -- what a minibatch of many small buckets wants; large buckets are better off on
-        their own shared-table launches (the default 'auto' switches at 1024 instances per bucket on average)."""
+        """Adds the buckets' statistics to `stats`.  grouped_sweeps: the sweeps of ALL sentence shapes with pairwise factors
+        in one launch sequence (batch.sweep_groups -> mlbp_sweep_groups_f64: every bucket its own topology and roots;
+        the shared-table kernels take a group table) instead of one launch sequence per bucket; 'auto' groups whenever
+        two or more buckets qualify."""
         trs = list(self.trainers.values())
         if not trs:
             return
-        n_inst = sum(tr.batch.B for tr in trs)
-        grouped = grouped_sweeps is True or (grouped_sweeps == 'auto' and len(trs) > 1 and n_inst < 1024 * len(trs))
-        grouped = grouped and all(tr.topo.P >= 1 and tr.batch.X == 64 for tr in trs)
-        if not grouped:
-            for tr in trs:
+        together = [tr for tr in trs if tr.topo.P >= 1 and tr.batch.X == 64] if grouped_sweeps else []
+        if len(together) < 2 and grouped_sweeps is not True:
+            together = []
+        for tr in trs:
+            if not any(tr is t for t in together):
                 stats += tr.local_statistics()
+        if not together:
             return
         from .batch import sweep_groups
-        for tr in trs:
+        for tr in together:
             tr.build_potentials()
-        sweep_groups([tr.batch for tr in trs], [tr.roots[:tr.n_sweeps_run] for tr in trs], init=True,
-                     marginals=[tr._marg for tr in trs])
-        for tr in trs:
-            stats += tr._statistics_after_sweep(gradient_from_messages=True)
+        sweep_groups([tr.batch for tr in together], [tr.roots[:tr.n_sweeps_run] for tr in together], init=True,
+                     marginals=[tr._marg for tr in together], gradients=[(tr._g_ee, tr._g_ed) for tr in together],
+                     keep_messages=False)
+        for tr in together:
+            stats += tr._statistics_after_sweep()
 
 
 class TiDirTrainer:

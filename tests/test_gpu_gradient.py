@@ -406,9 +406,9 @@ def test_tidir_trainer_user_adapt(tmp_path):
 
 
 def test_tidir_trainer_sweeps_all_sentence_shapes_in_one_launch(tmp_path):
-    """TiDirTrainer(grouped_sweeps=True): the sweeps of every bucket (its own topology and roots) run as ONE launch of
-    the fast kernel (mlbp_sweep_groups_f64), the gradient then reads the messages from memory.  Same statistics as
-    the per-bucket launch sequences, and training moves theta the same way."""
+    """TiDirTrainer(grouped_sweeps=True): the sweeps of every bucket (its own topology and roots) run as ONE launch
+    sequence of the shared-table matrix-core kernels (mlbp_sweep_groups_f64 -> a group table), each bucket's gradient
+    launch follows.  Same statistics as the per-bucket launch sequences, and training moves theta the same way."""
     from macaronicusermodeling_amd import _ffi, tidir
     from macaronicusermodeling_amd.train import TiDirTrainer
     paths = tidir.synthesize(str(tmp_path), n_instances=40, X=64, Vde=64, sent_len=(4, 7), n_predicted=(2, 3), seed=21)
@@ -420,7 +420,8 @@ def test_tidir_trainer_sweeps_all_sentence_shapes_in_one_launch(tmp_path):
         t.theta_en_en += torch.tensor([0.3, -0.2, 0.1], dtype=torch.float64, device=t.theta_en_en.device)
         t.theta_en_de += torch.tensor([0.2, 0.1, -0.3, 0.05, 0.0, 0.1], dtype=torch.float64, device=t.theta_en_de.device)
     sa = a.local_statistics().clone()
-    assert _ffi.lib.mlbp_last_sweep_kernel() == 7       # the lean kernel ran the groups
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 3       # MLBP_KERNEL_SHARED_MFMA ran the groups
+    assert sum(tr.batch.program(tr.roots[:tr.n_sweeps_run]).exact_count(tr.batch.B) for tr in a._full.trainers.values()) == 0
     sb = b.local_statistics().clone()
     np.testing.assert_allclose(sa.cpu().numpy(), sb.cpu().numpy(), rtol=1e-9, atol=1e-12)
     ha, hb = a.train(epochs=2, reg_param=0.2), b.train(epochs=2, reg_param=0.2)

@@ -352,3 +352,42 @@ def test_large_state_shared_float32_tables_on_the_f32_matrix_cores(X):
     print('X=%d f32 MFMA path: vs f64 contraction on rounded tables %.2e (messages) %.2e (marginals); vs unrounded oracle %.2e'
           % (X, rel_arith, rel_marg, worst))
     assert rel_arith < 2e-6 and rel_marg < 2e-6 and worst < 1e-5
+
+
+def test_groups_of_mixed_shapes_in_one_shared_launch_sequence():
+    """mlbp_sweep_groups_f64 over four topologies (K2, two K3, K4 -- the last one spills tiles and has three-source
+    updates), each with its own roots, batch size (partial last groups of 16) and tables: ONE prepare + ONE sweep launch of
+    the shared-table kernels behind a group table.  Same bits as the four single launch sequences, the oracle's values, a
+    degenerate graph of one group redone by the exact kernel."""
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.batch import sweep_groups
+    names, sizes = ['user_k2', 'user_k3_gaps_1_2_3', 'user_k4', 'user_k3_gaps_3_6'], [5, 37, 18, 16]
+
+    def mutate(inputs):
+        inputs[3]['pot_en_de'] = inputs[3]['pot_en_de'].copy(); inputs[3]['pot_en_de'][:, :] = 0.0
+    built = [_shared_batch(SPECS[n](), B, seed=11 + k, mutate=mutate if k == 1 else None) for k, (n, B) in enumerate(zip(names, sizes))]
+    roots = [(list(topo.var_ids) * 3)[k:k + 3] for k, (_, topo, _) in enumerate(built)]
+    single_msgs, single_marg = [], []
+    for (fb, topo, _), r in zip(built, roots):
+        m = torch.empty(fb.B, topo.n_vars, 64, dtype=torch.float64, device=fb.device)
+        fb.sweep(r, init=True, marginals=m)
+        assert _ffi.lib.mlbp_last_sweep_kernel() == KERNEL_SHARED_MFMA
+        single_msgs.append(fb.msgs.clone()); single_marg.append(m)
+        fb.msgs.fill_(float('nan'))
+    margs = [torch.full_like(m, float('nan')) for m in single_marg]
+    progs = sweep_groups([fb for fb, _, _ in built], roots, init=True, marginals=margs)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == KERNEL_SHARED_MFMA, _ffi.lib.mlbp_last_error()
+    assert [p.exact_count(B) for p, B in zip(progs, sizes)] == [0, 1, 0, 0]
+    for k, (fb, topo, inputs) in enumerate(built):
+        assert torch.equal(fb.msgs, single_msgs[k]) and torch.equal(margs[k], single_marg[k])
+        got = fb.msgs.cpu().numpy()
+        with np.errstate(all='ignore'):
+            for b in range(0, fb.B, 3):
+                _, _, want = oracle_msgs(SPECS[names[k]](), inputs[b], roots[k])
+                np.testing.assert_allclose(got[b], want, rtol=RTOL, atol=1e-300)
+    # a second call with other batch contents re-uses the uploaded group table; one group that does not qualify
+    # (no shared-table claim) sends the whole call to the per-group path
+    built[0][0].pair_tables_shared = False
+    sweep_groups([fb for fb, _, _ in built], roots, init=True, marginals=margs)
+    for k, (fb, _, _) in enumerate(built):
+        np.testing.assert_allclose(fb.msgs.cpu().numpy(), single_msgs[k].cpu().numpy(), rtol=1e-11, atol=1e-300)

@@ -284,6 +284,10 @@ int mlbp_set_sweep_variant(int32_t variant);
 #define MLBP_KERNEL_SHARED_GEMM 6
 #define MLBP_KERNEL_LEAN 7            /* scale-free X <= 64 kernel, micro-op form (mlbp_lean.hip): the default */
 int mlbp_last_sweep_kernel(void);
+/* Diagnostic: 1 when that call's gradient (mlbp_sweep_args.gradient) ran as the epilogue of the sweep kernels themselves --
+ * tables and final messages still on chip: MLBP_KERNEL_LEAN and MLBP_KERNEL_SHARED_MFMA with F = (3, 6) and at most three
+ * pairwise factors -- 0 when a separate gradient launch followed the sweeps (or none was asked for). */
+int mlbp_last_sweep_fused_gradient(void);
 
 /* Fills msgs[B][n_msgs][X] with 1/X: FactorGraph.initialize (LBP.py:211-216). */
 int mlbp_init_messages_f64(double* msgs, int64_t n_rows, int32_t X, void* stream);
@@ -413,6 +417,14 @@ int mlbp_sum_rows_f64(const double* in, int64_t rows, int32_t cols, double* out,
  * [sum grad_en_en | sum grad_en_de | sum log-posterior | count] without assembling a matrix. */
 int mlbp_sum_rows_cat_f64(const double* in0, int32_t cols0, const double* in1, int32_t cols1, const double* in2,
                           int32_t cols2, int64_t rows, int32_t append_count, double* out, void* stream);
+
+/* One optimisation step's batch statistics in ONE launch: out = [sum_b grad_en_en[b][:] | sum_b grad_en_de[b][:] |
+ * sum_b log-posterior(b) | B], the log-posterior of FactorGraph.get_posterior_probs (LBP.py:247-259: sum_v
+ * log marginals[b][v][labels[b][v]], -inf replaced by -99.99) computed on the fly -- what mlbp_log_posterior_f64 followed
+ * by mlbp_sum_rows_cat_f64 produce, the same bits (train_mp.py:405-424's accumulation).  lp_out: optional DEVICE [B], receives the
+ * per-graph log-posteriors.  A label outside [0, X) is skipped and raises mlbp_gradient_status. */
+int mlbp_step_statistics_f64(const double* grad_en_en, int32_t F_ee, const double* grad_en_de, int32_t F_ed, const double* marginals,
+                             const int32_t* labels, int32_t n_vars, int32_t X, int64_t B, double* lp_out, double* out, void* stream);
 
 /* out[s][j] = sum of in[b][j] over the rows with seg_id[b] == s (DEVICE int32 [rows], values in [0, n_seg)), fixed
  * order: the per-domain sums of batch_sgd_accumulate under --user_adapt / --experience_adapt (train_mp.py:413-415). */

@@ -77,6 +77,7 @@ SIGNATURES = {
     'mlbp_last_error': (C.c_char_p, []),
     'mlbp_device_count': (C.c_int, []),
     'mlbp_last_sweep_kernel': (C.c_int, []),
+    'mlbp_last_sweep_fused_gradient': (C.c_int, []),
     'mlbp_has_loops': (C.c_int, [C.POINTER(Topology), _i32]),
     'mlbp_message_schedule': (C.c_int, [C.POINTER(Topology), _i32, _i32p, _i32]),
     'mlbp_message_slots': (C.c_int, [C.POINTER(Topology), _i32p, _i32p, _i32p, _i32p]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     'mlbp_sum_rows_f64': (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     'mlbp_sum_rows_cat_f64': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp]),
     'mlbp_segment_sum_rows_f64': (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp]),
+    'mlbp_step_statistics_f64': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp]),
     'mlbp_dense_dot_f64': (C.c_int, [_i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _vp, _i64, _i64,
                                      _i64, _vp, _i64, _i64, _vp]),
     'mlbp_pointwise_multiply_f64': (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),

@@ -379,7 +379,12 @@ constexpr int SUM_PARTS = 64;
 __device__ double g_sum_partials[SUM_PARTS * 64];
 __device__ unsigned g_sum_done = 0;
 
-struct SumCat { const double* in[3]; int cols[3]; };       // up to three [rows][cols_i] arrays read as one [rows][sum cols] matrix
+// up to three [rows][cols_i] arrays read as one [rows][sum cols] matrix; with `marg` the third array's single column is not
+// read but computed: row b's log-posterior sum_v log marg[b][v][labels[b][v]] (LBP.py:247-259), also stored to lp_out if given
+struct SumCat {
+  const double* in[3]; int cols[3];
+  const double* marg; const int32_t* labels; int n_vars, X; double* lp_out; int32_t* status;
+};
 
 __global__ __launch_bounds__(WG) void sum_rows_kernel(SumCat cat, int64_t rows, int append_count, double* out) {
   // every thread sums ALL columns of its rows (fixed order), the columns then meet once: lanes by DPP, waves through
@@ -396,6 +401,19 @@ __global__ __launch_bounds__(WG) void sum_rows_kernel(SumCat cat, int64_t rows, 
     for (int j0 = 0; j0 < cols; j0 += 8) {                 // eight columns at a time in registers
       const int nj = cols - j0 < 8 ? cols - j0 : 8;
       double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      if (a == 2 && cat.marg) {
+        for (int64_t b = r0 + threadIdx.x; b < r1; b += WG) {
+          double total = 0.0;
+          for (int v = 0; v < cat.n_vars; ++v) {
+            const int lab = cat.labels[b * cat.n_vars + v];
+            if ((unsigned)lab >= (unsigned)cat.X) { atomicExch(cat.status, 1); continue; }
+            const double lp = log(cat.marg[(b * cat.n_vars + v) * cat.X + lab]);
+            total += (lp == -__builtin_huge_val()) ? -99.99 : lp;  // LBP.py:254-256
+          }
+          if (cat.lp_out) cat.lp_out[b] = total;
+          acc[0] += total;
+        }
+      } else
       for (int64_t b = r0 + threadIdx.x; b < r1; b += WG) {
         const double* row = in + b * cols + j0;
 #pragma unroll
@@ -617,9 +635,23 @@ int mlbp_sum_rows_cat_f64(const double* in0, int32_t cols0, const double* in1, i
   if (int e = need_device()) return e;
   if ((int64_t)cols0 + cols1 + cols2 > 64)
     return fail(MLBP_EUNSUPPORTED, "mlbp_sum_rows: at most 64 columns (got %d)", cols0 + cols1 + cols2);
-  SumCat cat = {{in0, in1, in2}, {cols0, cols1, cols2}};
+  SumCat cat = {{in0, in1, in2}, {cols0, cols1, cols2}, nullptr, nullptr, 0, 0, nullptr, nullptr};
   // the partials live in one device-wide scratch array: launches on DIFFERENT streams must not overlap
   hipLaunchKernelGGL(sum_rows_kernel, dim3(SUM_PARTS), dim3(WG), 0, (hipStream_t)stream, cat, rows, append_count ? 1 : 0, out);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_step_statistics_f64(const double* grad_en_en, int32_t F_ee, const double* grad_en_de, int32_t F_ed, const double* marginals,
+                             const int32_t* labels, int32_t n_vars, int32_t X, int64_t B, double* lp_out, double* out, void* stream) {
+  if (!grad_en_en || !grad_en_de || !marginals || !labels || !out || B <= 0 || F_ee <= 0 || F_ed <= 0 || n_vars <= 0 || X <= 0)
+    return fail(MLBP_EINVAL, "mlbp_step_statistics_f64: bad arguments");
+  if (F_ee + F_ed + 1 > 64) return fail(MLBP_EUNSUPPORTED, "mlbp_step_statistics_f64: at most 63 feature columns (got %d)", F_ee + F_ed);
+  if (int e = need_device()) return e;
+  SumCat cat = {{grad_en_en, grad_en_de, marginals}, {F_ee, F_ed, 1}, marginals, labels, n_vars, X, lp_out, nullptr};
+  if (int e = status_word(&cat.status)) return e;
+  // (the partials live in one device-wide scratch array, as for mlbp_sum_rows_cat_f64)
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(SUM_PARTS), dim3(WG), 0, (hipStream_t)stream, cat, B, 1, out);
   HIP_TRY(hipGetLastError());
   return MLBP_OK;
 }

@@ -48,7 +48,7 @@ struct SharedProgram {
   bool ok = false;
   const char* why = "";               // when !ok: what rules the program out
   int n_ops = 0, n_live = 0, n_cpw = 0, n_back = 0, n_fill = 0, n_init = 0, n_bundles = 0;
-  int off_ent = 0, off_back = 0, off_fill = 0, off_init = 0, off_ptile = 0;
+  int off_ent = 0, off_back = 0, off_fill = 0, off_init = 0, off_ptile = 0, off_written = 0;
   int max_sources = 1;                 // most tiles any variable update multiplies
   std::vector<int32_t> sweeps;         // {first op, count} of the transformed op list (one sequence: sweep boundaries mean nothing here)
   std::vector<int32_t> image;          // bundles [n_bundles + 1][2][16] | cprod entries [n_cpw] | write-back pairs [n_back][2] | fill slots [n_fill] | uniform tiles [n_init]
@@ -65,6 +65,10 @@ bool build_shared_readout(const SharedProgram& sp, int n_msgs, int n_vars, const
 // Enqueues the shared-table kernel when it applies (sets *launched); flagged graphs are left in
 // prog->d_bail for the exact kernel.
 int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream, bool* launched);
+// Whether that launch also runs a->gradient (as the sweep kernel's epilogue); and whether the exact X = 64 kernel can (it
+// redoes flagged graphs, gradient included).  Both are functions of the arguments alone.
+bool shared_gradient_fused(const mlbp_program* prog, const mlbp_sweep_args* a);
+bool exact_kernel_fuses_gradient(const mlbp_program* prog, const mlbp_sweep_args* a);
 // The same for several (program, arguments) groups in one launch sequence; *launched false = some group does not qualify.
 int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args* args, int n_groups, void* stream, bool* launched);
 // Pairwise part of the gradient for shared tables (X = 64, F_ee = 3), ADDED to a->grad_en_en.
@@ -121,6 +125,8 @@ struct mlbp_program {
   int32_t n_sreadout;
   double* d_tfrag;        // [32][2][4096] table fragments in MFMA operand order (lazily allocated)
   double* d_spill = nullptr;   // message tiles of the shared-table kernel that do not fit LDS (lazily allocated)
+  double* d_wfrag = nullptr;   // the gradient epilogue's weighted table fragments [n_pair_tables][2][4][4096] (lazily allocated)
+  size_t wfrag_cap = 0;
   double* d_ptiles = nullptr;  // constant-product tiles of the shared-table kernel [groups][n_cprod][1024] (lazily allocated)
   size_t ptiles_cap = 0;       // in doubles
   size_t spill_cap = 0;        // in doubles

@@ -249,7 +249,7 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
   }
   out.n_ops = n_ops; out.n_cpw = (int)ent.size();
   out.n_back = (int)back.size() / 2; out.n_fill = (int)fill.size(); out.n_init = (int)init_tiles.size();
-  // device image: bundles [n_bundles + 1][2][4] | cprod entries | write-back pairs | fill slots | uniform tiles | product tiles
+  // device image: bundles [n_bundles + 1][2][4] | cprod entries | write-back pairs | fill slots | uniform tiles | product tiles | written bits
   out.image = bundles;
   out.off_ent = (int)out.image.size();
   out.image.insert(out.image.end(), ent.begin(), ent.end());
@@ -261,6 +261,12 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
   out.image.insert(out.image.end(), init_tiles.begin(), init_tiles.end());
   out.off_ptile = (int)out.image.size();                         // tile of constant product k
   for (int k = 0; k < fp.n_cprod; ++k) out.image.push_back(out.live_of_slot[n_msgs + 1 + k]);
+  out.off_written = (int)out.image.size();                       // bit c: some update of the program writes slot c
+  for (int c0 = 0; c0 < n_msgs; c0 += 32) {
+    uint32_t w = 0;
+    for (int c = c0; c < n_msgs && c < c0 + 32; ++c) w |= (written[c] ? 1u : 0u) << (c - c0);
+    out.image.push_back((int32_t)w);
+  }
   for (int q = 0; q < 16; ++q) out.image.push_back(0);
   out.why = "";
   out.ok = true;
@@ -341,6 +347,37 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef const int32_t __attribute__((address_space(4))) * const_i32p;
 __device__ __forceinline__ const_i32p as_const(const int32_t* p) { return (const_i32p)(uintptr_t)p; }
 
+// The gradient as the sweep kernel's epilogue (FactorGraph.get_unregularized_gradeint, LBP.py:301-320, beliefs fused in): what
+// gradient_shared_pairs_kernel reads, minus the message buffer -- the final messages are the workgroup's own.
+// Group tables (mlbp_sweep_groups_f64): the group of block `block` -- starts ascending, starts[n] = the grid size -- and its
+// description, both through the scalar data cache: the description then lives in SGPRs exactly like a kernel argument
+// (a plain struct copy from global memory lands in VGPRs and from there in scratch).
+__device__ __forceinline__ int find_group(const int32_t* starts, int n, int block) {
+  const const_i32p s = as_const(starts);
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (s[mid] <= block) lo = mid; else hi = mid - 1;
+  }
+  return __builtin_amdgcn_readfirstlane(lo);
+}
+template <typename T>
+__device__ __forceinline__ void load_uniform(T& dst, const T* src) {
+  static_assert(sizeof(T) % 4 == 0, "copied as 32-bit words");
+  const const_i32p w = as_const(reinterpret_cast<const int32_t*>(src));
+  int32_t* o = reinterpret_cast<int32_t*>(&dst);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(T) / 4); ++i) o[i] = w[i];
+}
+
+struct SharedGradDev {
+  const int32_t* c_slot; const int32_t* r_slot; const int32_t* pair_phi; const int32_t* pair_label;
+  const double* phi[2];         // interleaved [64][64][3]: the label term
+  const double* wfrag;          // [table][which][4][4096] A fragments of T (.) phi_k and T (shared_prepare_kernel)
+  double* grad_en_en;           // [B][3]: the unary factors' terms are there (shared_prepare_kernel), the pairwise ones are added
+  int32_t enabled, pad_;
+};
+
 struct SharedDev {
   const double* pair_tables;
   const int32_t* pair_tab;
@@ -359,6 +396,8 @@ struct SharedDev {
   int32_t n_res;                // tiles [0, n_res) live in LDS, the rest in `spill`
   double* spill;                // [workgroups][n_live - n_res][64][16] or NULL
   const double* tfrag;          // [n_pair_tables][2][4096] A fragments of every table (only when there are <= FRAG_TABLES), or NULL
+  int32_t off_written, pad_;
+  SharedGradDev gr;
 };
 
 #define MLBP_MFMA16(A)                                                               \
@@ -372,10 +411,17 @@ __device__ unsigned long long* g_sh_stamp = nullptr;
 __device__ int g_sh_ablate = 0;      // timing experiments of tools/stamp_shared.py (results become wrong): 1 no MFMAs, 2 no tile reads, 4 no result stores
 #define ABL(bit) (abl_ & (bit))
 #define ABL_DECL const int abl_ = __builtin_amdgcn_readfirstlane(g_sh_ablate);
-#define STAMP_DECL unsigned long long _t0 = 0, _ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef MLBP_STAMPS_LIGHT      // ablations only: no clock reads in the kernel
+#define STAMP_DECL
+#define STAMP_START
+#define STAMP(i)
+#define STAMP_FLUSH
+#else
+#define STAMP_DECL unsigned long long _t0 = 0, _ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t0) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #define STAMP(i) { unsigned long long _t1; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t1) :: "memory"); __builtin_amdgcn_sched_barrier(0); _ph[i] += _t1 - _t0; _t0 = _t1; }
-#define STAMP_FLUSH if (g_sh_stamp && blockIdx.x < 64 && (threadIdx.x & 63) == 0) { for (int _i = 0; _i < 8; ++_i) g_sh_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + _i] = _ph[_i]; }
+#define STAMP_FLUSH if (g_sh_stamp && blockIdx.x < 64 && (threadIdx.x & 63) == 0) { for (int _i = 0; _i < 12; ++_i) g_sh_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 12 + _i] = _ph[_i]; }
+#endif
 #else
 #define ABL(bit) 0
 #define ABL_DECL
@@ -407,6 +453,13 @@ constexpr int FRAG_TABLES = 32;                                  // shared-table
 constexpr int PWG = 256, PGB = 4;                                // threads / graphs per block of the prepare kernel
 struct PrepareDev {
   const double* pair_tables; double* tfrag; int32_t n_frag_tables;
+  int32_t n_wfrag_tables;                                        // > 0: also the gradient's weighted fragments, T (.) phi_k and T
+  double* wfrag; const double* phi_p0; const double* phi_p1;     // wfrag [table][which][4][4096]; phi planar [3][64][64]
+  // ... and the unary factors' gradient terms, phi[label][obs][:] - E[table row][:] (E from mlbp_unary_expectations_f64), summed
+  // per graph into grad_en_en [B][3] / grad_en_de [B][6] (assigned: the sweep kernel's epilogue adds the pairwise terms)
+  const double* unary_expect; const int32_t* unary_kind; const int32_t* unary_obs; const int32_t* unary_label;
+  const double* phi_i0; const double* phi_i1; const double* phi_ed;        // interleaved [64][64][3] x 2, [64][Vde][6]
+  double* grad_en_en; double* grad_en_de; int32_t Vde, grad_on;
   const double* unary_tables; const int32_t* unary_tab; const int32_t* ent;      // ent: [E][4] unary factor, slot, tile, first | last flags
   double* ptiles; uint8_t* bail; int32_t* status;
   int32_t B, U, n_unary_tables, E, n_cprod, n_groups;
@@ -419,14 +472,10 @@ __global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d, const
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int block = blockIdx.x, n_blocks = gridDim.x;
   if (MULTI) {
-    int lo = 0, hi = n_groups - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (gstart[mid] <= block) lo = mid; else hi = mid - 1;
-    }
-    d = gtab[lo];
-    block -= gstart[lo];
-    n_blocks = gstart[lo + 1] - gstart[lo];
+    const int lo = find_group(gstart, n_groups, block);
+    load_uniform(d, gtab + lo);
+    block -= as_const(gstart)[lo];
+    n_blocks = as_const(gstart)[lo + 1] - as_const(gstart)[lo];
   }
   for (int q = block; q < 2 * d.n_frag_tables; q += n_blocks) {
     const int ti = q >> 1, mt = q & 1;
@@ -436,6 +485,20 @@ __global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d, const
       const int l = e & 63, sk = (e >> 6) & 15, w = e >> 10;
       const int i = 16 * w + (l & 15), k = 4 * sk + (l >> 4);
       o[e] = mt ? T[k * 64 + i] : T[i * 64 + k];
+    }
+  }
+  // the gradient epilogue's A operands (what pair_weight_fragments_kernel writes): quarter jobs (one row block each) on the
+  // blocks behind those, which start as early and so finish inside the launch's main body
+  for (int q = block - 2 * d.n_frag_tables; q < 32 * d.n_wfrag_tables; q += n_blocks) {
+    if (q < 0) continue;
+    const int ti = q >> 5, which = (q >> 4) & 1, k = (q >> 2) & 3, w = q & 3;
+    const double* T = d.pair_tables + (size_t)ti * 4096;
+    const double* ph = (which ? d.phi_p1 : d.phi_p0) + (size_t)(k < 3 ? k : 0) * 4096;
+    double* o = d.wfrag + (((size_t)ti * 2 + which) * 4 + k) * 4096 + w * 1024;
+    for (int e = t; e < 1024; e += PWG) {
+      const int l = e & 63, sk = e >> 6;
+      const int idx = (16 * w + (l & 15)) * 64 + 4 * sk + (l >> 4);
+      o[e] = k < 3 ? T[idx] * ph[idx] : T[idx];
     }
   }
   const int g = block * PGB + wave;
@@ -452,6 +515,27 @@ __global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d, const
   // constant-product list; both loads are independent, the entry's row then comes through the lane crossbar
   int my_row = lane < d.U ? d.unary_tab[(size_t)g * d.U + lane] : 0;
   if ((unsigned)my_row >= (unsigned)d.n_unary_tables) { flagged = true; my_row = 0; }    // the exact kernel meets it again and reports it
+  // the unary factors' gradient terms (LBP.py:592-619 with the belief's expectation taken once per table row): eight lanes
+  // per factor -- lane 8 j + k takes feature k of factor 8 c + j -- so that a factor's row of expected features and its
+  // label's feature row are one or two cache lines per FACTOR for the address unit, not per feature (one lane per factor
+  // asked for three times as many lines as the table rows below).  Requested here, summed behind the products.
+  double u_ee = 0.0, u_ed = 0.0;                                 // lane k (after the sums): feature k of grad_en_en / grad_en_de
+  if (d.grad_on && d.unary_expect) {
+    int my_obs = 0, my_lab = 0, my_kind = 0;
+    if (lane < d.U) { my_obs = d.unary_obs[(size_t)g * d.U + lane]; my_lab = d.unary_label[(size_t)g * d.U + lane]; my_kind = d.unary_kind[lane]; }
+    const int k = lane & 7;
+    for (int c = 0; c < d.U; c += 8) {
+      const int u = c + (lane >> 3);
+      const int kind = __shfl(my_kind, u), row = __shfl(my_row, u), obs = __shfl(my_obs, u), lab = __shfl(my_lab, u);
+      if (u >= d.U) continue;
+      const int cols = kind == 2 ? d.Vde : 64, nf = kind == 2 ? 6 : 3;
+      if ((unsigned)obs >= (unsigned)cols || (unsigned)lab >= 64u || (unsigned)kind > 2u) { atomicExch(d.status, 1); continue; }
+      if (k >= nf) continue;
+      const double* pl = kind == 2 ? d.phi_ed + ((size_t)lab * cols + obs) * 6 : (kind ? d.phi_i1 : d.phi_i0) + ((size_t)lab * 64 + obs) * 3;
+      const double v = pl[k] - d.unary_expect[(size_t)row * 8 + k];
+      if (kind == 2) u_ed += v; else u_ee += v;
+    }
+  }
   for (int c0 = 0; c0 < d.E; c0 += 64) {                          // (more than 64 entries: a chunk at a time)
     const int el = min(c0 + lane, d.E - 1), n_here = min(64, d.E - c0);
     const int ent_u = d.ent[4 * el], ent_flags = d.ent[4 * el + 3];
@@ -493,6 +577,12 @@ __global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d, const
   }
   if (__any(flagged)) flagged = true;
   if (lane == 0) d.bail[g] = flagged ? 1 : 0;
+  if (d.grad_on) {                                               // lanes k, k + 8, ..., k + 56 meet: xor 8, 16, 32
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) { u_ee += __shfl_xor(u_ee, m); u_ed += __shfl_xor(u_ed, m); }
+    if (lane < 3) d.grad_en_en[(size_t)g * 3 + lane] = u_ee;
+    if (lane < 6) d.grad_en_de[(size_t)g * 6 + lane] = u_ed;
+  }
 }
 
 // 16 consecutive words through the scalar data cache (s_load_dwordx16): wave-uniform program data lands in SGPRs.
@@ -520,18 +610,10 @@ __device__ __forceinline__ int index_in_half(int mode, int sel) { return ((mode 
 // batch's table indices so that as many bundles as possible split.
 // MULTI: the launch holds several GROUPS of graphs, each with its own program and buffers (mlbp_sweep_groups_f64): gtab[k] is
 // group k's SharedDev, gstart[k] its first workgroup; the workgroup looks its group up and runs as if launched for it alone.
-template <int NTAB, bool SPILL, bool WIDE, bool MULTI>
-__global__ __launch_bounds__(SWG, 4) void sweep_x64_shared_kernel(SharedDev d, const SharedDev* gtab, const int32_t* gstart, int n_groups) {
-  int wg = blockIdx.x;
-  if (MULTI) {
-    int lo = 0, hi = n_groups - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (gstart[mid] <= wg) lo = mid; else hi = mid - 1;
-    }
-    d = gtab[lo];
-    wg -= gstart[lo];
-  }
+// (the body: `d` is the kernel argument, or -- MULTI -- a reference into the group table through the scalar data cache, so
+// that in both forms the description sits in SGPRs / is fetched by scalar loads where it is used)
+template <int NTAB, bool SPILL, bool WIDE, typename Dev>
+__device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   extern __shared__ double lds[];
   double* tiles = lds;                                           // [n_res][64 states][16 graphs]
   double* tot = tiles + (size_t)d.n_res * TILE;                  // [n_live][16 graphs][4 row blocks] partial column sums
@@ -881,9 +963,179 @@ __global__ __launch_bounds__(SWG, 4) void sweep_x64_shared_kernel(SharedDev d, c
       for (int sp = 0; sp < 8; ++sp) { const double2 v = src[64 * sp]; out[8 * sp] = v.x * inv; out[8 * sp + 4] = v.y * inv; }
     }
   }
-  STAMP(5)
-  STAMP_FLUSH
   if (bad && gvalid) d.bail[gi] = 2;                             // any wave that saw it says so (idempotent)
+  STAMP(5)
+  if (!d.gr.enabled) {
+    STAMP_FLUSH
+    return;
+  }
+  // ---- gradient epilogue (LBP.py:301-320 over beliefs of LBP.py:528-574): per pairwise factor and feature k
+  //      E_k = m_c^T (T (.) phi_k) m_r and Z = m_c^T T m_r on the matrix cores, from the factor's two stored variable->factor
+  //      messages -- read back from the message buffer this workgroup has just written (its own stores, behind a barrier) into
+  //      the tiles the sweeps no longer need.  Pairwise terms: the operations of gradient_shared_pairs_kernel in its order.
+  //      Every wave of the workgroup waits for every load here, so the gathers are issued a phase AHEAD of their use: a
+  //      pass's labels and first fragment before its messages, its label features behind them.  (The unary factors'
+  //      terms do not depend on the sweeps: shared_prepare_kernel has written them, this adds to them.) ----
+  __syncthreads();
+  const int NP = min(4, (d.n_res - 1) >> 1);                     // factors per pass: two tiles each, one tile of partial sums
+  double* red = tiles + (size_t)2 * NP * TILE;                   // [factor][k][row block][graph]
+  double* pc = tot;                                              // [factor][graph][3] per-graph terms of a pass (the totals are spent)
+  double out3[3] = {0.0, 0.0, 0.0};                              // thread t < 16: graph g0 + t
+  for (int p0 = 0; p0 < d.P; p0 += NP) {
+    const int np = min(NP, d.P - p0);
+    // thread (factor t >> 4, graph t & 15) of the first np * 16: the factor's labels ...
+    const int lp = p0 + (t >> 4), lg = g0 + (t & 15);
+    const bool l_on = t < np * G && lg < d.B;
+    int m0 = 0, m1 = 0;
+    if (l_on) { m0 = d.gr.pair_label[((size_t)lg * d.P + lp) * 2]; m1 = d.gr.pair_label[((size_t)lg * d.P + lp) * 2 + 1]; }
+    // ... the messages: wave w takes rows i = w + 8 j of the pass's np * 32 (factor i >> 5, side (i >> 4) & 1, graph i & 15), one
+    // 512-byte row each.  The slots (and whether the program ever writes them) come through the scalar cache -- a vector
+    // load here would be one more round of memory latency in front of the rows --, then all the rows are requested
+    // before the first is used.  The half's first A fragment goes out ahead of them.
+    const const_i32p cs = as_const(d.gr.c_slot), rs = as_const(d.gr.r_slot);
+    int slots[8];                                                 // tile q = 2 * factor + side: its message slot, or -1
+#pragma unroll
+    for (int q = 0; q < 8; ++q) slots[q] = q < 2 * np ? ((q & 1) ? cs[p0 + (q >> 1)] : rs[p0 + (q >> 1)]) : -1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool in = (unsigned)slots[q] < (unsigned)d.n_msgs;
+      const int w = img[d.off_written + (in ? slots[q] >> 5 : 0)];
+      if (!in || !((w >> (slots[q] & 31)) & 1)) slots[q] = -1;
+    }
+    const int n_items = 2 * np;
+    auto key = [&](int j) { const int pp = j % np; return row0[p0 + pp] * 2 + (as_const(d.gr.pair_phi)[p0 + pp] ? 1 : 0); };
+    auto fetchw = [&](double (&fr)[16], int j) {
+      const int k = 2 * (j / np) + half;
+      const double* W = d.gr.wfrag + ((size_t)key(j) * 4 + k) * 4096 + rb * 1024 + lane;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) fr[s] = ABL(256) ? 0.5 : W[64 * s];
+    };
+    fetchw(fr0, 0);
+    double sv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {                                // row i = wave + 8 j: tile i >> 4 = j >> 1, graph wave + 8 (j & 1)
+      sv[j] = uniform;                                            // never updated: still uniform (LBP.py:211-216)
+      if (j < 4 * np && slots[j >> 1] >= 0 && !ABL(32)) {
+        const int ggc = min(g0 + wave + 8 * (j & 1), d.B - 1);
+        sv[j] = d.msgs[((size_t)ggc * d.n_msgs + slots[j >> 1]) * 64 + lane];
+      }
+    }
+    // ... and the label's feature row (the labels have arrived, the messages are still on their way)
+    double lf[3] = {0.0, 0.0, 0.0};
+    const bool l_ok = l_on && (unsigned)m0 < 64u && (unsigned)m1 < 64u;
+    if (l_on && !l_ok) atomicExch(d.status, 1);
+    if (l_ok) {
+      const double* ph = d.gr.phi[d.gr.pair_phi[lp] ? 1 : 0] + ((size_t)m0 * 64 + m1) * 3;
+      lf[0] = ph[0]; lf[1] = ph[1]; lf[2] = ph[2];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < 4 * np) {
+        tiles[(size_t)(j >> 1) * TILE + tile_index(lane, wave + 8 * (j & 1))] = sv[j];
+      }
+    __syncthreads();
+    STAMP(8)
+    // this half's items in k-major order: j = kk * np + pp  ->  factor p0 + pp, feature k = 2 kk + half.  Consecutive
+    // factors that read the same (table, feature tensor) share one A fragment: it is fetched once per run (a K3 user
+    // graph's three factors are one run: 2 fetches per wave instead of 6), the next run's while this run multiplies; two
+    // items of a run go through the matrix pipe interleaved (two independent accumulation chains).
+    auto run_end = [&](int j) {                                  // first item behind the run that starts at j
+      int e = j + 1;
+      while (e < n_items && e % np != 0 && key(e) == key(e - 1)) ++e;
+      return e;
+    };
+    auto finish = [&](const double4_t& acc, int pp, int k) {
+      const double2* ct = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp + 1) * TILE) + 128 * rb + lane;
+      const double2 c0 = ct[0], c1 = ct[64];
+      const double part = column_sum((c0.x * acc.x + c0.y * acc.y) + (c1.x * acc.z + c1.y * acc.w));
+      if ((lane >> 4) == 0) red[((pp * 4 + k) * 4 + rb) * G + (lane & 15)] = part;
+    };
+    auto item = [&](const double (&fr)[16], int j) {
+      const int pp = j % np, k = 2 * (j / np) + half;
+      const double2* rt = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp) * TILE) + lane;
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const double2 v0 = rt[128 * h], v1 = rt[128 * h + 64];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h], v0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 1], v0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 2], v1.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 3], v1.y, acc, 0, 0, 0);
+      }
+      finish(acc, pp, k);
+    };
+    auto item2 = [&](const double (&fr)[16], int j) {            // items j and j + 1: the same fragment, the next factor
+      const int pp = j % np, k = 2 * (j / np) + half;
+      const double2* rt = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp) * TILE) + lane;
+      double4_t acc = {0.0, 0.0, 0.0, 0.0}, bcc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const double2 v0 = rt[128 * h], v1 = rt[128 * h + 64], w0 = rt[2 * (TILE / 2) + 128 * h], w1 = rt[2 * (TILE / 2) + 128 * h + 64];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h], v0.x, acc, 0, 0, 0);
+        bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h], w0.x, bcc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 1], v0.y, acc, 0, 0, 0);
+        bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 1], w0.y, bcc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 2], v1.x, acc, 0, 0, 0);
+        bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 2], w1.x, bcc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 3], v1.y, acc, 0, 0, 0);
+        bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 3], w1.y, bcc, 0, 0, 0);
+      }
+      finish(acc, pp, k);
+      finish(bcc, pp + 1, k);
+    };
+    for (int j = ABL(64) ? n_items : 0; j < n_items;) {
+      int e = run_end(j);
+      if (e < n_items) fetchw(fr1, e);
+#pragma unroll 1
+      for (; j + 1 < e; j += 2) item2(fr0, j);
+      if (j < e) item(fr0, j++);
+      if (j >= n_items) break;
+      e = run_end(j);
+      if (e < n_items) fetchw(fr0, e);
+#pragma unroll 1
+      for (; j + 1 < e; j += 2) item2(fr1, j);
+      if (j < e) item(fr1, j++);
+    }
+    __syncthreads();
+    STAMP(9)
+    if (t < np * G) {                                            // label features minus expected features, per (factor, graph)
+      const double* rp = red + (size_t)(t >> 4) * 16 * G + (t & 15);
+      const double Z = (rp[(12 + 0) * G] + rp[(12 + 1) * G]) + (rp[(12 + 2) * G] + rp[(12 + 3) * G]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double S = (rp[(4 * k + 0) * G] + rp[(4 * k + 1) * G]) + (rp[(4 * k + 2) * G] + rp[(4 * k + 3) * G]);
+        pc[t * 3 + k] = l_ok ? lf[k] - (Z > 0.0 ? S / Z : 0.0) : 0.0;         // au.normalize: zero-sum -> 0
+      }
+    }
+    __syncthreads();
+    if (t < G)
+      for (int pp = 0; pp < np; ++pp) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out3[k] += pc[(pp * G + t) * 3 + k];
+      }
+    __syncthreads();
+    STAMP(10)
+  }
+  // the unary factors' terms are in the output already (shared_prepare_kernel: they do not depend on the sweeps)
+  if (t < G && g0 + t < d.B) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.gr.grad_en_en[(size_t)(g0 + t) * 3 + k] += out3[k];
+  }
+  STAMP(11)
+  STAMP_FLUSH
+}
+
+typedef const SharedDev __attribute__((address_space(4))) SharedDevConst;
+template <int NTAB, bool SPILL, bool WIDE, bool MULTI>
+__global__ __launch_bounds__(SWG, 4) void sweep_x64_shared_kernel(SharedDev d, const SharedDev* gtab, const int32_t* gstart, int n_groups) {
+  if (MULTI) {
+    const int lo = find_group(gstart, n_groups, blockIdx.x);
+    SharedDevConst& dg = *(SharedDevConst*)(uintptr_t)(gtab + lo);
+    sweep_x64_shared_body<NTAB, SPILL, WIDE>(dg, (int)blockIdx.x - as_const(gstart)[lo]);
+  } else {
+    const SharedDev& dk = d;
+    sweep_x64_shared_body<NTAB, SPILL, WIDE>(dk, (int)blockIdx.x);
+  }
 }
 
 // Unary factor -> variable messages are constants (LBP.py:494-498): msgs[g][slot] = renormalize(column).  One
@@ -1123,11 +1375,36 @@ int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, size_t lds, s
   return MLBP_OK;
 }
 
+// resident tiles: as many as fit HALF the CU's LDS, so that two workgroups share a CU; *lds: the workgroup's LDS bytes
+int resident_tiles(const SharedProgram& sp, size_t* lds) {
+  const size_t fixed = (size_t)sp.n_live * 64 * sizeof(double) + 64 + 8 * (size_t)(sp.n_bundles + 1) * sizeof(int32_t) + 64;
+  int n_res = sp.n_live;
+  while (n_res > 0 && fixed + (size_t)n_res * 64 * 16 * sizeof(double) > 80 * 1024) --n_res;
+  if (lds) *lds = fixed + (size_t)n_res * 64 * 16 * sizeof(double);
+  return n_res;
+}
+
+}  // namespace
+
+// True when launch_shared_sweep / launch_shared_groups run the call's gradient (a->gradient) as the sweep kernel's epilogue:
+// shared tables with their planar feature tensors, the unary part by gather, and an exact kernel that can produce the
+// gradient of the graphs it redoes.  A function of the arguments alone: the dispatcher asks it again after the launch.
+bool shared_gradient_fused(const mlbp_program* prog, const mlbp_sweep_args* a) {
+  const mlbp_gradient_args* ga = a->gradient;
+  if (!ga || !exact_kernel_fuses_gradient(prog, a)) return false;
+  return (ga->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && prog->P >= 1 && a->n_pair_tables <= FRAG_TABLES && ga->phi_en_en_p &&
+         ga->phi_en_en_w1_p && ga->phi_en_en && ga->phi_en_en_w1 && (prog->U == 0 || (ga->unary_expect && ga->phi_en_de)) && a->msgs &&
+         prog->shared.ok && resident_tiles(prog->shared, nullptr) >= 3;
+}
+
+namespace {
+
 // What a shared-table sweep of (prog, a) needs: the two device descriptions, the LDS size, the grid sizes.  *ok false: the
 // kernel does not apply (mlbp_last_error says why).  Allocates the program's scratch on first use.
 struct SharedPlan { SharedDev d; PrepareDev q; size_t lds; int n_wg, n_prep_blocks; bool wide, spill; };
 int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, SharedPlan* out) {
   *ok = false;
+  memset(out, 0, sizeof(*out));
   const SharedProgram& sp = prog->shared;
   if (!(a->flags & MLBP_SWEEP_SHARED_PAIR_TABLES)) return MLBP_OK;
   if (a->X != 64 || !a->normalize_messages || !a->init_messages)
@@ -1139,10 +1416,8 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   // factor->variable messages come first in the numbering); the rest spill to global memory.  Measured on K4 user
   // graphs (21 tiles): 8 resident + 13 spilled with two workgroups per CU 0.216 ms, 16 resident + 5 spilled with
   // one 0.266 ms.
-  const size_t fixed = (size_t)sp.n_live * 64 * sizeof(double) + 64 + 8 * (size_t)(sp.n_bundles + 1) * sizeof(int32_t) + 64;
-  int n_res = sp.n_live;
-  while (n_res > 0 && fixed + (size_t)n_res * TILE * sizeof(double) > 80 * 1024) --n_res;
-  const size_t lds = fixed + (size_t)n_res * TILE * sizeof(double);
+  size_t lds = 0;
+  const int n_res = resident_tiles(sp, &lds);
   const int n_cprod = (int)sp.cprods.size();
   if (n_res < 1 || sp.n_live - n_res > 16 || lds > 160 * 1024)   // too much would spill: the per-graph kernels do better
     return fail(MLBP_OK, "shared-table kernel not used: %d live message tiles, %d fit LDS", sp.n_live, n_res);
@@ -1178,6 +1453,7 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   d.off_back = sp.off_back; d.off_fill = sp.off_fill; d.off_init = sp.off_init; d.off_ptile = sp.off_ptile;
   d.ptiles = mp->d_ptiles;
   d.n_res = n_res; d.spill = n_res < sp.n_live ? mp->d_spill : nullptr;
+  d.off_written = sp.off_written;
   d.tfrag = nullptr;
   if (a->n_pair_tables <= FRAG_TABLES) {
     if (!mp->d_tfrag) {                            // first use (a stream-capturing caller warms up or reserves first)
@@ -1192,6 +1468,27 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   q.unary_tables = a->unary_tables; q.unary_tab = a->unary_tab; q.ent = prog->d_simage + sp.off_ent;
   q.ptiles = mp->d_ptiles; q.bail = mp->d_bail; q.status = prog->d_status;
   q.B = a->B; q.U = prog->U; q.n_unary_tables = a->n_unary_tables; q.E = sp.n_cpw / 4; q.n_cprod = n_cprod; q.n_groups = n_groups;
+  // the gradient as the sweep kernel's epilogue (the prepare launch also writes its weighted table fragments)
+  if (shared_gradient_fused(prog, a)) {
+    const mlbp_gradient_args* ga = a->gradient;
+    const size_t need = (size_t)a->n_pair_tables * 8 * 4096;
+    if (need > mp->wfrag_cap) {                     // first use (a stream-capturing caller warms up first)
+      (void)hipFree(mp->d_wfrag);
+      mp->d_wfrag = nullptr; mp->wfrag_cap = 0;
+      if (hipMalloc(&mp->d_wfrag, need * sizeof(double)) != hipSuccess) return fail(MLBP_EHIP, "weighted fragment allocation failed");
+      mp->wfrag_cap = need;
+    }
+    q.n_wfrag_tables = a->n_pair_tables; q.wfrag = mp->d_wfrag; q.phi_p0 = ga->phi_en_en_p; q.phi_p1 = ga->phi_en_en_w1_p;
+    SharedGradDev& gr = d.gr;
+    gr.c_slot = ga->pair_c_slot; gr.r_slot = ga->pair_r_slot; gr.pair_phi = ga->pair_phi; gr.pair_label = ga->pair_label;
+    gr.phi[0] = ga->phi_en_en; gr.phi[1] = ga->phi_en_en_w1; gr.wfrag = mp->d_wfrag;
+    gr.grad_en_en = ga->grad_en_en; gr.enabled = 1;
+    q.unary_expect = prog->U > 0 ? ga->unary_expect : nullptr;
+    q.unary_kind = ga->unary_kind; q.unary_obs = ga->unary_obs; q.unary_label = ga->unary_label;
+    q.phi_i0 = ga->phi_en_en; q.phi_i1 = ga->phi_en_en_w1; q.phi_ed = ga->phi_en_de;
+    q.grad_en_en = ga->grad_en_en; q.grad_en_de = ga->grad_en_de; q.Vde = ga->Vde; q.grad_on = 1;
+    d.msgs = a->msgs;                               // the epilogue reads the stored variable->factor messages back
+  }
   out->lds = lds; out->n_wg = n_groups; out->n_prep_blocks = (a->B + PGB - 1) / PGB;
   out->wide = sp.max_sources > 2; out->spill = d.spill != nullptr;
   *ok = true;

@@ -1156,6 +1156,20 @@ void build_fused_program(const int32_t* ops_in, const int32_t* srcs, const int32
 // kernels on every graph (the tests' reference on the same inputs).
 int g_sweep_variant = 1;
 thread_local int g_last_kernel = -1;       // mlbp_last_sweep_kernel()
+thread_local int g_last_fused_gradient = 0; // mlbp_last_sweep_fused_gradient()
+}  // namespace
+
+namespace mlbp {
+bool exact_kernel_fuses_gradient(const mlbp_program* prog, const mlbp_sweep_args* a) {
+  const mlbp_gradient_args* ga = a->gradient;
+  if (!ga || a->X != 64 || !a->normalize_messages) return false;
+  if (ga->B != a->B || ga->X != a->X || ga->P != prog->P || ga->U != prog->U || ga->n_msgs != prog->n_msgs || ga->msgs != a->msgs) return false;
+  return ga->F_ee == 3 && ga->F_ed == 6 && prog->P >= 1 && prog->P <= 3 && prog->n_hoist == prog->U && prog->U <= WG &&
+         ga->phi_en_en_t && ga->phi_en_en_w1_t && ga->phi_en_de_t && !(ga->flags & MLBP_GRADIENT_APPROX_BELIEFS);
+}
+}  // namespace mlbp
+
+namespace {
 thread_local bool g_lean_predone = false;  // set by mlbp_sweep_groups_f64 around the per-group fix-up calls
 thread_local bool g_shared_predone = false;   // the same when the shared-table kernels ran the groups
 int sweep_variant() { return g_sweep_variant; }
@@ -1422,12 +1436,13 @@ int mlbp_program_destroy(mlbp_program* p) {
   (void)hipFree(p->d_ops); (void)hipFree(p->d_srcs); (void)hipFree(p->d_sweeps);
   (void)hipFree(p->d_pairseq); (void)hipFree(p->d_status);
   (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq); (void)hipFree(p->d_bail); (void)hipFree(p->d_readout);
-  (void)hipFree(p->d_limage); (void)hipFree(p->d_lreadout); (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout); (void)hipFree(p->d_tfrag); (void)hipFree(p->d_spill); (void)hipFree(p->d_gtable); (void)hipFree(p->d_ptiles); (void)hipFree(p->d_stable);
+  (void)hipFree(p->d_limage); (void)hipFree(p->d_lreadout); (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout); (void)hipFree(p->d_tfrag); (void)hipFree(p->d_spill); (void)hipFree(p->d_gtable); (void)hipFree(p->d_ptiles); (void)hipFree(p->d_stable); (void)hipFree(p->d_wfrag);
   delete p;
   return MLBP_OK;
 }
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream) {
+  g_last_fused_gradient = 0;
   if (!prog || !a) return fail(MLBP_EINVAL, "mlbp_sweep_f64: NULL program or args");
   prog = effective_program(prog, a);
   if (a->B <= 0 || a->X <= 0) return fail(MLBP_EINVAL, "mlbp_sweep_f64: B=%d X=%d", a->B, a->X);
@@ -1485,9 +1500,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       if (ga) {
         if (ga->B != a->B || ga->X != a->X || ga->P != prog->P || ga->U != prog->U || ga->n_msgs != prog->n_msgs || ga->msgs != a->msgs)
           return fail(MLBP_EINVAL, "mlbp_sweep_f64: gradient arguments do not describe the same batch");
-        grad_fused = norm && ga->F_ee == 3 && ga->F_ed == 6 && nt >= 1 && prog->n_hoist == prog->U && prog->U <= WG &&
-                     ga->phi_en_en_t && ga->phi_en_en_w1_t && ga->phi_en_de_t && !(ga->flags & MLBP_GRADIENT_APPROX_BELIEFS) &&
-                     !g_lean_predone && !g_shared_predone;
+        grad_fused = mlbp::exact_kernel_fuses_gradient(prog, a) && !g_lean_predone;
         if (grad_fused) {
           gf.pair_c_slot = ga->pair_c_slot; gf.pair_r_slot = ga->pair_r_slot; gf.pair_phi = ga->pair_phi; gf.pair_label = ga->pair_label;
           gf.unary_kind = ga->unary_kind; gf.unary_obs = ga->unary_obs; gf.unary_label = ga->unary_label;
@@ -1500,12 +1513,14 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       if (g_shared_predone) shared_done = true;  // mlbp_sweep_groups_f64 ran the shared-table kernels for this group already
       else if (fast && !g_lean_predone)
         if (int e = mlbp::launch_shared_sweep(prog, a, stream, &shared_done)) return e;
-      if (shared_done) { grad_fused = false; gf = GradFusedDev{}; }
+      // (the shared-table kernel ran the gradient as its epilogue: the fix-up pass keeps its own for the graphs it redoes)
+      if (shared_done && !(grad_fused && mlbp::shared_gradient_fused(prog, a))) { grad_fused = false; gf = GradFusedDev{}; }
       bool lean_done = false;                  // default path: the lean scale-free kernel (mlbp_lean.hip), up to 8 resident tables
       if (g_lean_predone) lean_done = true;     // mlbp_sweep_groups_f64 ran the lean kernel for this group already
       else if (fast && norm && prog->sf_ok && prog->P >= 1 && prog->P <= 8 && !shared_done)
         if (int e = mlbp::launch_lean_sweep(prog, a, grad_fused ? &gf : nullptr, stream, &lean_done)) return e;
       g_last_kernel = shared_done ? MLBP_KERNEL_SHARED_MFMA : (lean_done ? MLBP_KERNEL_LEAN : MLBP_KERNEL_EXACT);
+      g_last_fused_gradient = grad_fused ? 1 : 0;
       FusedDev f;
       f.only = (shared_done || lean_done) ? mp->d_bail : nullptr;     // after a fast pass: flagged graphs only
       f.image = prog->d_fops; f.fsweeps = prog->d_fsweeps;
@@ -1728,6 +1743,7 @@ int mlbp_set_sweep_variant(int32_t variant) {
 }
 
 int mlbp_last_sweep_kernel(void) { return g_last_kernel; }
+int mlbp_last_sweep_fused_gradient(void) { return g_last_fused_gradient; }
 
 int mlbp_program_exact_count(const mlbp_program* prog, int32_t B) {
   // Synchronising: how many of the first B graphs of the last default-variant launch were handed

@@ -237,12 +237,13 @@ class UserGraphTrainer:
         if gradient_from_messages:
             fb.gradient(self._g_ee, self._g_ed)
         self._patch_gradient()
+        if not self.n_dom:          # [sum g_ee | sum g_ed | sum log-posterior | count]: log-posteriors and sums in one launch
+            _ffi.check(_ffi.lib.mlbp_step_statistics_f64(self._g_ee.data_ptr(), self.F_ee, self._g_ed.data_ptr(), self.F_ed,
+                                                         self._marg.data_ptr(), fb._labels.data_ptr(), self.topo.n_vars, fb.X, fb.B,
+                                                         self._lp.data_ptr(), self.stats.data_ptr(), _stream_ptr(self.device)))
+            return self.stats
         _ffi.check(_ffi.lib.mlbp_log_posterior_f64(self._marg.data_ptr(), fb._labels.data_ptr(), fb.B, self.topo.n_vars,
                                                    fb.X, self._lp.data_ptr(), _stream_ptr(self.device)))
-        if not self.n_dom:          # [sum g_ee | sum g_ed | sum log-posterior | count] straight from the three arrays
-            _ffi.check(_ffi.lib.mlbp_sum_rows_cat_f64(self._g_ee.data_ptr(), self.F_ee, self._g_ed.data_ptr(), self.F_ed,
-                                                      self._lp.data_ptr(), 1, fb.B, 1, self.stats.data_ptr(), _stream_ptr(self.device)))
-            return self.stats
         r = self._rows
         r[:, :self.F_ee] = self._g_ee
         r[:, self.F_ee:self.F_ee + self.F_ed] = self._g_ed

@@ -136,6 +136,69 @@ def _oracle_step(spec, inputs, labels, obs, roots, lr, reg):
     return tot_ee, tot_ed, lp
 
 
+@pytest.mark.parametrize('B', [6, 53])
+def test_shared_table_sweep_runs_the_gradient_as_its_epilogue(B):
+    """Shared pots, K3 user graphs: the gradient of sweep(gradient=...) comes out of the shared-table sweep kernel itself (the
+    final variable->factor messages of the workgroup's 16 graphs against T (.) phi_k on the matrix cores, the unary part by
+    gather in the launch in front of it) -- the separate gradient launch's values to rounding, the oracle's values, and a graph
+    the matrix-core kernel hands to the exact kernel (a zero table column) gets its gradient there."""
+    import copy
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.train import UserGraphTrainer
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = C.user_spec(10, [1, 4, 7], 64, 48, seed=1)
+    topo = GraphTopology.from_spec(spec)
+    inputs = C.make_inputs(spec, 77)
+    roots = [4, 1, 7]
+    labels, obs = _instances(spec, topo, B, 5)
+    tr = UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],
+                          inputs['theta_en_en'], inputs['theta_en_de'], roots=roots)
+    fb = tr.batch
+    tr.build_potentials()
+    g_ee, g_ed = torch.full_like(tr._g_ee, float('nan')), torch.full_like(tr._g_ed, float('nan'))
+    fb.sweep(roots, init=True, marginals=tr._marg, gradient=(g_ee, g_ed), keep_messages=False)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 3 and _ffi.lib.mlbp_last_sweep_fused_gradient() == 1
+    assert fb.program(roots).exact_count(B) == 0
+    fb.sweep(roots, init=True)                                    # all messages to memory, then the separate launch
+    assert _ffi.lib.mlbp_last_sweep_fused_gradient() == 0
+    h_ee, h_ed = fb.gradient()
+    # (the same pairwise operations in the same order; the unary terms are summed per graph in the prepare launch, in another order)
+    np.testing.assert_allclose(g_ee.cpu().numpy(), h_ee.cpu().numpy(), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(g_ed.cpu().numpy(), h_ed.cpu().numpy(), rtol=1e-12, atol=1e-13)
+    for b in range(0, B, 7):
+        s = copy.deepcopy(spec)
+        g0 = O.Graph(s)
+        s['labels'] = [int(labels[b, g0.var_order.index(v)]) for v in s['var_ids']]
+        unary_ids = [f['id'] for f in g0.factors if len(f['vars']) == 1]
+        for f in s['factors']:
+            if len(f['vars']) == 1:
+                f['observed_dim'] = int(obs[b, unary_ids.index(f['id'])])
+        g = O.Graph(s)
+        msgs = O.init_messages(g)
+        O.treelike_inference(g, inputs, msgs, len(roots), roots, O.has_loops(g, roots[0]))
+        ee, ed = O.unregularized_gradient(g, inputs, msgs)
+        np.testing.assert_allclose(g_ee[b].cpu().numpy(), ee.reshape(-1), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(g_ed[b].cpu().numpy(), ed.reshape(-1), rtol=1e-9, atol=1e-12)
+    # one graph reads an all-zero unary row: flagged by the prepare launch, redone (gradient included) by the exact kernel
+    row = int(fb.unary_tab[B // 2, 0])
+    saved = tr.unary_tables[row].clone()
+    tr.unary_tables[row] = 0.0
+    k_ee, k_ed = torch.full_like(g_ee, float('nan')), torch.full_like(g_ed, float('nan'))
+    fb.sweep(roots, init=True, marginals=tr._marg, gradient=(k_ee, k_ed), keep_messages=False)
+    n_redone = fb.program(roots).exact_count(B)
+    assert _ffi.lib.mlbp_last_sweep_fused_gradient() == 1 and n_redone >= 1
+    try:
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(3))
+        e_ee, e_ed = torch.empty_like(g_ee), torch.empty_like(g_ed)
+        fb.sweep(roots, init=True, marginals=tr._marg, gradient=(e_ee, e_ed), keep_messages=False)
+    finally:
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(1))
+    assert bool(torch.isfinite(k_ee).all()) and bool(torch.isfinite(k_ed).all())
+    np.testing.assert_allclose(k_ee.cpu().numpy(), e_ee.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(k_ed.cpu().numpy(), e_ed.cpu().numpy(), rtol=1e-9, atol=1e-12)
+    tr.unary_tables[row] = saved
+
+
 def test_train_step_matches_sum_of_reference_steps():
     """UserGraphTrainer.step == theta + sum_i return_gradient_i (train_mp.py:398, 419-424) with the
     potentials built on the device from phi and theta (train_mp.py:220-255)."""

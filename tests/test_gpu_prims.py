@@ -46,6 +46,38 @@ def test_sum_rows_of_three_arrays_with_the_count_appended():
         _ffi.check(_ffi.lib.mlbp_sum_rows_cat_f64(ta.data_ptr(), 40, tb.data_ptr(), 30, None, 0, B, 0, out.data_ptr(), _stream(dev)))
 
 
+def test_step_statistics_in_one_launch_equal_the_two_launch_form():
+    """mlbp_step_statistics_f64 == mlbp_log_posterior_f64 then mlbp_sum_rows_cat_f64, bit for bit (LBP.py:247-259 with -inf ->
+    -99.99, train_mp.py:405-424's sums); a label out of range is skipped and raises the status word."""
+    from macaronicusermodeling_amd import _ffi
+    dev = torch.device('cuda:0')
+    rs = np.random.RandomState(4)
+    B, nv, X = 3001, 3, 64
+    marg = rs.rand(B, nv, X); marg /= marg.sum(2, keepdims=True)
+    labels = rs.randint(0, X, size=(B, nv)).astype(np.int32)
+    marg[7, 1, labels[7, 1]] = 0.0                                # log 0 -> -99.99
+    a, b = rs.randn(B, 3), rs.randn(B, 6)
+    tm, tl, ta, tb = (torch.from_numpy(x).to(dev) for x in (marg, labels, a, b))
+    lp1, lp2 = torch.empty(B, dtype=torch.float64, device=dev), torch.empty(B, dtype=torch.float64, device=dev)
+    out1, out2 = torch.empty(11, dtype=torch.float64, device=dev), torch.empty(11, dtype=torch.float64, device=dev)
+    _ffi.check(_ffi.lib.mlbp_log_posterior_f64(tm.data_ptr(), tl.data_ptr(), B, nv, X, lp1.data_ptr(), _stream(dev)))
+    _ffi.check(_ffi.lib.mlbp_sum_rows_cat_f64(ta.data_ptr(), 3, tb.data_ptr(), 6, lp1.data_ptr(), 1, B, 1, out1.data_ptr(), _stream(dev)))
+    _ffi.check(_ffi.lib.mlbp_step_statistics_f64(ta.data_ptr(), 3, tb.data_ptr(), 6, tm.data_ptr(), tl.data_ptr(), nv, X, B, lp2.data_ptr(),
+                                                 out2.data_ptr(), _stream(dev)))
+    assert torch.equal(lp1, lp2) and torch.equal(out1, out2)
+    want_lp = np.log(np.take_along_axis(marg, labels[:, :, None].astype(np.int64), 2)[:, :, 0].clip(1e-300))
+    want_lp[7, 1] = -99.99
+    np.testing.assert_allclose(lp2.cpu().numpy(), want_lp.sum(1), rtol=1e-12)
+    np.testing.assert_allclose(out2.cpu().numpy(), np.concatenate([a.sum(0), b.sum(0), [want_lp.sum()], [B]]), rtol=1e-11, atol=1e-9)
+    _ffi.check(_ffi.lib.mlbp_step_statistics_f64(ta.data_ptr(), 3, tb.data_ptr(), 6, tm.data_ptr(), tl.data_ptr(), nv, X, B, None,
+                                                 out1.data_ptr(), _stream(dev)))       # no per-graph output
+    assert torch.equal(out1, out2) and _ffi.lib.mlbp_gradient_status() == 0
+    tl[11, 0] = X
+    _ffi.check(_ffi.lib.mlbp_step_statistics_f64(ta.data_ptr(), 3, tb.data_ptr(), 6, tm.data_ptr(), tl.data_ptr(), nv, X, B, lp2.data_ptr(),
+                                                 out2.data_ptr(), _stream(dev)))
+    assert _ffi.lib.mlbp_gradient_status() == 1
+
+
 def test_potentials_of_several_feature_sets_and_parameter_vectors_in_one_launch():
     """mlbp_potentials_multi_f64 == exp(phi . theta) per job and repetition (train_mp.py:220-255), row-major and transposed
     outputs at their strides, identical to the one-job entry; bad job tables are refused."""

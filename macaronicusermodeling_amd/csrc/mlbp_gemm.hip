@@ -111,10 +111,15 @@ template <> struct Frag<float> {
   typedef float lds_t;
 };
 
-// The contraction runs at XA = 64 * RT states; N_T = 16 * NCT graphs per workgroup.  PADDED: the messages have d.X <= XA
+// The contraction runs at XA = 64 * RT states; N_T = 16 * NCT graphs per pass.  PADDED: the messages have d.X <= XA
 // states (rows of d.X doubles in memory, any parity: 8-byte accesses), the operands are zero beyond.
-template <typename TT, int RT, int NCT, int DEPTH, int NW, bool PADDED>
-__global__ __launch_bounds__(64 * NW) void contract_kernel(ContractDev d) {
+// HALVES = 2: the workgroup takes 2 * N_T graphs as two passes over the table, and the passes' memory phases meet the other
+// pass's matrix phase -- the second pass's source messages are requested before the first pass's main loop and land in
+// registers under it; the first pass's results are stored (fire and forget) under the second pass's loop.  With ONE pass
+// per workgroup every workgroup of the launch is in its HBM phase at the same time and the matrix cores wait (a third of an
+// update at X = 512, tools/contract_probe.py); two co-resident workgroups cannot be staggered to the same effect.
+template <typename TT, int RT, int NCT, int DEPTH, int NW, bool PADDED, int HALVES>
+__global__ __launch_bounds__(64 * NW, (NW == 16 && HALVES == 1 && NCT == 1) ? 8 : 1) void contract_kernel(ContractDev d) {
   constexpr int XA = 64 * RT, NT_G = 16 * NCT, XP = XA + 2;
   const int X = PADDED ? d.X : XA;
   constexpr int RTW = 4 * RT / NW;                               // 16-row tiles per wave (wave w owns tiles w, w + NW, ...)
@@ -126,65 +131,81 @@ __global__ __launch_bounds__(64 * NW) void contract_kernel(ContractDev d) {
   mt_t* Mt = reinterpret_cast<mt_t*>(lds_raw);                   // [NT_G][XP] input messages (later: the results, float64)
   double* Ot = lds_raw;                                          // [NT_G][XP] float64 view for the epilogue
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int b0 = blockIdx.x * NT_G;
   const double uniform = 1.0 / (double)X;
 
-  // ---- prologue: the input messages of this workgroup's graphs -> LDS.  A wave takes NT_G / 4 consecutive graphs, four
-  //      at a time, so that one round of memory latency covers four graphs; lane l holds states 2l, 2l+1 (+128 j) ----
+  // ---- prologue pieces: the input messages of a pass's graphs -> LDS.  A wave takes NT_G / NW consecutive graphs, up to
+  //      four at a time, so that one round of memory latency covers four graphs; lane l holds states 2l, 2l+1 (+128 j) ----
   constexpr int GPW = NT_G / NW, GU = GPW < 4 ? GPW : 4;        // graphs per wave, and how many of them go through together
   constexpr int H = RT / 2 + (RT & 1);                         // double2 pieces per lane (odd RT: last half-used)
+  constexpr int PF = 2;                                         // source messages requested together
   static_assert(RT % 2 == 0, "X must be a multiple of 128 here");
-  for (int g4 = 0; g4 < GPW; g4 += GU) {
-    double2 v[GU][H];
-    const double* gin[GU];
-    bool live[GU];
+  static_assert(HALVES == 1 || GPW == GU, "the overlapped form keeps one batch of graphs per wave in registers");
+  // states 2 (lane + 64 j), + 1 of a row of X doubles; beyond X: zero
+  auto load2 = [&](const double* row, int j) {
+    if (!PADDED) return reinterpret_cast<const double2*>(row)[lane + 64 * j];
+    const int x0 = 2 * (lane + 64 * j);
+    return make_double2(x0 < X ? row[x0] : 0.0, x0 + 1 < X ? row[x0 + 1] : 0.0);
+  };
+  auto uniform2 = [&](int j) {
+    const int x0 = 2 * (lane + 64 * j);
+    return (!PADDED) ? make_double2(uniform, uniform) : make_double2(x0 < X ? uniform : 0.0, x0 + 1 < X ? uniform : 0.0);
+  };
+  auto store2 = [&](double* row, int j, double2 val) {
+    if (!PADDED) { reinterpret_cast<double2*>(row)[lane + 64 * j] = val; return; }
+    const int x0 = 2 * (lane + 64 * j);
+    if (x0 < X) row[x0] = val.x;
+    if (x0 + 1 < X) row[x0 + 1] = val.y;
+  };
+  // graph u of the batch that starts at the wave's graph g4 of the pass whose first graph is b0
+  auto graph_of = [&](int b0, int g4, int u) { return b0 + wave * GPW + g4 + u; };
+  // requests sources q0, q0 + 1 (of the fused product; q0 = 0 with n_src = 0: the stored slot) of the batch's graphs
+  auto request = [&](int b0, int g4, int q0, double2 (&m)[PF][GU][H]) {
 #pragma unroll
-    for (int u = 0; u < GU; ++u) {
-      const int b = b0 + wave * GPW + g4 + u;
-      live[u] = b < d.B;
-      gin[u] = d.in + (size_t)(live[u] ? b : 0) * d.in_ld;
+    for (int f = 0; f < PF; ++f) {
+      if (f > 0 && q0 + f >= d.n_src) break;
+      const size_t so = (size_t)(d.n_src == 0 ? d.in_slot : d.src[q0 + f]) * X;
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int b = graph_of(b0, g4, u);
+        const double* gin = d.in + (size_t)(b < d.B ? b : 0) * d.in_ld + so;
+#pragma unroll
+        for (int j = 0; j < H; ++j) m[f][u][j] = load2(gin, j);
+      }
     }
-    // states 2 (lane + 64 j), + 1 of a row of X doubles; beyond X: zero
-    auto load2 = [&](const double* row, int j) {
-      if (!PADDED) return reinterpret_cast<const double2*>(row)[lane + 64 * j];
-      const int x0 = 2 * (lane + 64 * j);
-      return make_double2(x0 < X ? row[x0] : 0.0, x0 + 1 < X ? row[x0 + 1] : 0.0);
-    };
-    auto uniform2 = [&](int j) {
-      const int x0 = 2 * (lane + 64 * j);
-      return (!PADDED) ? make_double2(uniform, uniform) : make_double2(x0 < X ? uniform : 0.0, x0 + 1 < X ? uniform : 0.0);
-    };
-    auto store2 = [&](double* row, int j, double2 val) {
-      if (!PADDED) { reinterpret_cast<double2*>(row)[lane + 64 * j] = val; return; }
-      const int x0 = 2 * (lane + 64 * j);
-      if (x0 < X) row[x0] = val.x;
-      if (x0 + 1 < X) row[x0 + 1] = val.y;
-    };
+  };
+  // v <- v x sources q0, q0 + 1 in the reference's order, nan_to_num after each product (LBP.py:377-389)
+  auto multiply = [&](int q0, const double2 (&m)[PF][GU][H], double2 (&v)[GU][H]) {
+#pragma unroll
+    for (int f = 0; f < PF; ++f) {
+      if (q0 + f >= d.n_src) break;
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+          double px = m[f][u][j].x * v[u][j].x, py = m[f][u][j].y * v[u][j].y;
+          if (__builtin_expect(__any(!__builtin_isfinite(px) || !__builtin_isfinite(py)), 0)) { px = nan_to_num(px); py = nan_to_num(py); }
+          v[u][j] = make_double2(px, py);
+        }
+    }
+  };
+  // the batch's messages, given their first PF sources in m (requested earlier): the remaining sources, the renormalisation,
+  // the store of the variable->factor message when something later reads it, the LDS image
+  auto finish_prologue = [&](int b0, int g4, double2 (&m)[PF][GU][H]) {
+    double2 v[GU][H];
     if (d.n_src == 0) {
 #pragma unroll
       for (int u = 0; u < GU; ++u)
 #pragma unroll
-        for (int j = 0; j < H; ++j) v[u][j] = load2(gin[u] + (size_t)d.in_slot * X, j);
+        for (int j = 0; j < H; ++j) v[u][j] = m[0][u][j];
     } else {
 #pragma unroll
       for (int u = 0; u < GU; ++u)
 #pragma unroll
         for (int j = 0; j < H; ++j) v[u][j] = uniform2(j);
-      for (int q = 0; q < d.n_src; ++q) {
-        const size_t so = (size_t)d.src[q] * X;
-        double2 m[GU][H];
-#pragma unroll
-        for (int u = 0; u < GU; ++u)
-#pragma unroll
-          for (int j = 0; j < H; ++j) m[u][j] = load2(gin[u] + so, j);
-#pragma unroll
-        for (int u = 0; u < GU; ++u)
-#pragma unroll
-          for (int j = 0; j < H; ++j) {
-            double px = m[u][j].x * v[u][j].x, py = m[u][j].y * v[u][j].y;
-            if (__builtin_expect(__any(!__builtin_isfinite(px) || !__builtin_isfinite(py)), 0)) { px = nan_to_num(px); py = nan_to_num(py); }
-            v[u][j] = make_double2(px, py);
-          }
+      multiply(0, m, v);
+      for (int q = PF; q < d.n_src; q += PF) {
+        request(b0, g4, q, m);
+        multiply(q, m, v);
       }
       if (d.normalize) {
         double tot[GU];
@@ -204,8 +225,8 @@ __global__ __launch_bounds__(64 * NW) void contract_kernel(ContractDev d) {
       if (d.vf_slot >= 0) {
 #pragma unroll
         for (int u = 0; u < GU; ++u)
-          if (live[u]) {
-            double* o = d.out + (size_t)(b0 + wave * GPW + g4 + u) * d.out_ld + (size_t)d.vf_slot * X;
+          if (graph_of(b0, g4, u) < d.B) {
+            double* o = d.out + (size_t)graph_of(b0, g4, u) * d.out_ld + (size_t)d.vf_slot * X;
 #pragma unroll
             for (int j = 0; j < H; ++j) store2(o, j, v[u][j]);
           }
@@ -214,172 +235,208 @@ __global__ __launch_bounds__(64 * NW) void contract_kernel(ContractDev d) {
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
       mt_t* row = Mt + (wave * GPW + g4 + u) * XP;
+      const bool live = graph_of(b0, g4, u) < d.B;
 #pragma unroll
       for (int j = 0; j < H; ++j) {
-        row[2 * lane + 128 * j] = live[u] ? (mt_t)v[u][j].x : (mt_t)0;
-        row[2 * lane + 128 * j + 1] = live[u] ? (mt_t)v[u][j].y : (mt_t)0;
+        row[2 * lane + 128 * j] = live ? (mt_t)v[u][j].x : (mt_t)0;
+        row[2 * lane + 128 * j + 1] = live ? (mt_t)v[u][j].y : (mt_t)0;
       }
     }
-  }
-  __syncthreads();
+  };
 
-  // ---- main loop ----
   const avec* Af = reinterpret_cast<const avec*>(d.frag);
   const int gcol = lane & 15, krow = lane >> 4;
-  double4_t acc[RTW][NCT];
-#pragma unroll
-  for (int r = 0; r < RTW; ++r)
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) acc[r][c] = double4_t{0.0, 0.0, 0.0, 0.0};
-  // DEPTH register sets of A fragments in rotation, each requested DEPTH / 2 whole steps before it is used (the loop is
-  // unrolled by DEPTH so that no set is ever copied)
   constexpr int DIST = DEPTH / 2;
 #ifdef MLBP_CONTRACT_NOLOOP          // diagnostic build (tools/contract_probe.py): prologue + epilogue only
   constexpr int KB_RUN = 4;
 #else
   constexpr int KB_RUN = KB;
 #endif
-  avec a[DEPTH][RTW];
-  auto load_a = [&](avec (&dst)[RTW], int kb) {
-#pragma unroll
-    for (int r = 0; r < RTW; ++r) dst[r] = Af[((size_t)(wave + NW * r) * KB + kb) * 64 + lane];
-  };
-#pragma unroll
-  for (int s0 = 0; s0 < DIST; ++s0) load_a(a[s0], s0);
   static_assert(KB % 4 == 0 && (DEPTH == 2 || DEPTH == 4), "");
-  if constexpr (sizeof(TT) == 8) {
-    // The 16 x 16 x 4 product as FOUR v_mfma_f64_4x4x4 (4 blocks of 4 x 4 x 4): measured on this GPU the 16x16x4 form sustains
-    // 47-49 TFLOP/s, the 4x4x4 form 70-71 (tools/mfma_peak.hip, profiles/r02k_mfma_peak.txt).  Operand lanes (probed,
-    // profiles/r02k_mfma_f64_4x4x4_layout.txt): A_blk[i][k] at lane i + 4 blk + 16 k -- the 16x16x4 A fragment as it is,
-    // block = rows 4 blk .. 4 blk + 3; B_blk[k][j] at lane j + 4 blk + 16 k -- four graphs 4 q + j per instruction, the
-    // same in every block (LDS broadcast); D_blk[i][j] at lane j + 4 blk + 16 i, i.e. accumulator q of a lane holds
-    // (row 4 ((lane >> 2) & 3) + (lane >> 4), graph 4 q + (lane & 3)).
-    auto step = [&](const avec (&af)[RTW], int kb) {
+
+  // ---- main loop of one pass: acc = table x the LDS image ----
+  auto main_loop = [&](double4_t (&acc)[RTW][NCT]) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-#ifdef MLBP_CONTRACT_16X16          // A/B build: the single-instruction form
-        double bf[NCT];
+    for (int r = 0; r < RTW; ++r)
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) bf[c] = Mt[(16 * c + gcol) * XP + 8 * kb + 4 * e + krow];
+      for (int c = 0; c < NCT; ++c) acc[r][c] = double4_t{0.0, 0.0, 0.0, 0.0};
+    // DEPTH register sets of A fragments in rotation, each requested DEPTH / 2 whole steps before it is used (the loop is
+    // unrolled by DEPTH so that no set is ever copied)
+    avec a[DEPTH][RTW];
+    auto load_a = [&](avec (&dst)[RTW], int kb) {
 #pragma unroll
-        for (int r = 0; r < RTW; ++r)
-#pragma unroll
-          for (int c = 0; c < NCT; ++c)
-            acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(e ? af[r].y : af[r].x, bf[c], acc[r][c], 0, 0, 0);
-#else
-        double bf[NCT][4];
-#pragma unroll
-        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) bf[c][q] = Mt[(16 * c + 4 * q + (lane & 3)) * XP + 8 * kb + 4 * e + krow];
-#pragma unroll
-        for (int r = 0; r < RTW; ++r)
-#pragma unroll
-          for (int c = 0; c < NCT; ++c)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              acc[r][c][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(e ? af[r].y : af[r].x, bf[c][q], acc[r][c][q], 0, 0, 0);
-#endif
-      }
+      for (int r = 0; r < RTW; ++r) dst[r] = Af[((size_t)(wave + NW * r) * KB + kb) * 64 + lane];
     };
+#pragma unroll
+    for (int s0 = 0; s0 < DIST; ++s0) load_a(a[s0], s0);
+    if constexpr (sizeof(TT) == 8) {
+      // The 16 x 16 x 4 product as FOUR v_mfma_f64_4x4x4 (4 blocks of 4 x 4 x 4): measured on this GPU the 16x16x4 form sustains
+      // 47-49 TFLOP/s, the 4x4x4 form 70-71 (tools/mfma_peak.hip, profiles/r02k_mfma_peak.txt).  Operand lanes (probed,
+      // profiles/r02k_mfma_f64_4x4x4_layout.txt): A_blk[i][k] at lane i + 4 blk + 16 k -- the 16x16x4 A fragment as it is,
+      // block = rows 4 blk .. 4 blk + 3; B_blk[k][j] at lane j + 4 blk + 16 k -- four graphs 4 q + j per instruction, the
+      // same in every block (LDS broadcast); D_blk[i][j] at lane j + 4 blk + 16 i, i.e. accumulator q of a lane holds
+      // (row 4 ((lane >> 2) & 3) + (lane >> 4), graph 4 q + (lane & 3)).
+      auto step = [&](const avec (&af)[RTW], int kb) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#ifdef MLBP_CONTRACT_16X16          // A/B build: the single-instruction form
+          double bf[NCT];
+#pragma unroll
+          for (int c = 0; c < NCT; ++c) bf[c] = Mt[(16 * c + gcol) * XP + 8 * kb + 4 * e + krow];
+#pragma unroll
+          for (int r = 0; r < RTW; ++r)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+              acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(e ? af[r].y : af[r].x, bf[c], acc[r][c], 0, 0, 0);
+#else
+          double bf[NCT][4];
+#pragma unroll
+          for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bf[c][q] = Mt[(16 * c + 4 * q + (lane & 3)) * XP + 8 * kb + 4 * e + krow];
+#pragma unroll
+          for (int r = 0; r < RTW; ++r)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                acc[r][c][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(e ? af[r].y : af[r].x, bf[c][q], acc[r][c][q], 0, 0, 0);
+#endif
+        }
+      };
 #pragma unroll 1
-    for (int kb = 0; kb < KB_RUN; kb += DEPTH) {
+      for (int kb = 0; kb < KB_RUN; kb += DEPTH) {
 #pragma unroll
-      for (int s0 = 0; s0 < DEPTH; ++s0) {
-        if (kb + s0 + DIST < KB) load_a(a[(s0 + DIST) % DEPTH], kb + s0 + DIST);
-        step(a[s0], kb + s0);
-      }
-    }
-  } else {
-    // float32 products, summed in float32 over 64 states (4 fragment blocks) at a time, then added in float64
-    float4_t part[RTW][NCT];
-    auto step = [&](const avec (&af4)[RTW], int kb) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float bf[NCT];
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) bf[c] = Mt[(16 * c + gcol) * XP + 16 * kb + 4 * e + krow];
-#pragma unroll
-        for (int r = 0; r < RTW; ++r) {
-          const float af = e == 0 ? af4[r].x : (e == 1 ? af4[r].y : (e == 2 ? af4[r].z : af4[r].w));
-#pragma unroll
-          for (int c = 0; c < NCT; ++c) part[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[c], part[r][c], 0, 0, 0);
+        for (int s0 = 0; s0 < DEPTH; ++s0) {
+          if (kb + s0 + DIST < KB) load_a(a[(s0 + DIST) % DEPTH], kb + s0 + DIST);
+          step(a[s0], kb + s0);
         }
       }
-    };
+    } else {
+      // float32 products, summed in float32 over 64 states (4 fragment blocks) at a time, then added in float64
+      float4_t part[RTW][NCT];
+      auto step = [&](const avec (&af4)[RTW], int kb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float bf[NCT];
+#pragma unroll
+          for (int c = 0; c < NCT; ++c) bf[c] = Mt[(16 * c + gcol) * XP + 16 * kb + 4 * e + krow];
+#pragma unroll
+          for (int r = 0; r < RTW; ++r) {
+            const float af = e == 0 ? af4[r].x : (e == 1 ? af4[r].y : (e == 2 ? af4[r].z : af4[r].w));
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) part[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[c], part[r][c], 0, 0, 0);
+          }
+        }
+      };
 #pragma unroll 1
-    for (int kb = 0; kb < KB_RUN; kb += 4) {
+      for (int kb = 0; kb < KB_RUN; kb += 4) {
 #pragma unroll
-      for (int r = 0; r < RTW; ++r)
+        for (int r = 0; r < RTW; ++r)
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) part[r][c] = float4_t{0.f, 0.f, 0.f, 0.f};
+          for (int c = 0; c < NCT; ++c) part[r][c] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s0 = 0; s0 < 4; ++s0) {
-        if (kb + s0 + DIST < KB) load_a(a[(s0 + DIST) % DEPTH], kb + s0 + DIST);
-        step(a[s0 % DEPTH], kb + s0);
+        for (int s0 = 0; s0 < 4; ++s0) {
+          if (kb + s0 + DIST < KB) load_a(a[(s0 + DIST) % DEPTH], kb + s0 + DIST);
+          step(a[s0 % DEPTH], kb + s0);
+        }
+#pragma unroll
+        for (int r = 0; r < RTW; ++r)
+#pragma unroll
+          for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[r][c][i] += (double)part[r][c][i];
       }
-#pragma unroll
-      for (int r = 0; r < RTW; ++r)
-#pragma unroll
-        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[r][c][i] += (double)part[r][c][i];
     }
-  }
-  __syncthreads();                       // every wave has read its last message fragment: the image becomes the output
-  // ---- epilogue: accumulators -> LDS transposed ([graph][state], float64), renormalise, store whole rows ----
+  };
+
+  // ---- epilogue of one pass: accumulators -> LDS transposed ([graph][state], float64), renormalise, store whole rows
+  //      (every wave has read its last message fragment when this starts: the image becomes the output).
   // result element (row, col) of a 16 x 16 tile: float64 (four 4x4x4 MFMAs): see the main loop; float32 MFMA:
   // col = lane & 15 (graph), row = 4 (lane >> 4) + i
+  auto epilogue = [&](int b0, const double4_t (&acc)[RTW][NCT]) {
 #pragma unroll
-  for (int r = 0; r < RTW; ++r)
+    for (int r = 0; r < RTW; ++r)
 #pragma unroll
-    for (int c = 0; c < NCT; ++c)
+      for (int c = 0; c < NCT; ++c)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #ifndef MLBP_CONTRACT_16X16
-        if (sizeof(TT) == 8) {
-          Ot[(16 * c + 4 * i + (lane & 3)) * XP + 16 * (wave + NW * r) + 4 * ((lane >> 2) & 3) + krow] = acc[r][c][i];
-          continue;
-        }
+          if (sizeof(TT) == 8) {
+            Ot[(16 * c + 4 * i + (lane & 3)) * XP + 16 * (wave + NW * r) + 4 * ((lane >> 2) & 3) + krow] = acc[r][c][i];
+            continue;
+          }
 #endif
-        const int row = sizeof(TT) == 8 ? krow + 4 * i : 4 * krow + i;
-        Ot[(16 * c + gcol) * XP + 16 * (wave + NW * r) + row] = acc[r][c][i];
-      }
-  __syncthreads();
-  for (int g4 = 0; g4 < GPW; g4 += GU) {
-    double2 v[GU][H];
-    double tot[GU];
+          const int row = sizeof(TT) == 8 ? krow + 4 * i : 4 * krow + i;
+          Ot[(16 * c + gcol) * XP + 16 * (wave + NW * r) + row] = acc[r][c][i];
+        }
+    __syncthreads();
+    for (int g4 = 0; g4 < GPW; g4 += GU) {
+      double2 v[GU][H];
+      double tot[GU];
 #pragma unroll
-    for (int u = 0; u < GU; ++u) {
-      const double* row = Ot + (wave * GPW + g4 + u) * XP;
-      double part = 0.0;
-#pragma unroll
-      for (int j = 0; j < H; ++j) {
-        v[u][j] = make_double2(row[2 * lane + 128 * j], row[2 * lane + 128 * j + 1]);
-        part += v[u][j].x + v[u][j].y;
-      }
-      tot[u] = d.normalize ? wave_sum64(part) : 1.0;
-    }
-#pragma unroll
-    for (int u = 0; u < GU; ++u) {
-      const int b = b0 + wave * GPW + g4 + u;
-      if (b < d.B) {
-        double* o = d.out + (size_t)b * d.out_ld + (size_t)d.dst_slot * X;
+      for (int u = 0; u < GU; ++u) {
+        const double* row = Ot + (wave * GPW + g4 + u) * XP;
+        double part = 0.0;
 #pragma unroll
         for (int j = 0; j < H; ++j) {
-          const int x0 = 2 * (lane + 64 * j);
-          double2 val = v[u][j];
-          if (d.normalize) val = tot[u] > 0.0 ? make_double2(val.x / tot[u], val.y / tot[u]) : make_double2(uniform, uniform);
-          if (!PADDED) reinterpret_cast<double2*>(o)[lane + 64 * j] = val;
-          else {
-            if (x0 < X) o[x0] = val.x;
-            if (x0 + 1 < X) o[x0 + 1] = val.y;
+          v[u][j] = make_double2(row[2 * lane + 128 * j], row[2 * lane + 128 * j + 1]);
+          part += v[u][j].x + v[u][j].y;
+        }
+        tot[u] = d.normalize ? wave_sum64(part) : 1.0;
+      }
+#pragma unroll
+      for (int u = 0; u < GU; ++u) {
+        const int b = graph_of(b0, g4, u);
+        if (b < d.B) {
+          double* o = d.out + (size_t)b * d.out_ld + (size_t)d.dst_slot * X;
+#pragma unroll
+          for (int j = 0; j < H; ++j) {
+            double2 val = v[u][j];
+            if (d.normalize) val = tot[u] > 0.0 ? make_double2(val.x / tot[u], val.y / tot[u]) : make_double2(uniform, uniform);
+            store2(o, j, val);
           }
         }
       }
     }
+  };
+
+#ifdef MLBP_CONTRACT_STAGGER         // experiment: the second half of the grid starts late (units of 64 * 127 clocks)
+  if (blockIdx.x >= gridDim.x / 2)
+    for (int i = 0; i < MLBP_CONTRACT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+  double4_t acc[RTW][NCT];
+  const int b_first = blockIdx.x * (NT_G * HALVES);
+  {
+    double2 m[PF][GU][H];
+    for (int g4 = 0; g4 < GPW; g4 += GU) {
+      request(b_first, g4, 0, m);
+      finish_prologue(b_first, g4, m);
+    }
+  }
+  __syncthreads();
+  if constexpr (HALVES == 1) {
+    main_loop(acc);
+    __syncthreads();
+    epilogue(b_first, acc);
+  } else {
+    const int b_second = b_first + NT_G;
+    const bool second = b_second < d.B;                          // (uniform over the workgroup)
+    double2 m[PF][GU][H];
+    if (second) request(b_second, 0, 0, m);                      // in flight under the first pass's main loop
+    main_loop(acc);
+    __syncthreads();
+    epilogue(b_first, acc);                                      // its stores drain under the second pass
+    if (!second) return;
+    __syncthreads();                                             // the image is free again
+    finish_prologue(b_second, 0, m);
+    __syncthreads();
+    main_loop(acc);
+    __syncthreads();
+    epilogue(b_second, acc);
   }
 }
+
 
 template <typename TT>
 size_t contract_lds_bytes(int X, int nct) {
@@ -392,14 +449,28 @@ template <typename TT, int RT, bool PADDED>
 int launch_contract_rt(const ContractDev& d, int nct, hipStream_t st) {
   const int XA = 64 * RT;
   const int ntg = 16 * nct;
-  const size_t lds = contract_lds_bytes<TT>(XA, nct);
+  size_t lds_bytes = contract_lds_bytes<TT>(XA, nct);
   // 32 graphs per workgroup (float64, small tables, big batches): 4 waves, deep fragment prefetch; else 16 graphs per
   // workgroup and 8 waves (two workgroups = 4 waves per SIMD hide each other's stalls; measured 3-7 % over 4 waves)
   void (*k)(ContractDev) = nullptr;
-  if constexpr (PADDED) k = contract_kernel<TT, RT, 1, 2, 8, true>;
-  else k = nct == 2 ? contract_kernel<TT, RT, 2, 4, 4, false>
-                    : (sizeof(TT) == 8 ? contract_kernel<TT, RT, 1, 2, 8, false> : contract_kernel<TT, RT, 1, 4, 8, false>);
-  const int threads = nct == 2 ? WG : 512;
+  if constexpr (PADDED) k = contract_kernel<TT, RT, 1, 2, 8, true, 1>;
+  else k = nct == 2 ? contract_kernel<TT, RT, 2, 4, 4, false, 1>
+                    : (sizeof(TT) == 8 ? contract_kernel<TT, RT, 1, 2, 8, false, 1> : contract_kernel<TT, RT, 1, 4, 8, false, 1>);
+  int threads = nct == 2 ? WG : 512, graphs_per_wg = ntg;
+#ifdef MLBP_CONTRACT_EXPERIMENT      // tools/contract_probe.py -DMLBP_CONTRACT_EXPERIMENT=n: the round-3 forms that did not pay
+  if constexpr (!PADDED && (4 * RT) % 16 == 0) {
+    if (nct == 1 && d.B > 16) {
+      threads = 1024;
+      if (MLBP_CONTRACT_EXPERIMENT == 1) {          // two passes per workgroup, the second's sources requested under the first's loop
+        k = contract_kernel<TT, RT, 1, 4, 16, false, 2>; graphs_per_wg = 32;
+      } else if (MLBP_CONTRACT_EXPERIMENT == 2) {   // 16 graphs per 16-wave workgroup at 64 registers: 8 waves per SIMD
+        k = contract_kernel<TT, RT, 1, 2, 16, false, 1>; graphs_per_wg = 16;
+      } else {                                      // 32 graphs per 16-wave workgroup: half the table traffic per graph
+        k = contract_kernel<TT, RT, 2, 2, 16, false, 1>; graphs_per_wg = 32; lds_bytes = contract_lds_bytes<TT>(XA, 2);
+      }
+    }
+  }
+#endif
   static std::mutex mu;
   static std::vector<const void*> granted;
   {
@@ -412,7 +483,7 @@ int launch_contract_rt(const ContractDev& d, int nct, hipStream_t st) {
       granted.push_back((const void*)k);
     }
   }
-  hipLaunchKernelGGL(k, dim3((d.B + ntg - 1) / ntg), dim3(threads), lds, st, d);
+  hipLaunchKernelGGL(k, dim3((d.B + graphs_per_wg - 1) / graphs_per_wg), dim3(threads), lds_bytes, st, d);
   return MLBP_OK;
 }
 

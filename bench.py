@@ -253,7 +253,7 @@ def main():
     ap.add_argument('--no-writeback', action='store_true', help='shared workload: skip the message write-back (read-out only)')
     ap.add_argument('--batch', type=int, default=8192, help='graphs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-skip-unchanged', action='store_true', help='leave out the secondary MLBP_SWEEP_SKIP_UNCHANGED measurement (profiling runs: only the full schedule is launched)')
+    ap.add_argument('--no-skip-unchanged', action='store_true', help='leave out the secondary measurements -- MLBP_SWEEP_SKIP_UNCHANGED and the train step (profiling runs: only the full schedule of the sweep call is launched)')
     ap.add_argument('--sweeps', type=int, default=None, help='override sweeps per step (roots cycle)')
     ap.add_argument('--variant', type=int, default=None, help='mlbp_set_sweep_variant (A/B measurement)')
     ap.add_argument('--traffic-bytes', type=float, default=None,
@@ -468,7 +468,7 @@ def main():
     # on the same batch -- initialize + sweeps + per-graph gradient + log-posterior + the batch sums of batch_sgd_accumulate --
     # timed after the windows (HIP events, rank 0), never `value`.
     train = None
-    if rank == 0 and spec['style'] == 'trainmp' and X == 64:
+    if rank == 0 and spec['style'] == 'trainmp' and X == 64 and not a.no_skip_unchanged:      # (profiling runs launch the sweep call only)
         by_id = {f['id']: f for f in spec['factors']}
         pair_phi = [0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1 for j in topo.pair_factors]
         ukind = [2 if by_id[topo.factor_ids[j]]['factor_type'] == 'en_de' else (0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1)

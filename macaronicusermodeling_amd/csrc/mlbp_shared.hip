@@ -612,7 +612,7 @@ __device__ __forceinline__ int index_in_half(int mode, int sel) { return ((mode 
 // group k's SharedDev, gstart[k] its first workgroup; the workgroup looks its group up and runs as if launched for it alone.
 // (the body: `d` is the kernel argument, or -- MULTI -- a reference into the group table through the scalar data cache, so
 // that in both forms the description sits in SGPRs / is fetched by scalar loads where it is used)
-template <int NTAB, bool SPILL, bool WIDE, typename Dev>
+template <int NTAB, bool SPILL, bool WIDE, bool GRAD, typename Dev>
 __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   extern __shared__ double lds[];
   double* tiles = lds;                                           // [n_res][64 states][16 graphs]
@@ -965,7 +965,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   }
   if (bad && gvalid) d.bail[gi] = 2;                             // any wave that saw it says so (idempotent)
   STAMP(5)
-  if (!d.gr.enabled) {
+  if (!GRAD || !d.gr.enabled) {                                  // (GRAD is a template parameter: the sweeps-only instances do not carry the epilogue's registers)
     STAMP_FLUSH
     return;
   }
@@ -1126,15 +1126,18 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
 }
 
 typedef const SharedDev __attribute__((address_space(4))) SharedDevConst;
-template <int NTAB, bool SPILL, bool WIDE, bool MULTI>
+template <int NTAB, bool SPILL, bool WIDE, bool MULTI, bool GRAD>
 __global__ __launch_bounds__(SWG, 4) void sweep_x64_shared_kernel(SharedDev d, const SharedDev* gtab, const int32_t* gstart, int n_groups) {
   if (MULTI) {
     const int lo = find_group(gstart, n_groups, blockIdx.x);
     SharedDevConst& dg = *(SharedDevConst*)(uintptr_t)(gtab + lo);
-    sweep_x64_shared_body<NTAB, SPILL, WIDE>(dg, (int)blockIdx.x - as_const(gstart)[lo]);
+    sweep_x64_shared_body<NTAB, SPILL, WIDE, GRAD>(dg, (int)blockIdx.x - as_const(gstart)[lo]);
   } else {
-    const SharedDev& dk = d;
-    sweep_x64_shared_body<NTAB, SPILL, WIDE>(dk, (int)blockIdx.x);
+    // the description is the first kernel argument: read where it is used, through the scalar cache, out of the kernel
+    // argument segment -- preloaded as a by-value struct its 80 words crowd the scalar registers of the main loop
+    (void)d;
+    SharedDevConst& dk = *(SharedDevConst*)__builtin_amdgcn_kernarg_segment_ptr();
+    sweep_x64_shared_body<NTAB, SPILL, WIDE, GRAD>(dk, (int)blockIdx.x);
   }
 }
 
@@ -1340,13 +1343,16 @@ std::mutex g_attr_mutex;
 typedef void (*sweep_fn)(SharedDev, const SharedDev*, const int32_t*, int);
 
 // the instance for (two tables?, spilled tiles?, more than two sources?, groups?); raises its dynamic LDS limit once
-int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, size_t lds, sweep_fn* out) {
+int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, size_t lds, sweep_fn* out) {
   sweep_fn k = nullptr;
 #ifdef MLBP_STAMPS      // the diagnostic build instantiates the all-resident two-source kernels only
   if (spill || wide || multi) return fail(MLBP_EUNSUPPORTED, "stamps build: no spilling / wide / grouped instance");
-  k = two ? sweep_x64_shared_kernel<2, false, false, false> : sweep_x64_shared_kernel<1, false, false, false>;
+  k = two ? (grad ? sweep_x64_shared_kernel<2, false, false, false, true> : sweep_x64_shared_kernel<2, false, false, false, false>)
+          : (grad ? sweep_x64_shared_kernel<1, false, false, false, true> : sweep_x64_shared_kernel<1, false, false, false, false>);
 #else
-#define MLBP_SK(T, S, W, M) sweep_x64_shared_kernel<T, S, W, M>
+  // (the gradient epilogue comes with at most three pairwise factors: such programs never spill tiles)
+  if (grad && spill) return fail(MLBP_EUNSUPPORTED, "shared-table kernel: no instance with both the gradient epilogue and spilled tiles");
+#define MLBP_SK(T, S, W, M) (grad ? (S ? (sweep_fn) nullptr : (sweep_fn)sweep_x64_shared_kernel<T, false, W, M, true>) : (sweep_fn)sweep_x64_shared_kernel<T, S, W, M, false>)
 #define MLBP_SK_M(T, S, W) (multi ? MLBP_SK(T, S, W, true) : MLBP_SK(T, S, W, false))
 #define MLBP_SK_W(T, S) (wide ? MLBP_SK_M(T, S, true) : MLBP_SK_M(T, S, false))
 #define MLBP_SK_S(T) (spill ? MLBP_SK_W(T, true) : MLBP_SK_W(T, false))
@@ -1367,8 +1373,8 @@ int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, size_t lds, s
       granted.push_back({(const void*)k, lds});
       int per_cu = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, SWG, lds) == hipSuccess)
-        fail(MLBP_OK, "shared-table kernel <%d%s%s%s>: %zu bytes of LDS per workgroup, %d workgroups per CU", two ? 2 : 1,
-             spill ? ", spilling" : "", wide ? ", wide" : "", multi ? ", groups" : "", lds, per_cu);
+        fail(MLBP_OK, "shared-table kernel <%d%s%s%s%s>: %zu bytes of LDS per workgroup, %d workgroups per CU", two ? 2 : 1,
+             spill ? ", spilling" : "", wide ? ", wide" : "", multi ? ", groups" : "", grad ? ", gradient" : "", lds, per_cu);
     }
   }
   *out = k;
@@ -1394,7 +1400,7 @@ bool shared_gradient_fused(const mlbp_program* prog, const mlbp_sweep_args* a) {
   if (!ga || !exact_kernel_fuses_gradient(prog, a)) return false;
   return (ga->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && prog->P >= 1 && a->n_pair_tables <= FRAG_TABLES && ga->phi_en_en_p &&
          ga->phi_en_en_w1_p && ga->phi_en_en && ga->phi_en_en_w1 && (prog->U == 0 || (ga->unary_expect && ga->phi_en_de)) && a->msgs &&
-         prog->shared.ok && resident_tiles(prog->shared, nullptr) >= 3;
+         prog->shared.ok && prog->shared.n_live >= 3 && resident_tiles(prog->shared, nullptr) == prog->shared.n_live;   // (every tile in LDS)
 }
 
 namespace {
@@ -1519,7 +1525,7 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   hipLaunchKernelGGL(shared_prepare_kernel<false>, dim3(pl.n_prep_blocks), dim3(PWG), 0, st, pl.q, nullptr, nullptr, 0);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
   sweep_fn k = nullptr;
-  if (int e = pick_sweep_kernel(prog->P >= 2, pl.spill, pl.wide, false, pl.lds, &k)) return e;
+  if (int e = pick_sweep_kernel(prog->P >= 2, pl.spill, pl.wide, false, pl.d.gr.enabled != 0, pl.lds, &k)) return e;
   hipLaunchKernelGGL(k, dim3(pl.n_wg), dim3(SWG), pl.lds, st, pl.d, nullptr, nullptr, 0);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed");
   if (int e = enqueue_unary_writeback(prog, a, pl.d, st)) return e;
@@ -1536,7 +1542,7 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   if (n_groups < 1) return MLBP_OK;
   std::vector<SharedPlan> plans(n_groups);
   size_t lds = 0;
-  bool wide = false, spill = false, two = false;
+  bool wide = false, spill = false, two = false, grad = false;
   for (int k = 0; k < n_groups; ++k) {
     if (!progs[k]) return MLBP_OK;
     for (int j = 0; j < k; ++j)
@@ -1545,8 +1551,9 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
     if (int e = shared_plan(progs[k], &args[k], &ok, &plans[k])) return e;
     if (!ok) return MLBP_OK;
     lds = std::max(lds, plans[k].lds);
-    wide |= plans[k].wide; spill |= plans[k].spill; two |= progs[k]->P >= 2;
+    wide |= plans[k].wide; spill |= plans[k].spill; two |= progs[k]->P >= 2; grad |= plans[k].d.gr.enabled != 0;
   }
+  if (grad && spill) return MLBP_OK;                 // no such instance (one group spills tiles, another carries the gradient): group by group
   // table image: [SharedDev x n][PrepareDev x n][sweep starts n + 1][prepare starts n + 1], as 32-bit words
   const size_t w_sd = sizeof(SharedDev) / 4, w_pd = sizeof(PrepareDev) / 4;
   static_assert(sizeof(SharedDev) % 8 == 0 && sizeof(PrepareDev) % 8 == 0, "group tables are copied as words");
@@ -1579,7 +1586,7 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), 0, st, plans[0].q, d_pd, d_starts + n_groups + 1, n_groups);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
   sweep_fn k = nullptr;
-  if (int e = pick_sweep_kernel(two, spill, wide, true, lds, &k)) return e;
+  if (int e = pick_sweep_kernel(two, spill, wide, true, grad, lds, &k)) return e;
   hipLaunchKernelGGL(k, dim3(wg), dim3(SWG), lds, st, plans[0].d, d_sd, d_starts, n_groups);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed");
   for (int g = 0; g < n_groups; ++g)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (not product): builds a -DMLBP_STAMPS copy of libmlbp.so under gpurun_out/ and prints
-the share of shader-clock cycles each phase of the fused sweep kernel takes (wave 0 of the first 64
-workgroups).  Shares only -- the stamped build is slower than the shipped one."""
+the share of shader-clock cycles each phase of the EXACT X = 64 kernel (sweep_x64_fused_kernel, variant 3) takes (wave 0 of
+the first 64 workgroups; the lean kernel has tools/lean_probe.py, the shared-table kernel tools/stamp_shared.py).  Shares only -- the stamped build is slower than the shipped one."""
 import ctypes as C
 import os
 import subprocess
@@ -28,7 +28,7 @@ from macaronicusermodeling_amd.batch import FactorGraphBatch  # noqa: E402
 from macaronicusermodeling_amd.topology import GraphTopology  # noqa: E402
 
 workload = sys.argv[1] if len(sys.argv) > 1 else 'user_k3'
-variant = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+variant = 3          # the exact kernel on every graph (variants 0 and 2, the kernels this tool once stamped, were retired in round 3)
 spec, roots, sweeps, seed = bench.workload_spec(workload)
 X, B = spec['X'], 8192
 topo = GraphTopology.from_spec(spec)
@@ -45,9 +45,7 @@ torch.cuda.synchronize()
 raw = buf.cpu().numpy().reshape(64, 8)
 print('debug bits of phase 2 (wg0): slow=%d neg=%d inf=%d allzero=%d' % ((raw[0,2]>>40)&15, (raw[0,2]>>44)&15, (raw[0,2]>>48)&15, (raw[0,2]>>52)&15))
 t = (raw & ((1<<40)-1)).astype(float)
-names = (['A: indices, image, messages', 'B: tables + unary + products (incl. load latency)', 'loop: inputs + partials', 'loop: barrier',
-          'loop: gather + rescale', 'final normalisation', 'write-back + marginals', '-'] if variant == 1 else
-         ['prologue', 'op header', 'var product', 'var normalise', 'pair partials', 'barrier', 'gather partials', 'pair normalise'])
+names = ['prologue', 'op header', 'var product', 'var normalise', 'pair partials', 'barrier', 'gather partials', 'pair normalise']
 tot = t.sum(1).mean()
 print('workload %s variant %d: mean cycles per workgroup %.0f' % (workload, variant, tot))
 for i, n in enumerate(names):

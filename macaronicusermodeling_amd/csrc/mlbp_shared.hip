@@ -1350,9 +1350,10 @@ int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, si
   k = two ? (grad ? sweep_x64_shared_kernel<2, false, false, false, true> : sweep_x64_shared_kernel<2, false, false, false, false>)
           : (grad ? sweep_x64_shared_kernel<1, false, false, false, true> : sweep_x64_shared_kernel<1, false, false, false, false>);
 #else
-  // (the gradient epilogue comes with at most three pairwise factors: such programs never spill tiles)
-  if (grad && spill) return fail(MLBP_EUNSUPPORTED, "shared-table kernel: no instance with both the gradient epilogue and spilled tiles");
-#define MLBP_SK(T, S, W, M) (grad ? (S ? (sweep_fn) nullptr : (sweep_fn)sweep_x64_shared_kernel<T, false, W, M, true>) : (sweep_fn)sweep_x64_shared_kernel<T, S, W, M, false>)
+  // (the gradient epilogue comes with at most three pairwise factors and every tile in LDS: a variable with three pairwise
+  // factors has three neighbours, and four variables' tiles do not fit -- so neither spilled tiles nor three-source updates)
+  if (grad && (spill || wide)) return fail(MLBP_EUNSUPPORTED, "shared-table kernel: no instance with the gradient epilogue and spilled tiles or wide updates");
+#define MLBP_SK(T, S, W, M) (grad ? ((S || W) ? (sweep_fn) nullptr : (sweep_fn)sweep_x64_shared_kernel<T, false, false, M, true>) : (sweep_fn)sweep_x64_shared_kernel<T, S, W, M, false>)
 #define MLBP_SK_M(T, S, W) (multi ? MLBP_SK(T, S, W, true) : MLBP_SK(T, S, W, false))
 #define MLBP_SK_W(T, S) (wide ? MLBP_SK_M(T, S, true) : MLBP_SK_M(T, S, false))
 #define MLBP_SK_S(T) (spill ? MLBP_SK_W(T, true) : MLBP_SK_W(T, false))
@@ -1400,7 +1401,8 @@ bool shared_gradient_fused(const mlbp_program* prog, const mlbp_sweep_args* a) {
   if (!ga || !exact_kernel_fuses_gradient(prog, a)) return false;
   return (ga->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && prog->P >= 1 && a->n_pair_tables <= FRAG_TABLES && ga->phi_en_en_p &&
          ga->phi_en_en_w1_p && ga->phi_en_en && ga->phi_en_en_w1 && (prog->U == 0 || (ga->unary_expect && ga->phi_en_de)) && a->msgs &&
-         prog->shared.ok && prog->shared.n_live >= 3 && resident_tiles(prog->shared, nullptr) == prog->shared.n_live;   // (every tile in LDS)
+         prog->shared.ok && prog->shared.n_live >= 3 && resident_tiles(prog->shared, nullptr) == prog->shared.n_live &&   // (every tile in LDS,
+         prog->shared.max_sources <= 2;                                                                            //  two-source updates)
 }
 
 namespace {
@@ -1553,7 +1555,7 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
     lds = std::max(lds, plans[k].lds);
     wide |= plans[k].wide; spill |= plans[k].spill; two |= progs[k]->P >= 2; grad |= plans[k].d.gr.enabled != 0;
   }
-  if (grad && spill) return MLBP_OK;                 // no such instance (one group spills tiles, another carries the gradient): group by group
+  if (grad && (spill || wide)) return MLBP_OK;       // no such instance (one group spills tiles or has wide updates, another carries the gradient): group by group
   // table image: [SharedDev x n][PrepareDev x n][sweep starts n + 1][prepare starts n + 1], as 32-bit words
   const size_t w_sd = sizeof(SharedDev) / 4, w_pd = sizeof(PrepareDev) / 4;
   static_assert(sizeof(SharedDev) % 8 == 0 && sizeof(PrepareDev) % 8 == 0, "group tables are copied as words");

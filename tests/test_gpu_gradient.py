@@ -484,10 +484,31 @@ def test_tidir_trainer_sweeps_all_sentence_shapes_in_one_launch(tmp_path):
         t.theta_en_de += torch.tensor([0.2, 0.1, -0.3, 0.05, 0.0, 0.1], dtype=torch.float64, device=t.theta_en_de.device)
     sa = a.local_statistics().clone()
     assert _ffi.lib.mlbp_last_sweep_kernel() == 3       # MLBP_KERNEL_SHARED_MFMA ran the groups
+    assert _ffi.lib.mlbp_last_sweep_fused_gradient() == 1   # ... and each group's gradient as its epilogue
     assert sum(tr.batch.program(tr.roots[:tr.n_sweeps_run]).exact_count(tr.batch.B) for tr in a._full.trainers.values()) == 0
     sb = b.local_statistics().clone()
     np.testing.assert_allclose(sa.cpu().numpy(), sb.cpu().numpy(), rtol=1e-9, atol=1e-12)
     ha, hb = a.train(epochs=2, reg_param=0.2), b.train(epochs=2, reg_param=0.2)
+    np.testing.assert_allclose(ha, hb, rtol=1e-9)
+    np.testing.assert_allclose(a.theta_en_de.cpu().numpy(), b.theta_en_de.cpu().numpy(), rtol=1e-8, atol=1e-12)
+
+
+def test_tidir_trainer_groups_with_larger_cliques_fall_back_group_by_group(tmp_path):
+    """Sentences with up to four predicted words: the K4 buckets (six pairwise factors: separate gradient launches, spilled
+    tiles) cannot share a launch with the K2 / K3 buckets that carry the gradient as their sweep kernel's epilogue --
+    mlbp_sweep_groups_f64 then runs group by group.  Same statistics and the same training as per-bucket launches."""
+    from macaronicusermodeling_amd import tidir
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    paths = tidir.synthesize(str(tmp_path), n_instances=36, X=64, Vde=64, sent_len=(5, 8), n_predicted=(2, 4), seed=33)
+    mk = lambda grouped: TiDirTrainer(paths['ti'], paths['end'], paths['ded'], paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'],
+                                      paths['phi_ped'], sweeps=3, grouped_sweeps=grouped)
+    a, b = mk(True), mk(False)
+    assert {tr.topo.P for tr in a._full.trainers.values()} >= {1, 3, 6}
+    for t in (a, b):
+        t.theta_en_en += torch.tensor([0.3, -0.2, 0.1], dtype=torch.float64, device=t.theta_en_en.device)
+        t.theta_en_de += torch.tensor([0.2, 0.1, -0.3, 0.05, 0.0, 0.1], dtype=torch.float64, device=t.theta_en_de.device)
+    np.testing.assert_allclose(a.local_statistics().cpu().numpy(), b.local_statistics().cpu().numpy(), rtol=1e-9, atol=1e-12)
+    ha, hb = a.train(epochs=3, reg_param=0.2), b.train(epochs=3, reg_param=0.2)       # (three epochs: replayed from a HIP graph)
     np.testing.assert_allclose(ha, hb, rtol=1e-9)
     np.testing.assert_allclose(a.theta_en_de.cpu().numpy(), b.theta_en_de.cpu().numpy(), rtol=1e-8, atol=1e-12)
 

@@ -454,6 +454,70 @@ __global__ __launch_bounds__(WG) void sum_rows_kernel(SumCat cat, int64_t rows, 
 }
 
 
+// mlbp_step_statistics_f64 at the trainer's feature counts: sum_rows_kernel's arithmetic in its order (so: its bits), with a
+// row's nine gradient entries, its labels and the marginals they select requested together -- the generic kernel walks the
+// three arrays one after the other, three rounds of memory latency in a launch that is little else.
+template <int C0, int C1>
+__global__ __launch_bounds__(WG) void step_statistics_kernel(SumCat cat, int64_t rows, double* out) {
+  constexpr int NC = C0 + C1 + 1;
+  __shared__ double part[WG / 64][NC];
+  __shared__ bool last;
+  const int64_t per = (rows + SUM_PARTS - 1) / SUM_PARTS;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) acc[j] = 0.0;
+  for (int64_t b = r0 + threadIdx.x; b < r1; b += WG) {
+    double v[C0 + C1];
+#pragma unroll
+    for (int j = 0; j < C0; ++j) v[j] = cat.in[0][b * C0 + j];
+#pragma unroll
+    for (int j = 0; j < C1; ++j) v[C0 + j] = cat.in[1][b * C1 + j];
+    double total = 0.0;
+    for (int vi = 0; vi < cat.n_vars; ++vi) {
+      const int lab = cat.labels[b * cat.n_vars + vi];
+      if ((unsigned)lab >= (unsigned)cat.X) { atomicExch(cat.status, 1); continue; }
+      const double lp = log(cat.marg[(b * cat.n_vars + vi) * cat.X + lab]);
+      total += (lp == -__builtin_huge_val()) ? -99.99 : lp;  // LBP.py:254-256
+    }
+    if (cat.lp_out) cat.lp_out[b] = total;
+#pragma unroll
+    for (int j = 0; j < C0 + C1; ++j) acc[j] += v[j];
+    acc[NC - 1] += total;
+  }
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    const double s = wave_sum(acc[j]);
+    if (lane == 0) part[wave][j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NC) {
+    double v = part[0][threadIdx.x];
+    for (int w = 1; w < WG / 64; ++w) v += part[w][threadIdx.x];
+    g_sum_partials[blockIdx.x * 64 + threadIdx.x] = v;
+    __threadfence();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(&g_sum_done, 1u) == SUM_PARTS - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x < NC) {
+    double p[SUM_PARTS];
+#pragma unroll
+    for (int q = 0; q < SUM_PARTS; ++q) p[q] = __builtin_nontemporal_load(&g_sum_partials[q * 64 + threadIdx.x]);
+    double a = 0.0;
+#pragma unroll
+    for (int q = 0; q < SUM_PARTS; ++q) a += p[q];
+    out[threadIdx.x] = a;
+  }
+  if (threadIdx.x == 0) { out[NC] = (double)rows; g_sum_done = 0; }
+}
+
 // out[s][j] = sum over the rows b with seg_id[b] == s of in[b][j]: one workgroup per segment, fixed order
 // (thread-strided partial sums, then a tree) -- the per-domain half of batch_sgd_accumulate (train_mp.py:413-415).
 __global__ __launch_bounds__(WG) void segment_sum_rows_kernel(const double* in, int64_t rows, int cols, const int32_t* seg_id,
@@ -651,7 +715,8 @@ int mlbp_step_statistics_f64(const double* grad_en_en, int32_t F_ee, const doubl
   SumCat cat = {{grad_en_en, grad_en_de, marginals}, {F_ee, F_ed, 1}, marginals, labels, n_vars, X, lp_out, nullptr};
   if (int e = status_word(&cat.status)) return e;
   // (the partials live in one device-wide scratch array, as for mlbp_sum_rows_cat_f64)
-  hipLaunchKernelGGL(sum_rows_kernel, dim3(SUM_PARTS), dim3(WG), 0, (hipStream_t)stream, cat, B, 1, out);
+  if (F_ee == 3 && F_ed == 6) hipLaunchKernelGGL((step_statistics_kernel<3, 6>), dim3(SUM_PARTS), dim3(WG), 0, (hipStream_t)stream, cat, B, out);
+  else hipLaunchKernelGGL(sum_rows_kernel, dim3(SUM_PARTS), dim3(WG), 0, (hipStream_t)stream, cat, B, 1, out);
   HIP_TRY(hipGetLastError());
   return MLBP_OK;
 }

@@ -941,6 +941,9 @@ static int lean_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool gr
   *lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 4 * 256) * sizeof(double) + 16 * (size_t)(lp.n_bundles + 1) * sizeof(int32_t);
   if (prog->P == 7 && !padx) *lds += 32 * 1024;   // the seventh table lives in LDS
   if (grad) *lds += 5 * (size_t)prog->U * sizeof(int32_t);
+#ifdef MLBP_LEAN_EXTRA_LDS            // diagnostic build (tools/lean_occupancy.py): fewer workgroups per CU, same kernel
+  *lds += MLBP_LEAN_EXTRA_LDS;
+#endif
   if (*lds > 80 * 1024) return MLBP_OK;           // large graphs: the generic kernel's rules apply
   const bool dense = (a->flags & MLBP_SWEEP_DENSE_TABLES) != 0;
   if (dense && ((int64_t)a->B * prog->P > a->n_pair_tables || (int64_t)a->B * prog->U > a->n_unary_tables))

@@ -475,7 +475,10 @@ def main():
                  for j in topo.unary_factors]
         rs = np.random.RandomState(seed + 5)
         Vde = spec['Vde']
-        fb.set_features(rs.rand(X, X, 3), rs.rand(X, X, 3), rs.rand(X, Vde, 6), pair_phi, ukind)
+        f_ee, f_w1 = rs.rand(X, X, 3), rs.rand(X, X, 3)
+        if a.workload.endswith('_trainlayout'):      # the trainer's tensors as train_mp.py:600-606 stacks them: [pmi, 0, 1] and [pmi, pmi_w1, 1]
+            f_ee[:, :, 1] = 0.0; f_ee[:, :, 2] = 1.0; f_w1[:, :, 0] = f_ee[:, :, 0]; f_w1[:, :, 2] = 1.0
+        fb.set_features(f_ee, f_w1, rs.rand(X, Vde, 6), pair_phi, ukind)
         obs = np.stack([rs.randint(0, Vde if k == 2 else X, size=B) for k in ukind], axis=1)
         if a.workload.endswith('_trainlayout'):
             obs = unary_tab - np.array(ukind)[None, :] * 64           # the observed word IS the row a factor reads

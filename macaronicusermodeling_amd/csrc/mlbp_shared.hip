@@ -374,6 +374,7 @@ struct SharedGradDev {
   const int32_t* c_slot; const int32_t* r_slot; const int32_t* pair_phi; const int32_t* pair_label;
   const double* phi[2];         // interleaved [64][64][3]: the label term
   const double* wfrag;          // [table][which][4][4096] A fragments of T (.) phi_k and T (shared_prepare_kernel)
+  const int32_t* plane_flags;   // [which][4]: feature plane k of tensor `which` is 0 general | 1 all zeros | 2 all ones (same launch)
   double* grad_en_en;           // [B][3]: the unary factors' terms are there (shared_prepare_kernel), the pairwise ones are added
   int32_t enabled, pad_;
 };
@@ -455,6 +456,7 @@ struct PrepareDev {
   const double* pair_tables; double* tfrag; int32_t n_frag_tables;
   int32_t n_wfrag_tables;                                        // > 0: also the gradient's weighted fragments, T (.) phi_k and T
   double* wfrag; const double* phi_p0; const double* phi_p1;     // wfrag [table][which][4][4096]; phi planar [3][64][64]
+  int32_t* plane_flags;                                          // [2][4] (behind wfrag): constant feature planes, see SharedGradDev
   // ... and the unary factors' gradient terms, phi[label][obs][:] - E[table row][:] (E from mlbp_unary_expectations_f64), summed
   // per graph into grad_en_en [B][3] / grad_en_de [B][6] (assigned: the sweep kernel's epilogue adds the pairwise terms)
   const double* unary_expect; const int32_t* unary_kind; const int32_t* unary_obs; const int32_t* unary_label;
@@ -500,6 +502,19 @@ __global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d, const
       const int idx = (16 * w + (l & 15)) * 64 + 4 * sk + (l >> 4);
       o[e] = k < 3 ? T[idx] * ph[idx] : T[idx];
     }
+  }
+  // ... and which feature planes are constant: the reference's tensors are [pmi, 0, 1] and [pmi, pmi_w1, 1]
+  // (train_mp.py:600-606: a zero plane and the bias), and for those the epilogue needs no contraction -- the expected
+  // feature is 0 resp. the belief's total.  One job per plane, on the blocks behind the fragment jobs.
+  for (int q = block - 2 * d.n_frag_tables - 32 * d.n_wfrag_tables; q < (d.n_wfrag_tables > 0 ? 6 : 0); q += n_blocks) {
+    if (q < 0) continue;
+    const int which = q / 3, k = q - 3 * which;
+    const double* ph = (which ? d.phi_p1 : d.phi_p0) + (size_t)k * 4096;
+    const double c = ph[0];
+    bool same = c == 0.0 || c == 1.0;
+    for (int e = t; e < 4096 && same; e += PWG) same = ph[e] == c;
+    const int all = __syncthreads_and(same ? 1 : 0);
+    if (t == 0) d.plane_flags[which * 4 + k] = all ? (c == 0.0 ? 1 : 2) : 0;
   }
   const int g = block * PGB + wave;
   if (g >= d.B) return;
@@ -992,7 +1007,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
     // 512-byte row each.  The slots (and whether the program ever writes them) come through the scalar cache -- a vector
     // load here would be one more round of memory latency in front of the rows --, then all the rows are requested
     // before the first is used.  The half's first A fragment goes out ahead of them.
-    const const_i32p cs = as_const(d.gr.c_slot), rs = as_const(d.gr.r_slot);
+    const const_i32p cs = as_const(d.gr.c_slot), rs = as_const(d.gr.r_slot), pf = as_const(d.gr.plane_flags);
     int slots[8];                                                 // tile q = 2 * factor + side: its message slot, or -1
 #pragma unroll
     for (int q = 0; q < 8; ++q) slots[q] = q < 2 * np ? ((q & 1) ? cs[p0 + (q >> 1)] : rs[p0 + (q >> 1)]) : -1;
@@ -1010,7 +1025,19 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
 #pragma unroll
       for (int s = 0; s < 16; ++s) fr[s] = ABL(256) ? 0.5 : W[64 * s];
     };
-    fetchw(fr0, 0);
+    auto run_end = [&](int j) {                                  // first item behind the run that starts at j
+      int e = j + 1;
+      while (e < n_items && e % np != 0 && key(e) == key(e - 1)) ++e;
+      return e;
+    };
+    // an item whose feature plane is all zeros or all ones needs no contraction (the per-graph terms below use 0 resp. Z)
+    auto needed = [&](int j) { const int k = 2 * (j / np) + half; return k == 3 || pf[(key(j) & 1) * 4 + k] == 0; };
+    auto next_run = [&](int j) {                                  // start of the first needed run at or behind j
+      while (j < n_items && !needed(j)) j = run_end(j);
+      return j;
+    };
+    const int j_first = next_run(0);
+    if (j_first < n_items) fetchw(fr0, j_first);
     double sv[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {                                // row i = wave + 8 j: tile i >> 4 = j >> 1, graph wave + 8 (j & 1)
@@ -1039,11 +1066,6 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
     // factors that read the same (table, feature tensor) share one A fragment: it is fetched once per run (a K3 user
     // graph's three factors are one run: 2 fetches per wave instead of 6), the next run's while this run multiplies; two
     // items of a run go through the matrix pipe interleaved (two independent accumulation chains).
-    auto run_end = [&](int j) {                                  // first item behind the run that starts at j
-      int e = j + 1;
-      while (e < n_items && e % np != 0 && key(e) == key(e - 1)) ++e;
-      return e;
-    };
     auto finish = [&](const double4_t& acc, int pp, int k) {
       const double2* ct = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp + 1) * TILE) + 128 * rb + lane;
       const double2 c0 = ct[0], c1 = ct[64];
@@ -1083,28 +1105,34 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
       finish(acc, pp, k);
       finish(bcc, pp + 1, k);
     };
-    for (int j = ABL(64) ? n_items : 0; j < n_items;) {
-      int e = run_end(j);
-      if (e < n_items) fetchw(fr1, e);
+    for (int j = ABL(64) ? n_items : j_first; j < n_items;) {
+      int e = run_end(j), nx = next_run(e);
+      if (nx < n_items) fetchw(fr1, nx);
 #pragma unroll 1
       for (; j + 1 < e; j += 2) item2(fr0, j);
-      if (j < e) item(fr0, j++);
+      if (j < e) item(fr0, j);
+      j = nx;
       if (j >= n_items) break;
-      e = run_end(j);
-      if (e < n_items) fetchw(fr0, e);
+      e = run_end(j); nx = next_run(e);
+      if (nx < n_items) fetchw(fr0, nx);
 #pragma unroll 1
       for (; j + 1 < e; j += 2) item2(fr1, j);
-      if (j < e) item(fr1, j++);
+      if (j < e) item(fr1, j);
+      j = nx;
     }
     __syncthreads();
     STAMP(9)
     if (t < np * G) {                                            // label features minus expected features, per (factor, graph)
       const double* rp = red + (size_t)(t >> 4) * 16 * G + (t & 15);
       const double Z = (rp[(12 + 0) * G] + rp[(12 + 1) * G]) + (rp[(12 + 2) * G] + rp[(12 + 3) * G]);
+      const int wh = d.gr.pair_phi[p0 + (t >> 4)] ? 1 : 0;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
+        const int flag = d.gr.plane_flags[wh * 4 + k];
         const double S = (rp[(4 * k + 0) * G] + rp[(4 * k + 1) * G]) + (rp[(4 * k + 2) * G] + rp[(4 * k + 3) * G]);
-        pc[t * 3 + k] = l_ok ? lf[k] - (Z > 0.0 ? S / Z : 0.0) : 0.0;         // au.normalize: zero-sum -> 0
+        // expected feature: S / Z; a zero plane 0, the bias plane the normalised belief's total, 1  (au.normalize: zero-sum -> 0)
+        const double ex = Z > 0.0 ? (flag == 0 ? S / Z : (flag == 1 ? 0.0 : 1.0)) : 0.0;
+        pc[t * 3 + k] = l_ok ? lf[k] - ex : 0.0;
       }
     }
     __syncthreads();
@@ -1479,7 +1507,7 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   // the gradient as the sweep kernel's epilogue (the prepare launch also writes its weighted table fragments)
   if (shared_gradient_fused(prog, a)) {
     const mlbp_gradient_args* ga = a->gradient;
-    const size_t need = (size_t)a->n_pair_tables * 8 * 4096;
+    const size_t need = (size_t)a->n_pair_tables * 8 * 4096 + 8;      // + the eight plane flags (as doubles' worth of bytes)
     if (need > mp->wfrag_cap) {                     // first use (a stream-capturing caller warms up first)
       (void)hipFree(mp->d_wfrag);
       mp->d_wfrag = nullptr; mp->wfrag_cap = 0;
@@ -1487,9 +1515,10 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
       mp->wfrag_cap = need;
     }
     q.n_wfrag_tables = a->n_pair_tables; q.wfrag = mp->d_wfrag; q.phi_p0 = ga->phi_en_en_p; q.phi_p1 = ga->phi_en_en_w1_p;
+    q.plane_flags = reinterpret_cast<int32_t*>(mp->d_wfrag + (size_t)a->n_pair_tables * 8 * 4096);
     SharedGradDev& gr = d.gr;
     gr.c_slot = ga->pair_c_slot; gr.r_slot = ga->pair_r_slot; gr.pair_phi = ga->pair_phi; gr.pair_label = ga->pair_label;
-    gr.phi[0] = ga->phi_en_en; gr.phi[1] = ga->phi_en_en_w1; gr.wfrag = mp->d_wfrag;
+    gr.phi[0] = ga->phi_en_en; gr.phi[1] = ga->phi_en_en_w1; gr.wfrag = mp->d_wfrag; gr.plane_flags = q.plane_flags;
     gr.grad_en_en = ga->grad_en_en; gr.enabled = 1;
     q.unary_expect = prog->U > 0 ? ga->unary_expect : nullptr;
     q.unary_kind = ga->unary_kind; q.unary_obs = ga->unary_obs; q.unary_label = ga->unary_label;

@@ -140,6 +140,18 @@ def make_inputs(spec, seed, table_kind='uniform'):
                 pot_en_en=pot_en_en, pot_en_en_w1=pot_en_en_w1, pot_en_de=pot_en_de)
 
 
+def reference_planes(inputs):
+    """The en_en feature tensors as train_mp.py:600-606 stacks them -- phi_en_en = [pmi, 0, 1], phi_en_en_w1 = [pmi, pmi_w1, 1] --
+    on make_inputs' random values, pots redone."""
+    inputs = dict(inputs)
+    ee, w1 = inputs['phi_en_en'].copy(), inputs['phi_en_en_w1'].copy()
+    ee[:, :, 1] = 0.0; ee[:, :, 2] = 1.0; w1[:, :, 0] = ee[:, :, 0]; w1[:, :, 2] = 1.0
+    X = ee.shape[0]
+    inputs.update(phi_en_en=ee, phi_en_en_w1=w1, pot_en_en=np.exp(ee.dot(inputs['theta_en_en'].T).reshape(X, X)),
+                  pot_en_en_w1=np.exp(w1.dot(inputs['theta_en_en'].T).reshape(X, X)))
+    return inputs
+
+
 def domain_of(X):
     return ['w%d' % i for i in range(X)]
 

@@ -136,20 +136,24 @@ def _oracle_step(spec, inputs, labels, obs, roots, lr, reg):
     return tot_ee, tot_ed, lp
 
 
+@pytest.mark.parametrize('planes', ['random', 'reference'])
 @pytest.mark.parametrize('B', [6, 53])
-def test_shared_table_sweep_runs_the_gradient_as_its_epilogue(B):
+def test_shared_table_sweep_runs_the_gradient_as_its_epilogue(B, planes):
     """Shared pots, K3 user graphs: the gradient of sweep(gradient=...) comes out of the shared-table sweep kernel itself (the
     final variable->factor messages of the workgroup's 16 graphs against T (.) phi_k on the matrix cores, the unary part by
     gather in the launch in front of it) -- the separate gradient launch's values to rounding, the oracle's values, and a graph
-    the matrix-core kernel hands to the exact kernel (a zero table column) gets its gradient there."""
+    the matrix-core kernel hands to the exact kernel (a zero table column) gets its gradient there.  planes = 'reference': the
+    zero plane and the bias plane of the reference's tensors, which the epilogue recognises and does not contract."""
     import copy
     from macaronicusermodeling_amd import _ffi
     from macaronicusermodeling_amd.train import UserGraphTrainer
     from macaronicusermodeling_amd.topology import GraphTopology
-    spec = C.user_spec(10, [1, 4, 7], 64, 48, seed=1)
+    spec = C.user_spec(10, [1, 4, 7] if planes == 'random' else [1, 2, 7], 64, 48, seed=1)     # ('reference': both pots in use)
     topo = GraphTopology.from_spec(spec)
     inputs = C.make_inputs(spec, 77)
-    roots = [4, 1, 7]
+    if planes == 'reference':
+        inputs = C.reference_planes(inputs)
+    roots = list(spec['var_ids'])[1:] + list(spec['var_ids'])[:1]
     labels, obs = _instances(spec, topo, B, 5)
     tr = UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],
                           inputs['theta_en_en'], inputs['theta_en_de'], roots=roots)

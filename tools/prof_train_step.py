@@ -12,6 +12,8 @@ spec = C.user_spec(10, [1, 4, 7], X, 64, seed=1)
 from macaronicusermodeling_amd.topology import GraphTopology
 topo = GraphTopology.from_spec(spec)
 inputs = C.make_inputs(spec, 5)
+if '--random-planes' not in sys.argv:        # the reference's tensors: [pmi, 0, 1] and [pmi, pmi_w1, 1] (train_mp.py:600-606)
+    inputs = C.reference_planes(inputs)
 rs = np.random.RandomState(0)
 labels = rs.randint(0, X, size=(B, topo.n_vars)); obs = rs.randint(0, 64, size=(B, topo.U))
 tr = UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],

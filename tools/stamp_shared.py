@@ -48,6 +48,8 @@ if GRAD:
     spec = CS.user_spec(10, [1, 4, 7], X, 64, seed=1)
     topo = GraphTopology.from_spec(spec)
     inputs = CS.make_inputs(spec, 5)
+    if '--random-planes' not in sys.argv:        # the reference's tensors: [pmi, 0, 1] and [pmi, pmi_w1, 1] (train_mp.py:600-606)
+        inputs = CS.reference_planes(inputs)
     rs = np.random.RandomState(0)
     tr = UserGraphTrainer(spec, rs.randint(0, X, size=(B, topo.n_vars)), rs.randint(0, 64, size=(B, topo.U)), inputs['phi_en_en'],
                           inputs['phi_en_en_w1'], inputs['phi_en_de'], inputs['theta_en_en'], inputs['theta_en_de'])

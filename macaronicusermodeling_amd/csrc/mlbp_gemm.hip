@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 && HALVES == 1 && NCT == 1) ? 8 
   static_assert(KB % 4 == 0 && (DEPTH == 2 || DEPTH == 4), "");
 
   // ---- main loop of one pass: acc = table x the LDS image ----
-  auto main_loop = [&](double4_t (&acc)[RTW][NCT]) {
+  auto main_loop = [&](double4_t (&acc)[RTW][NCT], auto&& at_step) {      // at_step(kb): called once per DEPTH steps, in front of them
 #pragma unroll
     for (int r = 0; r < RTW; ++r)
 #pragma unroll
@@ -306,6 +306,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 && HALVES == 1 && NCT == 1) ? 8 
       };
 #pragma unroll 1
       for (int kb = 0; kb < KB_RUN; kb += DEPTH) {
+        at_step(kb);
 #pragma unroll
         for (int s0 = 0; s0 < DEPTH; ++s0) {
           if (kb + s0 + DIST < KB) load_a(a[(s0 + DIST) % DEPTH], kb + s0 + DIST);
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 && HALVES == 1 && NCT == 1) ? 8 
       };
 #pragma unroll 1
       for (int kb = 0; kb < KB_RUN; kb += 4) {
+        at_step(kb);
 #pragma unroll
         for (int r = 0; r < RTW; ++r)
 #pragma unroll
@@ -416,22 +418,29 @@ __global__ __launch_bounds__(64 * NW, (NW == 16 && HALVES == 1 && NCT == 1) ? 8 
   }
   __syncthreads();
   if constexpr (HALVES == 1) {
-    main_loop(acc);
+    main_loop(acc, [](int) {});
     __syncthreads();
     epilogue(b_first, acc);
   } else {
     const int b_second = b_first + NT_G;
     const bool second = b_second < d.B;                          // (uniform over the workgroup)
     double2 m[PF][GU][H];
+#if defined(MLBP_CONTRACT_EXPERIMENT) && MLBP_CONTRACT_EXPERIMENT == 4
+    // the request goes out INSIDE the first pass's loop, at a step that differs from wave to wave: the table fragments behind it
+    // wait for it (loads return in order), but one wave at a time, with the SIMD's other waves on the matrix pipe
+    const int at = (wave * 4 * (KB / 64 > 0 ? KB / 64 : 1)) % KB;
+    main_loop(acc, [&](int kb) { if (second && kb == (at / DEPTH) * DEPTH) request(b_second, 0, 0, m); });
+#else
     if (second) request(b_second, 0, 0, m);                      // in flight under the first pass's main loop
-    main_loop(acc);
+    main_loop(acc, [](int) {});
+#endif
     __syncthreads();
     epilogue(b_first, acc);                                      // its stores drain under the second pass
     if (!second) return;
     __syncthreads();                                             // the image is free again
     finish_prologue(b_second, 0, m);
     __syncthreads();
-    main_loop(acc);
+    main_loop(acc, [](int) {});
     __syncthreads();
     epilogue(b_second, acc);
   }
@@ -461,7 +470,7 @@ int launch_contract_rt(const ContractDev& d, int nct, hipStream_t st) {
   if constexpr (!PADDED && (4 * RT) % 16 == 0) {
     if (nct == 1 && d.B > 16) {
       threads = 1024;
-      if (MLBP_CONTRACT_EXPERIMENT == 1) {          // two passes per workgroup, the second's sources requested under the first's loop
+      if (MLBP_CONTRACT_EXPERIMENT == 1 || MLBP_CONTRACT_EXPERIMENT == 4) {   // two passes per workgroup, the second's sources requested under the first's loop (4: inside it)
         k = contract_kernel<TT, RT, 1, 4, 16, false, 2>; graphs_per_wg = 32;
       } else if (MLBP_CONTRACT_EXPERIMENT == 2) {   // 16 graphs per 16-wave workgroup at 64 registers: 8 waves per SIMD
         k = contract_kernel<TT, RT, 1, 2, 16, false, 1>; graphs_per_wg = 16;

@@ -192,7 +192,10 @@ typedef struct mlbp_sweep_args {
                                  FactorGraph.get_unregularized_gradeint (LBP.py:301-320) are written
                                  after the last sweep -- inside the same launch (tables still in
                                  registers, messages in LDS) when X = 64, F = (3,6), at most 3
-                                 pairwise factors and the transposed feature tensors are given;
+                                 pairwise factors and the transposed feature tensors are given
+                                 (shared pairwise tables: the matrix-core kernel's epilogue for the
+                                 pairwise factors -- it needs the planar tensors and unary_expect --,
+                                 the unary factors' terms in the launch in front of it);
                                  otherwise by mlbp_gradient_f64 enqueued behind the sweeps            */
   int32_t flags;              /* MLBP_SWEEP_* bits, 0 = none                                        */
   const int32_t* pair_tab_host;

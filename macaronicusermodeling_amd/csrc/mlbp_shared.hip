@@ -451,7 +451,7 @@ __device__ __forceinline__ int tile_index(int state, int graph) {
 // The dependent chain (row index -> rows -> product) that cost the sweep kernel a fifth of its single round runs here at
 // full occupancy instead: 8192 independent waves, two batches of rows in flight each.
 constexpr int FRAG_TABLES = 32;                                  // shared-table batches have a handful of tables
-constexpr int PWG = 256, PGB = 4;                                // threads / graphs per block of the prepare kernel
+constexpr int PWG = 1024, PGB = 16;                              // threads / graphs per block of the prepare kernel: one group of 16 graphs
 struct PrepareDev {
   const double* pair_tables; double* tfrag; int32_t n_frag_tables;
   int32_t n_wfrag_tables;                                        // > 0: also the gradient's weighted fragments, T (.) phi_k and T
@@ -469,7 +469,8 @@ struct PrepareDev {
 // MULTI: several groups of graphs (mlbp_sweep_groups_f64: every group its own program, tables, messages) in one launch;
 // gtab[k] = the group's PrepareDev, gstart[k] = its first block (ascending; gstart[n_groups] = the grid size).
 template <bool MULTI>
-__global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d, const PrepareDev* gtab, const int32_t* gstart, int n_groups) {
+__global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, const PrepareDev* gtab, const int32_t* gstart, int n_groups) {
+  extern __shared__ double ptile_lds[];                          // [n_cprod][1024] the group's product tiles, assembled here and stored as whole lines
   ABL_DECL
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int block = blockIdx.x, n_blocks = gridDim.x;
@@ -516,10 +517,13 @@ __global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d, const
     const int all = __syncthreads_and(same ? 1 : 0);
     if (t == 0) d.plane_flags[which * 4 + k] = all ? (c == 0.0 ? 1 : 2) : 0;
   }
+  // one workgroup = one group of 16 graphs, one wave per graph: a wave writes its column of the group's tiles into LDS, and the
+  // workgroup stores each tile as whole cache lines (a wave's column alone is 16 bytes in each of 32 lines per tile: the
+  // partial-line stores of 16 different waves into the same lines were what this launch spent most of its time on)
   const int g = block * PGB + wave;
-  if (g >= d.B) return;
-  double* tiles_out = d.ptiles + (size_t)(g >> 4) * d.n_cprod * TILE;       // this graph is column g & 15 of its group's tiles
-  const int col = g & 15;
+  const bool on = g < d.B;
+  const int col = wave;
+  if (on) {
   constexpr int RB = 8;
   constexpr unsigned KEY_LIMIT = 0x7A11A0FCu;                    // high word of 1e280
   double cur = 1.0;
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d, const
           if (flags & 2) {
             const double sum = wave_sum(cur);
             flagged |= !total_ok(sum) || __any(key > KEY_LIMIT);
-            if (!ABL(16)) tiles_out[(size_t)k_out * TILE + tile_index(lane, col)] = cur * __builtin_amdgcn_rcp(sum);
+            ptile_lds[(size_t)k_out * TILE + tile_index(lane, col)] = cur * __builtin_amdgcn_rcp(sum);
             ++k_out;
           }
         }
@@ -597,6 +601,13 @@ __global__ __launch_bounds__(PWG) void shared_prepare_kernel(PrepareDev d, const
     for (int m = 8; m < 64; m <<= 1) { u_ee += __shfl_xor(u_ee, m); u_ed += __shfl_xor(u_ed, m); }
     if (lane < 3) d.grad_en_en[(size_t)g * 3 + lane] = u_ee;
     if (lane < 6) d.grad_en_de[(size_t)g * 6 + lane] = u_ed;
+  }
+  }   // if (on)
+  __syncthreads();
+  if (!ABL(16)) {
+    const double2* src = reinterpret_cast<const double2*>(ptile_lds);
+    double2* dst = reinterpret_cast<double2*>(d.ptiles + (size_t)block * d.n_cprod * TILE);
+    for (int i = t; i < d.n_cprod * (TILE / 2); i += PWG) dst[i] = src[i];          // (columns of graphs beyond B: whatever LDS held; never read as results)
   }
 }
 
@@ -1526,7 +1537,7 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
     q.grad_en_en = ga->grad_en_en; q.grad_en_de = ga->grad_en_de; q.Vde = ga->Vde; q.grad_on = 1;
     d.msgs = a->msgs;                               // the epilogue reads the stored variable->factor messages back
   }
-  out->lds = lds; out->n_wg = n_groups; out->n_prep_blocks = (a->B + PGB - 1) / PGB;
+  out->lds = lds; out->n_wg = n_groups; out->n_prep_blocks = (a->B + PGB - 1) / PGB;       // (= n_groups)
   out->wide = sp.max_sources > 2; out->spill = d.spill != nullptr;
   *ok = true;
   return MLBP_OK;
@@ -1553,7 +1564,7 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   if (int e = shared_plan(prog, a, &ok, &pl)) return e;
   if (!ok) return MLBP_OK;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(shared_prepare_kernel<false>, dim3(pl.n_prep_blocks), dim3(PWG), 0, st, pl.q, nullptr, nullptr, 0);
+  hipLaunchKernelGGL(shared_prepare_kernel<false>, dim3(pl.n_prep_blocks), dim3(PWG), (size_t)pl.q.n_cprod * TILE * sizeof(double), st, pl.q, nullptr, nullptr, 0);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
   sweep_fn k = nullptr;
   if (int e = pick_sweep_kernel(prog->P >= 2, pl.spill, pl.wide, false, pl.d.gr.enabled != 0, pl.lds, &k)) return e;
@@ -1574,6 +1585,7 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   std::vector<SharedPlan> plans(n_groups);
   size_t lds = 0;
   bool wide = false, spill = false, two = false, grad = false;
+  int max_cprod = 1;
   for (int k = 0; k < n_groups; ++k) {
     if (!progs[k]) return MLBP_OK;
     for (int j = 0; j < k; ++j)
@@ -1583,6 +1595,7 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
     if (!ok) return MLBP_OK;
     lds = std::max(lds, plans[k].lds);
     wide |= plans[k].wide; spill |= plans[k].spill; two |= progs[k]->P >= 2; grad |= plans[k].d.gr.enabled != 0;
+    max_cprod = std::max(max_cprod, (int)plans[k].q.n_cprod);
   }
   if (grad && (spill || wide)) return MLBP_OK;       // no such instance (one group spills tiles or has wide updates, another carries the gradient): group by group
   // table image: [SharedDev x n][PrepareDev x n][sweep starts n + 1][prepare starts n + 1], as 32-bit words
@@ -1614,7 +1627,7 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   const SharedDev* d_sd = reinterpret_cast<const SharedDev*>(owner->d_stable);
   const PrepareDev* d_pd = reinterpret_cast<const PrepareDev*>(owner->d_stable + w_sd * n_groups);
   const int32_t* d_starts = owner->d_stable + (w_sd + w_pd) * n_groups;
-  hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), 0, st, plans[0].q, d_pd, d_starts + n_groups + 1, n_groups);
+  hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), (size_t)max_cprod * TILE * sizeof(double), st, plans[0].q, d_pd, d_starts + n_groups + 1, n_groups);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
   sweep_fn k = nullptr;
   if (int e = pick_sweep_kernel(two, spill, wide, true, grad, lds, &k)) return e;

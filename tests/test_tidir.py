@@ -167,3 +167,44 @@ def test_reader_and_shape_compiler_equal_the_reference_graph_builder():
                 assert en[obs[fid]] == word_label
             n_checked += 1
     assert n_checked > 60
+
+
+def test_prediction_writer_reproduces_the_reference_text_from_its_own_distributions():
+    """tidir.prediction_text -- what TiDirTrainer.predict(save_predictions=...) writes per instance -- fed with the distributions
+    the REFERENCE printed: tests/golden/tidir_batch_reference.json holds, per instance, the '*SENT_ID:' block and the .dist lines
+    its batch_predictions returned (train_mp.py:310-343, LBP.py:109-143).  The .dist lines carry every variable's log-marginals
+    (6 decimals); parsed and handed back, the writer must give the same .dist text character for character, and the same block:
+    same words in the same places and order (given words, guesses, the 50 most probable words by descending probability),
+    numbers to the 4 decimals printed (one unit of slack: they are re-rounded from 6-decimal values)."""
+    import json
+    from macaronicusermodeling_amd import tidir
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tidir_batch_reference.json'), encoding='utf8'))
+    en, de = gold['vocab_en'], gold['vocab_de']
+    instances = [tidir.parse_instance(l) for l in gold['instances']]
+    buckets = tidir.bucket_instances(instances, en, de)
+    seen = 0
+    for key, b in buckets.items():
+        predicted = list(key[1])
+        for row in b['rows']:
+            ref = gold['predictions'][row['index']]
+            logm = np.array([[float(x) for x in line.split(' ||| ')[2].split()] for line in ref['dist'].split('\n')])
+            assert logm.shape == (len(predicted), len(en))
+            top = np.argsort(-logm, axis=1, kind='stable')[:, :50]
+            top_logs = np.take_along_axis(logm, top, axis=1)
+            label_logs = [logm[v, row['label'][pos]] for v, pos in enumerate(predicted)]
+            block, dist = tidir.prediction_text(row, predicted, en, top, top_logs, label_logs, logm)
+            assert dist == ref['dist']
+            got, want = block.split('\n'), ref['block'].split('\n')
+            assert got[0] == want[0] and len(got) == len(want)
+            for gl, wl in zip(got[1:], want[1:]):
+                gt, wt = gl.split(' '), wl.split(' ')
+                assert len(gt) == len(wt)
+                for a_, b_ in zip(gt, wt):
+                    try:
+                        fa, fb = float(a_), float(b_)
+                    except ValueError:
+                        assert a_ == b_                      # a word: the same one in the same place
+                    else:
+                        assert abs(fa - fb) <= 1.0001e-4
+            seen += 1
+    assert seen == len(gold['predictions'])

@@ -68,8 +68,10 @@ def workload_spec(name):
         return C.chain_spec(8, 64), [0] * 10, 10, 1235
     if name == 'ring8':
         return C.ring_spec(8, 64), [0] * 10, 10, 1235
-    if name == 'ring8_x1000':      # a vocabulary-sized state space that is not a power of two
+    if name in ('ring8_x1000', 'ring8_x1000_shared'):      # a vocabulary-sized state space that is not a power of two
         return C.ring_spec(8, 1000), [0] * 10, 10, 1239
+    if name == 'ring8_x2048_shared':    # past the one-image contraction kernel: 2 x 2 blocks of 1024 states
+        return C.ring_spec(8, 2048), [0] * 10, 10, 1240
     if name in ('ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared', 'ring8_x512_shared_f32'):
         return C.ring_spec(8, 512), [0] * 10, 10, 1238
     raise SystemExit('unknown workload %s' % name)
@@ -247,7 +249,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'user_k3_trainlayout', 'user_k4', 'user_k4_shared', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared', 'ring8_x512_shared_f32', 'ring8_x1000'],
+    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'user_k3_trainlayout', 'user_k4', 'user_k4_shared', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared', 'ring8_x512_shared_f32', 'ring8_x1000', 'ring8_x1000_shared', 'ring8_x2048_shared'],
                     help='user_k3_shared = the same graphs with the reference\'s table layout: all graphs share the two '
                          'en_en pots (MFMA kernel, reported against the f64 matrix peak)')
     ap.add_argument('--no-writeback', action='store_true', help='shared workload: skip the message write-back (read-out only)')

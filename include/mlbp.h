@@ -28,13 +28,18 @@
  *   - a mlbp_program belongs to the device that was current when it was created (mlbp_sweep_f64 checks this) and owns
  *     per-program device state (status word, per-graph redo flags): calls that use the SAME program must be enqueued
  *     on one stream, or be ordered by the caller;
- *   - calls with DIFFERENT programs may run on different streams concurrently, with two exceptions that share
- *     process-wide scratch and must not overlap across streams: the shared-table path at X >= 128 (sweeps and gradient;
- *     its fragment and product buffers) and mlbp_log_posterior_sum_f64 (its block partials); a mlbp_sweep_groups_f64 call
- *     counts as a use of EVERY program it names (its group table lives with the first one);
- *   - scratch buffers (redo flags, fragment copies, spill areas, group tables) are allocated -- and a group table
- *     uploaded -- at the first call that needs them or changes them: that call is not enqueue-only;
- *     mlbp_program_reserve and one eager step with the same arguments before stream capture move all of it up front;
+ *   - calls with DIFFERENT programs may run on different streams concurrently (every scratch buffer of the sweep paths --
+ *     redo flags, fragment copies, spill areas, formed messages, group tables -- belongs to a program), with these exceptions
+ *     that share process-wide scratch and must not overlap across streams: mlbp_log_posterior_sum_f64 /
+ *     mlbp_step_statistics_f64 (their block partials) and a STANDALONE mlbp_gradient_f64 on shared tables that was given no
+ *     mlbp_gradient_args.workspace; a mlbp_sweep_groups_f64 call counts as a use of EVERY program it names (its group table
+ *     lives with the first one);
+ *   - scratch is allocated -- and a group table uploaded -- at the first call that needs it or needs more of it: that call is
+ *     not enqueue-only; mlbp_program_reserve and one eager step with the same arguments before stream capture move all of it
+ *     up front.  Scratch only ever GROWS by a new block; a block that was outgrown stays alive until mlbp_program_destroy (the
+ *     process-wide fallback blocks: until exit), so a HIP graph captured earlier keeps replaying against valid memory whatever
+ *     later calls ask for.  A program keeps one device copy per DISTINCT group table (up to 64; beyond that the oldest copy is
+ *     overwritten and a graph captured on it must be captured again);
  *   - mlbp_set_sweep_variant and the status words behind mlbp_gradient_status are process-wide.
  */
 #ifndef MLBP_H
@@ -200,7 +205,8 @@ typedef struct mlbp_sweep_args {
   int32_t flags;              /* MLBP_SWEEP_* bits, 0 = none                                        */
   const int32_t* pair_tab_host;
                               /* HOST int32 [P] or NULL: with MLBP_SWEEP_SHARED_PAIR_TABLES, the pair_tab row
-                                 every graph has.  Needed for X >= 128, where the sweeps then run op by op
+                                 every graph has.  Needed for X > 64 (any X up to 4096: the reference's X is its vocabulary,
+                                 train_mp.py:591-594), where the sweeps then run op by op
                                  over the whole batch with one hand-written MFMA contraction launch per factor->variable update;
                                  the statement is checked on the device, a false one raises
                                  mlbp_program_status to 2                                            */
@@ -371,7 +377,15 @@ typedef struct mlbp_gradient_args {
   const int32_t* pair_slots_host; /* HOST int32 [3][P] or NULL: the contents of pair_c_slot | pair_r_slot | pair_phi.  The X >= 128
                                    path walks the factors on the host; given this copy it only enqueues (and can be captured
                                    into a HIP graph), without it the call reads the three device arrays back and synchronises */
+  void* workspace;              /* optional DEVICE scratch of workspace_bytes bytes, owned by the caller: the shared-table paths keep
+                                   their weighted table fragments and per-graph sums there (mlbp_gradient_workspace_bytes says how
+                                   much).  NULL: a process-wide block, grown on demand and never freed -- calls that fall back on it
+                                   must not overlap across streams.  Inside mlbp_sweep_f64 (mlbp_sweep_args.gradient) a NULL
+                                   workspace is replaced by scratch the PROGRAM owns                                        */
+  int64_t workspace_bytes;
 } mlbp_gradient_args;
+/* Bytes of workspace mlbp_gradient_f64(a) would use (0: that call needs none).  Host only. */
+int64_t mlbp_gradient_workspace_bytes(const mlbp_gradient_args* a);
 /* flags: pair_tab[b][p] is the same for every graph b (see MLBP_SWEEP_SHARED_PAIR_TABLES).  With X = 64,
  * F_ee = 3 and the planar feature copies given, the pairwise factors of 16 graphs at a time are then
  * contracted on the matrix cores ((T (.) phi_k) . r, four contractions per factor).  Groups of 16 graphs for

@@ -38,7 +38,7 @@ class GradientArgs(C.Structure):
                 ('phi_en_de', C.c_void_p), ('phi_en_en_t', C.c_void_p), ('phi_en_en_w1_t', C.c_void_p),
                 ('phi_en_de_t', C.c_void_p), ('phi_en_en_p', C.c_void_p), ('phi_en_en_w1_p', C.c_void_p),
                 ('grad_en_en', C.c_void_p), ('grad_en_de', C.c_void_p), ('flags', C.c_int32), ('pair_tab_host', C.c_void_p), ('unary_expect', C.c_void_p),
-                ('pair_slots_host', C.c_void_p)]
+                ('pair_slots_host', C.c_void_p), ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64)]
 
 
 class PotentialsJob(C.Structure):
@@ -101,6 +101,7 @@ SIGNATURES = {
     'mlbp_pair_beliefs_f64': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     'mlbp_gradient_f64': (C.c_int, [C.POINTER(GradientArgs), _vp]),
     'mlbp_gradient_status': (C.c_int, []),
+    'mlbp_gradient_workspace_bytes': (C.c_int64, [C.POINTER(GradientArgs)]),
     'mlbp_unary_expectations_f64': (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     'mlbp_patch_unary_tables_f64': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     'mlbp_patch_gradient_f64': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),

@@ -608,7 +608,24 @@ int need_device() {
 
 }  // namespace
 
+// which shared-table form a gradient call takes (a function of the arguments alone)
+static bool takes_shared_x64(const mlbp_gradient_args* a) {
+  return a->X == 64 && !(a->flags & MLBP_GRADIENT_APPROX_BELIEFS) && (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->F_ee == 3 && a->P > 0 &&
+         a->n_pair_tables <= 32 && a->phi_en_en_p && a->phi_en_en_w1_p;
+}
+static bool takes_gemm_pairs(const mlbp_gradient_args* a) {
+  return a->X != 64 && !(a->flags & MLBP_GRADIENT_APPROX_BELIEFS) && (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->pair_tab_host &&
+         mlbp::gemm_path_supports(a->X) && a->F_ee == 3 && a->P > 0 && a->P <= 16 && a->phi_en_en_p && a->phi_en_en_w1_p;
+}
+
 extern "C" {
+
+int64_t mlbp_gradient_workspace_bytes(const mlbp_gradient_args* a) {
+  if (!a) return 0;
+  if (takes_shared_x64(a)) return (int64_t)mlbp::shared_gradient_workspace_bytes(a);
+  if (takes_gemm_pairs(a)) return (int64_t)mlbp::gemm_gradient_workspace_bytes(a);
+  return 0;
+}
 
 int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream) {
   if (!a) return fail(MLBP_EINVAL, "mlbp_gradient_f64: NULL args");
@@ -633,7 +650,7 @@ int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream) {
     return fail(MLBP_EINVAL, "mlbp_gradient_f64: approximate beliefs keep the %d largest entries; kth(=%d) out of bounds (64)", MLBP_APPROX_K, MLBP_APPROX_K - 1);
   if (a->X == 64) {
     // shared pairwise tables: the pairwise factors of 16 graphs at a time on the matrix cores, after the unary part
-    const bool shared = (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->F_ee == 3 && a->P > 0 && a->n_pair_tables <= 32 && a->phi_en_en_p && a->phi_en_en_w1_p;
+    const bool shared = takes_shared_x64(a);
     d.skip_pairs = shared ? 1 : 0;
     if (shared && a->unary_expect && a->F_ed == 6)               // unary part by gather inside the pair kernel
       return mlbp::launch_shared_pair_gradient(a, d.status, stream);
@@ -650,8 +667,7 @@ int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream) {
                 MLBP_APPROX_K, MLBP_APPROX_K - 1, a->X);
   const size_t dyn = approx ? 2 * (size_t)a->X * sizeof(double) : 0;
   // shared pairwise tables at a large state space: pairwise part as MFMA contractions over the whole batch (mlbp_gemm.hip)
-  const bool gemm_pairs = !approx && (a->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && a->pair_tab_host && mlbp::gemm_path_supports(a->X) && a->F_ee == 3 &&
-                          a->P > 0 && a->P <= 16 && a->phi_en_en_p && a->phi_en_en_w1_p && mlbp::gemm_path_ready() == MLBP_OK;
+  const bool gemm_pairs = takes_gemm_pairs(a);
   d.skip_pairs = gemm_pairs ? 1 : 0;
   if (a->F_ee == 3) hipLaunchKernelGGL((gradient_kernel<3, 6>), dim3(a->B), dim3(WG), dyn, st, d);
   else if (a->F_ee == 2) hipLaunchKernelGGL((gradient_kernel<2, 2>), dim3(a->B), dim3(WG), dyn, st, d);

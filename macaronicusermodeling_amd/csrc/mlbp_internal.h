@@ -80,6 +80,32 @@ int gemm_path_ready();      // always MLBP_OK (kept for the callers' sake)
 bool gemm_path_supports(int X);
 // Pairwise part of the gradient for shared tables at X >= 128 (F_ee = 3), ADDED to a->grad_en_en.
 int launch_gemm_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void* stream);
+// Bytes of mlbp_gradient_args.workspace that call needs (0: none): the weighted table fragments and the per-graph sums.
+size_t gemm_gradient_workspace_bytes(const mlbp_gradient_args* a);
+size_t shared_gradient_workspace_bytes(const mlbp_gradient_args* a);
+
+// Program-owned device scratch grows by allocating a NEW block; the old one stays alive until mlbp_program_destroy -- a HIP
+// graph captured earlier may still name it (a free on growth was a use-after-free on replay).  *cap in bytes.
+int program_grow(mlbp_program* prog, void** p, size_t* cap, size_t bytes, bool zero = false);
+// A process-wide arena for the calls that carry no program and were given no workspace (mlbp_gradient_f64 with shared tables):
+// one block per (device, purpose), grown the same way and never freed.  Calls that use it on different streams must not overlap.
+int fallback_scratch(int purpose, size_t bytes, void** out);
+enum { SCRATCH_GEMM_GRADIENT = 0, SCRATCH_SHARED_GRADIENT = 1, SCRATCH_PURPOSES = 2 };
+}  // namespace mlbp
+
+namespace mlbp {
+// Device copies of the group tables of mlbp_sweep_groups_f64, ONE PER DISTINCT CONTENTS: a call whose table equals an earlier
+// one reuses that copy without an upload, a call with other buffers or groups gets its own -- so a HIP graph captured on one
+// table keeps replaying against it.  At most MAX tables per program; beyond that the oldest copy is overwritten
+// (a graph captured on it must be re-captured: include/mlbp.h says so).
+struct GroupTables {
+  enum { MAX = 64 };
+  struct Entry { std::vector<int32_t> words; int32_t* dev = nullptr; size_t cap_words = 0; };
+  std::vector<Entry> entries;
+  size_t next_evict = 0;
+};
+int group_table_device(GroupTables& gt, const std::vector<int32_t>& table, void* stream, int32_t** out);
+void group_tables_free(GroupTables& gt);
 }  // namespace mlbp
 
 // Device-resident, validated op list (see mlbp_program_create).
@@ -112,12 +138,8 @@ struct mlbp_program {
   bool last_was_pruned = false;     // the last sweep call ran the twin (mlbp_program_exact_count reads its flags)
   int32_t* d_limage = nullptr;   // LeanProgram::image
   int32_t* d_lreadout = nullptr; // build_lean_readout
-  int32_t* d_gtable = nullptr;   // group table of mlbp_sweep_groups_f64 calls that name this program first (launch_lean_groups)
-  size_t gtable_cap = 0;         // in words
-  std::vector<int32_t> h_gtable; // what d_gtable holds (a call uploads only when its table differs)
-  int32_t* d_stable = nullptr;   // the same for the shared-table kernels (launch_shared_groups)
-  size_t stable_cap = 0;
-  std::vector<int32_t> h_stable;
+  mlbp::GroupTables gtables;     // group tables of mlbp_sweep_groups_f64 calls that name this program first (launch_lean_groups)
+  mlbp::GroupTables stables;     // the same for the shared-table kernels (launch_shared_groups)
   // shared-table form (mlbp_shared.hip)
   mlbp::SharedProgram shared;
   int32_t* d_simage;      // SharedProgram::image
@@ -126,11 +148,17 @@ struct mlbp_program {
   double* d_tfrag;        // [32][2][4096] table fragments in MFMA operand order (lazily allocated)
   double* d_spill = nullptr;   // message tiles of the shared-table kernel that do not fit LDS (lazily allocated)
   double* d_wfrag = nullptr;   // the gradient epilogue's weighted table fragments [n_pair_tables][2][4][4096] (lazily allocated)
-  size_t wfrag_cap = 0;
+  size_t wfrag_cap = 0;          // in BYTES (program_grow); spill_cap / ptiles_cap / stable_cap / gtable_cap likewise
   double* d_ptiles = nullptr;  // constant-product tiles of the shared-table kernel [groups][n_cprod][1024] (lazily allocated)
   size_t ptiles_cap = 0;       // in doubles
   size_t spill_cap = 0;        // in doubles
   std::vector<int32_t> h_ops, h_sweeps;   // host copies of the validated op list (the op-by-op GEMM path walks them)
+  // large-state shared-table path (mlbp_gemm.hip): fragment-ordered table copies [P][2][XA^2], the formed input messages of
+  // the chunked contraction [B][X], and the gradient's workspace when the caller gave none
+  void* d_gfrag = nullptr; size_t gfrag_cap = 0;
+  void* d_gxbuf = nullptr; size_t gxbuf_cap = 0;
+  void* d_gwork = nullptr; size_t gwork_cap = 0;
+  std::vector<void*> retired;    // blocks program_grow replaced: freed with the program
 };
 
 #endif

@@ -222,14 +222,24 @@ __device__ __forceinline__ void gradient_epilogue(const SweepDev& d, const GradF
                                                   int R_, int c_, int b3_) {
   constexpr int FEE = 3, FED = 6;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  double pacc[NT][FEE + 1];
+  // Pairwise factors.  sum_p E_p[k] = sum_ij (sum_p b_p[i][j]) phi[i][j][k] over the factors p that read one feature tensor, b_p =
+  // the factor's normalised beliefs: so the beliefs of those factors are ADDED cell by cell first and the tensor -- 98 KB per
+  // graph out of L2, interleaved [64][64][3] -- goes past once per graph instead of once per factor (2.4 GB per 8192-graph
+  // launch of K3 graphs: what the epilogue was bound by).  Three steps, all on the thread's 4 x 4 blocks:
+  //   1. W_p = (c r^T) (.) T_p in place of the table registers, and its total Z_p (wave sums, the four waves meet in LDS);
+  //   2. V_t = sum over the factors reading tensor t (gap == 1: phi_en_en_w1, else phi_en_en; LBP.py:469-480) of W_p / Z_p
+  //      (au.normalize: a total <= 0 gives zero beliefs);
+  //   3. G_t[k] = sum_ij V_t[i][j] phi_t[i][j][k]: three accumulators per tensor, the thread's sixteen cells of the tensor
+  //      loaded eight at a time.
+  int which = 0;                                                 // bit p: factor p reads phi_en_en_w1
+  double2 W[NT][4][2];
+  double* zs = scratch + 512;                                    // [4 waves][NT] (the per-wave results below use scratch[0 .. 4 PER))
 #pragma unroll
   for (int p = 0; p < NT; ++p) {
-#pragma unroll
-    for (int q = 0; q <= FEE; ++q) pacc[p][q] = 0.0;
+    double z = 0.0;
     if (p < d.P) {
       const int cs = as_const(gf.pair_c_slot)[p], rs = as_const(gf.pair_r_slot)[p];
-      const double* phi = as_const(gf.pair_phi)[p] ? gf.phi_en_en_w1 : gf.phi_en_en;        // interleaved [64][64][3]
+      which |= (as_const(gf.pair_phi)[p] ? 1 : 0) << p;
       const double2 ca = lds2(wb + cs * 512 + G.mt), cb = lds2(wb + cs * 512 + G.mt + 16);
       const double2 r0 = lds2(wb + rs * 512 + G.tm0), r1 = lds2(wb + rs * 512 + G.tm1);
 #pragma unroll
@@ -238,20 +248,69 @@ __device__ __forceinline__ void gradient_epilogue(const SweepDev& d, const GradF
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           const double2 rj = k ? r1 : r0, T = tab[p][r][k];
-          const double w0 = (ci * rj.x) * T.x, w1 = (ci * rj.y) * T.y;
-          const int col = 32 * (k ? 1 - b3_ : b3_) + 2 * c_;
-          const double2* ph = reinterpret_cast<const double2*>(phi + ((size_t)(4 * R_ + r) * 64 + col) * FEE);   // 48 bytes, 16-aligned
-          const double2 f01 = ph[0], f2g0 = ph[1], g12 = ph[2];          // cell (i, col): f0 f1 f2 | cell (i, col + 1): g0 g1 g2
-          pacc[p][0] += w0 + w1;
-          pacc[p][1] += w0 * f01.x + w1 * f2g0.y;
-          pacc[p][2] += w0 * f01.y + w1 * g12.x;
-          pacc[p][3] += w0 * f2g0.x + w1 * g12.y;
+          W[p][r][k] = make_double2((ci * rj.x) * T.x, (ci * rj.y) * T.y);
+          z += W[p][r][k].x + W[p][r][k].y;
         }
       }
+      z = wave_sum(z);
+      if (lane == 0) zs[wave * NT + p] = z;
+    } else {
 #pragma unroll
-      for (int q = 0; q <= FEE; ++q) pacc[p][q] = wave_sum(pacc[p][q]);
+      for (int r = 0; r < 4; ++r) W[p][r][0] = W[p][r][1] = make_double2(0.0, 0.0);
     }
   }
+  lds_barrier();
+  double2 V[2][4][2];
+#pragma unroll
+  for (int tz = 0; tz < 2; ++tz)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) V[tz][r][0] = V[tz][r][1] = make_double2(0.0, 0.0);
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+    if (p < d.P) {
+      const double Z = (zs[p] + zs[NT + p]) + (zs[2 * NT + p] + zs[3 * NT + p]);
+      const double inv = Z > 0.0 ? 1.0 / Z : 0.0;                // au.normalize: zero sum -> zero beliefs
+      const double i0 = ((which >> p) & 1) ? 0.0 : inv, i1 = ((which >> p) & 1) ? inv : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          V[0][r][k].x += W[p][r][k].x * i0; V[0][r][k].y += W[p][r][k].y * i0;
+          V[1][r][k].x += W[p][r][k].x * i1; V[1][r][k].y += W[p][r][k].y * i1;
+        }
+    }
+  }
+  double gacc[2][FEE] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  const int all = (1 << (d.P < NT ? d.P : NT)) - 1;
+#pragma unroll
+  for (int tz = 0; tz < 2; ++tz) {
+    if (tz ? (which & all) == 0 : (which & all) == all) continue;          // no factor reads this tensor (wave-uniform)
+    // (global address space spelled out: behind a run-time choice the loads otherwise come out as FLAT ones, which wait on
+    // the LDS counter as well)
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    typedef const v2d __attribute__((address_space(1))) * gptr2;
+    const double* phi = tz ? gf.phi_en_en_w1 : gf.phi_en_en;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int col = 32 * (k ? 1 - b3_ : b3_) + 2 * c_;
+      v2d cell[4][3];                                            // cell (i, col): f0 f1 f2 | cell (i, col + 1): g0 g1 g2
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const gptr2 ph = (gptr2)(uintptr_t)(phi + ((size_t)(4 * R_ + r) * 64 + col) * FEE);   // 48 bytes, 16-aligned
+        cell[r][0] = ph[0]; cell[r][1] = ph[1]; cell[r][2] = ph[2];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double w0 = V[tz][r][k].x, w1 = V[tz][r][k].y;
+        gacc[tz][0] += w0 * cell[r][0].x + w1 * cell[r][1].y;
+        gacc[tz][1] += w0 * cell[r][0].y + w1 * cell[r][2].x;
+        gacc[tz][2] += w0 * cell[r][1].x + w1 * cell[r][2].y;
+      }
+    }
+  }
+  double gsum[FEE];                                              // expected features of all pairwise factors (this wave's share)
+#pragma unroll
+  for (int q = 0; q < FEE; ++q) gsum[q] = wave_sum(gacc[0][q] + gacc[1][q]);
   // unary factors: wave w takes factors w, w + 4, ...; three at a time so that their feature slabs are in flight together
   double lab_ee[FEE] = {0.0, 0.0, 0.0}, lab_ed[FED] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // phi at the label (wave-uniform)
   double exp_ee[FEE] = {0.0, 0.0, 0.0}, exp_ed[FED] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // per-lane partial expected features
@@ -279,7 +338,8 @@ __device__ __forceinline__ void gradient_epilogue(const SweepDev& d, const GradF
           const double2 a0 = ph[0], a1 = ph[1], a2 = ph[2];
           pv[j][0] = a0.x; pv[j][1] = a0.y; pv[j][2] = a1.x; pv[j][3] = a1.y; pv[j][4] = a2.x; pv[j][5] = a2.y;
         } else {
-          const double* ph = (kind ? gf.phi_en_en_w1_t : gf.phi_en_en_t) + ((size_t)obs * 64 + lane) * FEE;
+          typedef const double __attribute__((address_space(1))) * gptr1;      // (global, not FLAT, behind the run-time choice of tensor)
+          const gptr1 ph = (gptr1)(uintptr_t)((kind ? gf.phi_en_en_w1_t : gf.phi_en_en_t) + ((size_t)obs * 64 + lane) * FEE);
           at[j] = (obs * 64 + lab) * FEE;
 #pragma unroll
           for (int q = 0; q < FEE; ++q) pv[j][q] = ph[q];
@@ -299,8 +359,8 @@ __device__ __forceinline__ void gradient_epilogue(const SweepDev& d, const GradF
     }
   }
   if (bad && lane == 0) atomicExch(d.status, 1);
-  // combine the four waves: per wave NT * (FEE + 1) pair sums, then FEE + FED unary sums
-  constexpr int PER = NT * (FEE + 1) + FEE + FED;
+  // combine the four waves: per wave the FEE pairwise sums, then FEE + FED unary sums
+  constexpr int PER = FEE + FEE + FED;
   {
     double ue[FEE], ud[FED];
 #pragma unroll
@@ -310,13 +370,11 @@ __device__ __forceinline__ void gradient_epilogue(const SweepDev& d, const GradF
     if (lane == 0) {
       double* o = scratch + wave * PER;
 #pragma unroll
-      for (int p = 0; p < NT; ++p)
+      for (int q = 0; q < FEE; ++q) o[q] = gsum[q];
 #pragma unroll
-        for (int q = 0; q <= FEE; ++q) o[p * (FEE + 1) + q] = pacc[p][q];
+      for (int q = 0; q < FEE; ++q) o[FEE + q] = ue[q];
 #pragma unroll
-      for (int q = 0; q < FEE; ++q) o[NT * (FEE + 1) + q] = ue[q];
-#pragma unroll
-      for (int q = 0; q < FED; ++q) o[NT * (FEE + 1) + FEE + q] = ud[q];
+      for (int q = 0; q < FED; ++q) o[FEE + FEE + q] = ud[q];
     }
   }
   lds_barrier();
@@ -326,7 +384,7 @@ __device__ __forceinline__ void gradient_epilogue(const SweepDev& d, const GradF
     for (int q = 0; q < PER; ++q) tot[q] = (scratch[q] + scratch[PER + q]) + (scratch[2 * PER + q] + scratch[3 * PER + q]);
     double gee[FEE];
 #pragma unroll
-    for (int q = 0; q < FEE; ++q) gee[q] = tot[NT * (FEE + 1) + q];
+    for (int q = 0; q < FEE; ++q) gee[q] = tot[FEE + q] - tot[q];
     bool lbad = false;
 #pragma unroll
     for (int p = 0; p < NT; ++p) {
@@ -334,17 +392,15 @@ __device__ __forceinline__ void gradient_epilogue(const SweepDev& d, const GradF
         const int l0 = gf.pair_label[((size_t)g * d.P + p) * 2], l1 = gf.pair_label[((size_t)g * d.P + p) * 2 + 1];
         if ((unsigned)l0 >= 64u || (unsigned)l1 >= 64u) { lbad = true; continue; }
         const double* phi = gf.pair_phi[p] ? gf.phi_en_en_w1 : gf.phi_en_en;
-        const double Z = tot[p * (FEE + 1)];
 #pragma unroll
-        for (int q = 0; q < FEE; ++q)
-          gee[q] += phi[((size_t)l0 * 64 + l1) * FEE + q] - (Z > 0.0 ? tot[p * (FEE + 1) + 1 + q] / Z : 0.0);     // au.normalize: zero sum -> 0
+        for (int q = 0; q < FEE; ++q) gee[q] += phi[((size_t)l0 * 64 + l1) * FEE + q];
       }
     }
     if (lbad) atomicExch(d.status, 1);
 #pragma unroll
     for (int q = 0; q < FEE; ++q) gf.grad_en_en[(size_t)g * FEE + q] = gee[q];
 #pragma unroll
-    for (int q = 0; q < FED; ++q) gf.grad_en_de[(size_t)g * FED + q] = tot[NT * (FEE + 1) + FEE + q];
+    for (int q = 0; q < FED; ++q) gf.grad_en_de[(size_t)g * FED + q] = tot[FEE + FEE + q];
   }
 }
 
@@ -372,6 +428,8 @@ __device__ __forceinline__ double rescale(double r, int& bad) {
 // GRAD: FactorGraph.get_unregularized_gradeint (LBP.py:301-320) of the graph as an epilogue (gradient_epilogue): the tables
 // are still in registers and the messages in LDS, so the per-graph gradient costs no second pass over the tables in HBM.
 template <int NT, bool PADX, bool MULTI, int NL, bool GRAD>
+// (GRAD instances: two workgroups per CU -- the epilogue keeps twelve accumulators and a thread's cells of a feature tensor beside
+// the tables, which does not fit the 168 registers of three; the sweeps lose nothing at two per CU, profiles/r03h_lean_kernel_occupancy.txt)
 __global__ __launch_bounds__(WG, (NT >= 7 ? 1 : (NT >= 4 ? 2 : 3))) void sweep_x64_lean_kernel(SweepDev d, LeanDev f, const int32_t* groups,
                                                                                              int n_groups, GradFusedDev gf) {
   int g = blockIdx.x;
@@ -1053,22 +1111,13 @@ int launch_lean_groups(const mlbp_program* const* progs, const mlbp_sweep_args* 
     w[30] = d.n_vars; w[31] = d.n_pair_tables; w[32] = d.n_unary_tables; w[33] = f.dense;
     total += args[k].B;
   }
+  // one device copy per distinct table (stream-ordered upload on first sight, none afterwards): a captured graph keeps its own
   mlbp_program* owner = const_cast<mlbp_program*>(progs[0]);
-  if (table.size() > owner->gtable_cap) {
-    (void)hipFree(owner->d_gtable);
-    owner->d_gtable = nullptr; owner->gtable_cap = 0; owner->h_gtable.clear();
-    HIP_TRY(hipMalloc(&owner->d_gtable, table.size() * sizeof(int32_t)));
-    owner->gtable_cap = table.size();
-  }
-  if (owner->h_gtable != table) {
-    // stream-ordered behind any launch still reading the old table; the source is the program's own host copy, which
-    // lives until the next change
-    owner->h_gtable = table;
-    HIP_TRY(hipMemcpyAsync(owner->d_gtable, owner->h_gtable.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
-  }
+  int32_t* d_gtable = nullptr;
+  if (int e = group_table_device(owner->gtables, table, stream, &d_gtable)) return e;
   lean_fn k = pick_lean<true>(p_max, false);
   if (int e = ensure_lds((const void*)k, lds_max)) return e;
-  hipLaunchKernelGGL(k, dim3(total), dim3(WG), lds_max, (hipStream_t)stream, d0, f0, owner->d_gtable, n_groups, GradFusedDev{});
+  hipLaunchKernelGGL(k, dim3(total), dim3(WG), lds_max, (hipStream_t)stream, d0, f0, d_gtable, n_groups, GradFusedDev{});
   HIP_TRY(hipGetLastError());
   *launched = true;
   return MLBP_OK;

@@ -1472,19 +1472,12 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   mlbp_program* mp = const_cast<mlbp_program*>(prog);
   const int n_groups = (a->B + G - 1) / G;
   const size_t spill_doubles = (size_t)n_groups * (sp.n_live - n_res) * TILE;
-  if (spill_doubles > mp->spill_cap) {             // first use at this size (a stream-capturing caller warms up first)
-    (void)hipFree(mp->d_spill);
-    mp->d_spill = nullptr; mp->spill_cap = 0;
-    if (hipMalloc(&mp->d_spill, spill_doubles * sizeof(double)) != hipSuccess) return fail(MLBP_EHIP, "tile spill allocation failed");
-    mp->spill_cap = spill_doubles;
-  }
+  // (first use at this size allocates -- a stream-capturing caller warms up or reserves first; a block that is outgrown stays
+  // alive with the program: program_grow)
+  if (spill_doubles > 0)
+    if (int e = program_grow(mp, reinterpret_cast<void**>(&mp->d_spill), &mp->spill_cap, spill_doubles * sizeof(double))) return e;
   const size_t ptile_doubles = (size_t)n_groups * n_cprod * TILE;
-  if (ptile_doubles > mp->ptiles_cap) {
-    (void)hipFree(mp->d_ptiles);
-    mp->d_ptiles = nullptr; mp->ptiles_cap = 0;
-    if (hipMalloc(&mp->d_ptiles, ptile_doubles * sizeof(double)) != hipSuccess) return fail(MLBP_EHIP, "product tile allocation failed");
-    mp->ptiles_cap = ptile_doubles;
-  }
+  if (int e = program_grow(mp, reinterpret_cast<void**>(&mp->d_ptiles), &mp->ptiles_cap, ptile_doubles * sizeof(double))) return e;
   if (mp->bail_cap < a->B)
     if (int e = mlbp_program_reserve(mp, a->B)) return e;
   SharedDev& d = out->d;
@@ -1519,12 +1512,7 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   if (shared_gradient_fused(prog, a)) {
     const mlbp_gradient_args* ga = a->gradient;
     const size_t need = (size_t)a->n_pair_tables * 8 * 4096 + 8;      // + the eight plane flags (as doubles' worth of bytes)
-    if (need > mp->wfrag_cap) {                     // first use (a stream-capturing caller warms up first)
-      (void)hipFree(mp->d_wfrag);
-      mp->d_wfrag = nullptr; mp->wfrag_cap = 0;
-      if (hipMalloc(&mp->d_wfrag, need * sizeof(double)) != hipSuccess) return fail(MLBP_EHIP, "weighted fragment allocation failed");
-      mp->wfrag_cap = need;
-    }
+    if (int e = program_grow(mp, reinterpret_cast<void**>(&mp->d_wfrag), &mp->wfrag_cap, need * sizeof(double))) return e;
     q.n_wfrag_tables = a->n_pair_tables; q.wfrag = mp->d_wfrag; q.phi_p0 = ga->phi_en_en_p; q.phi_p1 = ga->phi_en_en_w1_p;
     q.plane_flags = reinterpret_cast<int32_t*>(mp->d_wfrag + (size_t)a->n_pair_tables * 8 * 4096);
     SharedGradDev& gr = d.gr;
@@ -1612,21 +1600,12 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   }
   starts[n_groups] = wg; starts[2 * n_groups + 1] = pb;
   mlbp_program* owner = const_cast<mlbp_program*>(progs[0]);
-  if (table.size() > owner->stable_cap) {
-    (void)hipFree(owner->d_stable);
-    owner->d_stable = nullptr; owner->stable_cap = 0; owner->h_stable.clear();
-    if (hipMalloc(&owner->d_stable, table.size() * sizeof(int32_t)) != hipSuccess) return fail(MLBP_EHIP, "group table allocation failed");
-    owner->stable_cap = table.size();
-  }
   hipStream_t st = (hipStream_t)stream;
-  if (owner->h_stable != table) {
-    owner->h_stable = table;
-    if (hipMemcpyAsync(owner->d_stable, owner->h_stable.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, st) != hipSuccess)
-      return fail(MLBP_EHIP, "group table upload failed");
-  }
-  const SharedDev* d_sd = reinterpret_cast<const SharedDev*>(owner->d_stable);
-  const PrepareDev* d_pd = reinterpret_cast<const PrepareDev*>(owner->d_stable + w_sd * n_groups);
-  const int32_t* d_starts = owner->d_stable + (w_sd + w_pd) * n_groups;
+  int32_t* d_stable = nullptr;               // one device copy per distinct table: a captured graph keeps replaying against its own
+  if (int e = group_table_device(owner->stables, table, stream, &d_stable)) return e;
+  const SharedDev* d_sd = reinterpret_cast<const SharedDev*>(d_stable);
+  const PrepareDev* d_pd = reinterpret_cast<const PrepareDev*>(d_stable + w_sd * n_groups);
+  const int32_t* d_starts = d_stable + (w_sd + w_pd) * n_groups;
   hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), (size_t)max_cprod * TILE * sizeof(double), st, plans[0].q, d_pd, d_starts + n_groups + 1, n_groups);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
   sweep_fn k = nullptr;
@@ -1639,6 +1618,8 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   return MLBP_OK;
 }
 
+size_t shared_gradient_workspace_bytes(const mlbp_gradient_args* a) { return sizeof(double) * (size_t)a->n_pair_tables * 2 * 4 * 4096; }
+
 int launch_shared_pair_gradient(const mlbp_gradient_args* a, int32_t* status, void* stream) {
   PairGradDev d;
   d.msgs = a->msgs; d.pair_tables = a->pair_tables; d.pair_tab = a->pair_tab;
@@ -1649,13 +1630,18 @@ int launch_shared_pair_gradient(const mlbp_gradient_args* a, int32_t* status, vo
   d.unary_expect = (a->F_ed == 6 && a->U > 0) ? a->unary_expect : nullptr;
   d.unary_tab = a->unary_tab; d.unary_kind = a->unary_kind; d.unary_obs = a->unary_obs; d.unary_label = a->unary_label;
   d.phi_ed = a->phi_en_de; d.grad_en_de = a->grad_en_de; d.U = a->U; d.n_unary_tables = a->n_unary_tables; d.Vde = a->Vde;
-  // fragment scratch: one device-wide buffer (launches on different streams must not overlap, like mlbp_sum_rows_f64)
-  static double* wfrag = nullptr;
-  static std::mutex wmutex;
-  {
-    std::lock_guard<std::mutex> lock(wmutex);
-    if (!wfrag && hipMalloc(&wfrag, sizeof(double) * PG_MAXW * 2 * 4 * 4096) != hipSuccess)
-      return fail(MLBP_EHIP, "shared-table pair gradient: scratch allocation failed");
+  // fragment scratch: the caller's workspace (mlbp_gradient_args.workspace), else the process-wide fallback block (calls that
+  // use it on different streams must not overlap; never freed, so a captured graph stays valid)
+  if (a->n_pair_tables > PG_MAXW) return fail(MLBP_EUNSUPPORTED, "shared-table pair gradient: at most %d pairwise tables", PG_MAXW);
+  const size_t need = shared_gradient_workspace_bytes(a);
+  double* wfrag = nullptr;
+  if (a->workspace) {
+    if (a->workspace_bytes < need) return fail(MLBP_EINVAL, "mlbp_gradient_f64: workspace of %zu bytes, %zu needed", (size_t)a->workspace_bytes, need);
+    wfrag = static_cast<double*>(a->workspace);
+  } else {
+    void* blk = nullptr;
+    if (int e = fallback_scratch(SCRATCH_SHARED_GRADIENT, need, &blk)) return e;
+    wfrag = static_cast<double*>(blk);
   }
   d.wfrag = wfrag;
   hipLaunchKernelGGL(pair_weight_fragments_kernel, dim3(a->n_pair_tables * 8), dim3(WG), 0, (hipStream_t)stream, a->pair_tables,

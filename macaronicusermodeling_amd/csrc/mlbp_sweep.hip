@@ -1445,9 +1445,28 @@ int mlbp_program_destroy(mlbp_program* p) {
   (void)hipFree(p->d_ops); (void)hipFree(p->d_srcs); (void)hipFree(p->d_sweeps);
   (void)hipFree(p->d_pairseq); (void)hipFree(p->d_status);
   (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq); (void)hipFree(p->d_bail); (void)hipFree(p->d_readout);
-  (void)hipFree(p->d_limage); (void)hipFree(p->d_lreadout); (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout); (void)hipFree(p->d_tfrag); (void)hipFree(p->d_spill); (void)hipFree(p->d_gtable); (void)hipFree(p->d_ptiles); (void)hipFree(p->d_stable); (void)hipFree(p->d_wfrag);
+  (void)hipFree(p->d_limage); (void)hipFree(p->d_lreadout); (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout); (void)hipFree(p->d_tfrag); (void)hipFree(p->d_spill); (void)hipFree(p->d_ptiles); (void)hipFree(p->d_wfrag);
+  (void)hipFree(p->d_gfrag); (void)hipFree(p->d_gxbuf); (void)hipFree(p->d_gwork);
+  for (void* q : p->retired) (void)hipFree(q);
+  mlbp::group_tables_free(p->gtables); mlbp::group_tables_free(p->stables);
   delete p;
   return MLBP_OK;
+}
+
+// mlbp_gradient_f64 behind the sweeps of a call: a gradient that was given no workspace gets scratch the PROGRAM owns
+// (grown by new blocks only), so that the call is safe on its own stream and inside a captured graph
+static int gradient_behind_sweeps(const mlbp_program* prog, const mlbp_gradient_args* ga, void* stream) {
+  mlbp_gradient_args g = *ga;
+  if (!g.workspace) {
+    const int64_t need = mlbp_gradient_workspace_bytes(&g);
+    if (need > 0) {
+      mlbp_program* mp = const_cast<mlbp_program*>(prog);
+      if (int e = mlbp::program_grow(mp, &mp->d_gwork, &mp->gwork_cap, (size_t)need)) return e;
+      g.workspace = mp->d_gwork;
+      g.workspace_bytes = (int64_t)mp->gwork_cap;
+    }
+  }
+  return mlbp_gradient_f64(&g, stream);
 }
 
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream) {
@@ -1551,7 +1570,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       hipLaunchKernelGGL(k, dim3(f.only ? (a->B + FIXUP_GRAPHS_PER_WG - 1) / FIXUP_GRAPHS_PER_WG : a->B), dim3(WG), lds, st, d, f, gf);
       HIP_TRY(hipGetLastError());
       if (ga && !grad_fused)
-        if (int e = mlbp_gradient_f64(ga, stream)) return e;
+        if (int e = gradient_behind_sweeps(prog, ga, stream)) return e;
       if (a->marginals && !norm)
         return mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
                                   prog->d_readout + prog->n_vars + 1, 0, a->marginals, stream);
@@ -1576,7 +1595,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       if (a->marginals)
         if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
                                        prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;
-      if (a->gradient) return mlbp_gradient_f64(a->gradient, stream);
+      if (a->gradient) return gradient_behind_sweeps(prog, a->gradient, stream);
       return MLBP_OK;
     }
   }
@@ -1619,7 +1638,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     if (a->marginals)
       if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
                                      prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;
-    if (a->gradient) return mlbp_gradient_f64(a->gradient, stream);
+    if (a->gradient) return gradient_behind_sweeps(prog, a->gradient, stream);
     return MLBP_OK;
   }
   // small state spaces (X < 64): the lean X = 64 kernel on zero-padded vectors and tables; the graphs it flags are redone
@@ -1648,7 +1667,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   if (a->marginals)
     if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
                                    prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;
-  if (a->gradient) return mlbp_gradient_f64(a->gradient, stream);
+  if (a->gradient) return gradient_behind_sweeps(prog, a->gradient, stream);
   return MLBP_OK;
 }
 
@@ -1692,16 +1711,73 @@ int mlbp_debug_set_stamp_buffer(void* dev_ptr) {
 }
 #endif
 
+}  // extern "C"
+
+namespace mlbp {
+int program_grow(mlbp_program* prog, void** p, size_t* cap, size_t bytes, bool zero) {
+  if (bytes <= *cap && *p) return MLBP_OK;
+  void* fresh = nullptr;
+  if (hipMalloc(&fresh, bytes ? bytes : 1) != hipSuccess) return fail(MLBP_EHIP, "program scratch: allocation of %zu bytes failed", bytes);
+  if (zero && hipMemset(fresh, 0, bytes) != hipSuccess) { (void)hipFree(fresh); return fail(MLBP_EHIP, "program scratch: memset failed"); }
+  if (*p) prog->retired.push_back(*p);     // a captured graph may still name it: freed with the program
+  *p = fresh;
+  *cap = bytes;
+  return MLBP_OK;
+}
+
+int fallback_scratch(int purpose, size_t bytes, void** out) {
+  struct Block { void* p = nullptr; size_t cap = 0; };
+  static std::mutex mu;
+  static std::vector<std::vector<Block>> per_device;      // [device][purpose]; replaced blocks are never freed (process lifetime)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(MLBP_EHIP, "hipGetDevice failed");
+  std::lock_guard<std::mutex> lock(mu);
+  if ((int)per_device.size() <= dev) per_device.resize(dev + 1, std::vector<Block>(SCRATCH_PURPOSES));
+  Block& b = per_device[dev][purpose];
+  if (bytes > b.cap) {
+    void* fresh = nullptr;
+    const size_t want = bytes > 2 * b.cap ? bytes : 2 * b.cap;
+    if (hipMalloc(&fresh, want) != hipSuccess) return fail(MLBP_EHIP, "scratch allocation of %zu bytes failed", want);
+    b.p = fresh; b.cap = want;
+  }
+  *out = b.p;
+  return MLBP_OK;
+}
+
+int group_table_device(GroupTables& gt, const std::vector<int32_t>& table, void* stream, int32_t** out) {
+  for (auto& e : gt.entries)
+    if (e.words == table) { *out = e.dev; return MLBP_OK; }
+  GroupTables::Entry* slot = nullptr;
+  if (gt.entries.size() < (size_t)GroupTables::MAX) { gt.entries.emplace_back(); slot = &gt.entries.back(); }
+  else { slot = &gt.entries[gt.next_evict]; gt.next_evict = (gt.next_evict + 1) % GroupTables::MAX; }
+  if (table.size() > slot->cap_words) {
+    int32_t* fresh = nullptr;
+    if (hipMalloc(&fresh, table.size() * sizeof(int32_t)) != hipSuccess) return fail(MLBP_EHIP, "group table allocation failed");
+    (void)hipFree(slot->dev);               // (only a recycled slot has one: its table is being replaced anyway)
+    slot->dev = fresh; slot->cap_words = table.size();
+  }
+  slot->words = table;
+  if (hipMemcpyAsync(slot->dev, slot->words.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+    return fail(MLBP_EHIP, "group table upload failed");
+  *out = slot->dev;
+  return MLBP_OK;
+}
+
+void group_tables_free(GroupTables& gt) {
+  for (auto& e : gt.entries) (void)hipFree(e.dev);
+  gt.entries.clear();
+}
+}  // namespace mlbp
+
+extern "C" {
+
 int mlbp_program_reserve(mlbp_program* p, int32_t max_graphs) {
   if (!p || max_graphs <= 0) return fail(MLBP_EINVAL, "mlbp_program_reserve: bad arguments");
   if (p->pruned)
     if (int e = mlbp_program_reserve(p->pruned, max_graphs)) return e;
   if (p->bail_cap >= max_graphs) return MLBP_OK;
-  (void)hipFree(p->d_bail);
-  p->d_bail = nullptr;
-  p->bail_cap = 0;
-  HIP_TRY(hipMalloc(&p->d_bail, (size_t)max_graphs));
-  HIP_TRY(hipMemset(p->d_bail, 0, (size_t)max_graphs));     // mlbp_program_exact_count before any fast-path launch reads 0
+  size_t cap = (size_t)p->bail_cap;                        // (cleared: mlbp_program_exact_count before any fast-path launch reads 0)
+  if (int e = mlbp::program_grow(p, reinterpret_cast<void**>(&p->d_bail), &cap, (size_t)max_graphs, true)) return e;
   p->bail_cap = max_graphs;
   return MLBP_OK;
 }

@@ -325,11 +325,12 @@ def test_tidir_trainer_epochs_and_predictions(tmp_path):
     assert counts == tuple(int(v) for v in want_counts)
 
 
-@pytest.mark.parametrize('X', [128, 203])
+@pytest.mark.parametrize('X', [128, 203, 777, 1100])
 def test_train_step_at_a_large_state_space_uses_batched_gemms(X):
-    """X = 128 / 203 (a vocabulary size that is no multiple of anything: zero-padded to 256): the trainer's shared pots make
-    every factor->variable update of the shard one MFMA contraction over the batch; same step as the oracle's per-instance
-    loop."""
+    """X = 128 / 203 (a vocabulary size that is no multiple of anything: zero-padded to 256) / 777 (the one-image kernel at 896)
+    / 1100 (the chunked kernel, 2 x 2 blocks of 640): the trainer's shared pots make every factor->variable update of the shard
+    one MFMA contraction over the batch, and every pairwise factor's share of the gradient one more (four weighted tables side by
+    side, the dot with the other message in its epilogue); same step as the oracle's per-instance loop."""
     from macaronicusermodeling_amd import _ffi
     from macaronicusermodeling_amd.train import UserGraphTrainer
     from macaronicusermodeling_amd.topology import GraphTopology
@@ -729,6 +730,87 @@ def test_grouped_statistics_and_the_large_state_step_replay_from_a_hip_graph(tmp
     r2 = ut.local_statistics().clone()
     ut._graph = None
     assert torch.equal(ut.local_statistics(), r2) and not torch.equal(r2, e1)
+
+
+def _large_state_trainer(B, seed, X=128):
+    from macaronicusermodeling_amd.train import UserGraphTrainer
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = C.user_spec(8, [1, 3, 6], X, 40, seed=2)
+    topo = GraphTopology.from_spec(spec)
+    inputs = C.make_inputs(spec, 78)
+    labels, obs = _instances(spec, topo, B, seed)
+    return UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],
+                            inputs['theta_en_en'], inputs['theta_en_de'], roots=[3, 1, 6])
+
+
+def test_a_captured_large_state_step_survives_larger_calls_behind_it():
+    """the X >= 128 shared-table path kept its fragment and gradient buffers in process-wide statics that a
+    later, larger call freed and re-allocated -- a HIP graph captured before replayed against freed memory.  The buffers now
+    belong to the program (and, for a standalone mlbp_gradient_f64, to the caller's workspace or a block that only grows by
+    new allocations): a step captured at B = 64 replays bit-identically after an eager step at B = 512 and after standalone
+    gradient calls of both sizes."""
+    small = _large_state_trainer(64, 6)
+    want = small.local_statistics().clone()
+    small.capture()
+    assert torch.equal(small.local_statistics(), want)
+    big = _large_state_trainer(512, 7)
+    big_stats = big.local_statistics().clone()              # larger B: more scratch everywhere
+    big.batch.sweep(big.roots, init=True)
+    big.batch.gradient()                                    # standalone, no workspace: the process-wide block grows
+    small.batch.gradient()
+    torch.cuda.synchronize()
+    assert torch.equal(small.local_statistics(), want)      # replayed
+    assert torch.equal(big.local_statistics(), big_stats)
+    # a caller-owned workspace gives the same numbers as the fallback block
+    from macaronicusermodeling_amd import _ffi
+    import ctypes
+    fb = big.batch
+    fb.sweep(big.roots, init=True)
+    ee1, ed1 = fb.gradient()
+    ee2, ed2 = torch.empty_like(ee1), torch.empty_like(ed1)
+    a = fb._gradient_args(ee2, ed2)
+    need = _ffi.lib.mlbp_gradient_workspace_bytes(ctypes.byref(a))
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device=fb.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), need
+    _ffi.check(_ffi.lib.mlbp_gradient_f64(ctypes.byref(a), None if False else ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert torch.equal(ee1, ee2) and torch.equal(ed1, ed2)
+    a.workspace_bytes = need - 8
+    with pytest.raises(_ffi.MlbpError):
+        _ffi.check(_ffi.lib.mlbp_gradient_f64(ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+
+def test_two_threads_run_large_state_steps_on_two_streams():
+    """Different programs on different streams, X = 128 shared tables (sweeps as batched contractions + the pairwise gradient):
+    every scratch buffer of the path belongs to a program, so two host threads with their own trainers and streams run
+    concurrently and get what each gets alone (the header's concurrency rule; the buffers used to be process-wide)."""
+    import threading
+    alone = []
+    for k in range(2):
+        tr = _large_state_trainer(96 + 32 * k, 11 + k)
+        alone.append(tr.local_statistics().clone())
+    torch.cuda.synchronize()
+    out, errs = [None, None], []
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                tr = _large_state_trainer(96 + 32 * k, 11 + k)
+                for _ in range(6):
+                    got = tr.local_statistics()
+                st.synchronize()
+                out[k] = got.clone()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in range(2):
+        assert torch.equal(out[k], alone[k])
 
 
 def _write_tidir(gold, d):

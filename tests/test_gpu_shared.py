@@ -267,6 +267,55 @@ def test_large_state_shared_tables_run_as_batched_gemms(X):
     assert prog.status() == 2
 
 
+@pytest.mark.parametrize('X', [640, 777, 1000, 1100, 1536, 2048])
+def test_vocabulary_sized_shared_tables_run_as_batched_gemms(X):
+    """X = len(en_domain) in the reference (train_mp.py:591-594) and its pairwise tables are always shared (LBP.py:456-467,
+    695-706): sizes past 512 stay on the matrix cores.  Up to 1024 states the one-image contraction kernel (its LDS image of 16
+    graphs is at most 131 KiB); beyond, the chunked kernel, which walks the table in blocks of at most 1024 x 1024 states
+    (1100 -> 2 x 2 blocks of 640, 1536 -> 768, 2048 -> 1024).  Against the oracle per graph and against the per-graph
+    kernels on the same inputs (the wide kernel up to 1024 states, the generic one beyond)."""
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.batch import FactorGraphBatch
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = C.ring_spec(3, X)
+    topo = GraphTopology.from_spec(spec)
+    B = 19                                      # two workgroups of 16 graphs, the second one ragged
+    rs = np.random.RandomState(4000 + X)
+    shared = C.make_inputs(spec, 61)            # graph 0: the pairwise tables every graph reads
+    inputs = []
+    for b in range(B):                          # ... and its own unary columns
+        tabs = list(shared['tables'])
+        for f in spec['factors']:
+            if len(f['vars']) == 1 and b > 0:
+                tabs[f['table']] = rs.rand(X, 1) + 0.01
+        inputs.append(dict(tables=tabs))
+    g = O.Graph(spec)
+    pair = np.stack([O.factor_table(g, inputs[0], g.by_id[topo.factor_ids[j]]).reshape(X, X) for j in topo.pair_factors])
+    unary = np.stack([O.factor_table(g, inputs[b], g.by_id[topo.factor_ids[j]]).reshape(X) for b in range(B) for j in topo.unary_factors])
+    fb = FactorGraphBatch(topo, X, B)
+    fb.set_pair_tables(pair, np.tile(np.arange(topo.P), (B, 1)))
+    fb.set_unary_tables(unary)
+    roots = [0, 2, 1]
+    marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=fb.device)
+    fb.msgs.fill_(float('nan'))
+    prog = fb.sweep(roots, init=True, marginals=marg)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 6, _ffi.lib.mlbp_last_error()      # MLBP_KERNEL_SHARED_GEMM
+    assert prog.status() == 0
+    got, gm = fb.msgs.clone(), marg.clone()
+    assert float((got.sum(-1) - 1).abs().max()) < 1e-12
+    try:
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(3))                             # per-graph kernels on the same inputs
+        fb.sweep(roots, init=True, marginals=marg)
+        assert _ffi.lib.mlbp_last_sweep_kernel() == (4 if X <= 1024 else 5)
+    finally:
+        _ffi.check(_ffi.lib.mlbp_set_sweep_variant(1))
+    np.testing.assert_allclose(got.cpu().numpy(), fb.msgs.cpu().numpy(), rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(gm.cpu().numpy(), marg.cpu().numpy(), rtol=1e-11, atol=1e-300)
+    for b in (0, 15, B - 1):
+        _, _, want = oracle_msgs(spec, inputs[b], roots)
+        np.testing.assert_allclose(got[b].cpu().numpy(), want, rtol=RTOL, atol=1e-300)
+
+
 @pytest.mark.parametrize('which', ['ring8', 'chain8'])
 def test_shared_kernel_with_most_tiles_spilled(which):
     """Rings / chains of 8 variables need 22-24 message tiles; 8-9 stay in LDS, the rest live in the global spill area

@@ -526,6 +526,11 @@ typedef struct mlbp_potentials_job {
   double* pot_t;           /* [n_rep] x [cols][rows], or NULL */
   int64_t theta_stride, pot_stride, pot_t_stride;
   int32_t rows, cols, F, reserved;
+  double* expect;          /* [n_rep] x [cols][8], or NULL (rows == 64 only): expect[j][k] = sum_i b_i phi[i][j][k] with
+                              b = au.normalize(pot[:, j]) -- the expected features of a unary factor observed at column j
+                              (LBP.py:540, 600-603), i.e. what mlbp_unary_expectations_f64 computes for row j of pot_t, here
+                              from the values the launch has in registers anyway (one launch less per optimisation step) */
+  int64_t expect_stride;   /* doubles between two repetitions' expect arrays */
 } mlbp_potentials_job;
 int mlbp_potentials_multi_f64(const mlbp_potentials_job* jobs, int32_t n_jobs, int32_t n_rep, void* stream);
 

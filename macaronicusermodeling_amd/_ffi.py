@@ -44,7 +44,8 @@ class GradientArgs(C.Structure):
 class PotentialsJob(C.Structure):
     _fields_ = [('phi', C.c_void_p), ('theta', C.c_void_p), ('pot', C.c_void_p), ('pot_t', C.c_void_p),
                 ('theta_stride', C.c_int64), ('pot_stride', C.c_int64), ('pot_t_stride', C.c_int64),
-                ('rows', C.c_int32), ('cols', C.c_int32), ('F', C.c_int32), ('reserved', C.c_int32)]
+                ('rows', C.c_int32), ('cols', C.c_int32), ('F', C.c_int32), ('reserved', C.c_int32),
+                ('expect', C.c_void_p), ('expect_stride', C.c_int64)]
 
 
 class SweepArgs(C.Structure):

@@ -203,29 +203,127 @@ def sparse_normalize(m1, c_idx, r_idx):
     return m1
 
 
-# ---- names that exist in the reference module but have NO caller anywhere in the reference --------
-# (SURVEY.md section 2, row 2).  They are kept so `dir(au)` stays a superset; they are not part of
-# the hot path and are deliberately not given a CPU implementation here.
-def _dead(name, line):
-    def fn(*args, **kwargs):
-        raise NotImplementedError('%s (c_array_utils.pyx:%s) has no caller in the reference and is outside the '
-                                  'accelerated hot path' % (name, line))
-    fn.__name__ = name
-    return fn
+# ---- the functions of the reference module that NOTHING in the reference calls -----------------------------------------
+# (c_array_utils.pyx:18-20, 43-75, 96-105, 132-190.)  Not on the hot path and not accelerated: small
+# host-side NumPy bodies with the reference's argument meaning, in-place behaviour, return types and errors, so that code
+# which imports the module finds every name doing what it did.  Pinned on outputs of the reference's own module
+# (tests/golden/au_dormant_functions.npz, generated by make_golden.py; tests/test_au_dormant.py).  Top-K selections: the K
+# largest entries, ties by lower index (the rule of mlbp_topk_f64; np.argpartition leaves the order open).
+def _top_k(flat, k):
+    """Indices of the k largest entries of a 1-D array (ties: lower index first), ascending by index."""
+    order = np.lexsort((np.arange(flat.size), -flat))
+    return np.sort(order[:k])
 
 
-clip = _dead('clip', '18-20')
-induce_s_pointwise_multiply_clip = _dead('induce_s_pointwise_multiply_clip', '43-50')
-induce_s = _dead('induce_s', '53-63')
-induce_s_mutliply_clip = _dead('induce_s_mutliply_clip', '66-75')
-make_sparse_and_dot = _dead('make_sparse_and_dot', '96-105')
-sparse_multiply_and_normalize = _dead('sparse_multiply_and_normalize', '132-142')
-sd_matrix_multiply = _dead('sd_matrix_multiply', '145-146')
-ss_matix_multiply = _dead('ss_matix_multiply', '153-154')
-make_adapt_phi = _dead('make_adapt_phi', '157-161')
-set_adaptation = _dead('set_adaptation', '164-173')
-set_adaptation_off = _dead('set_adaptation_off', '176-184')
-set_original = _dead('set_original', '187-190')
+def clip(m1):
+    """c_array_utils.pyx:18-20: entries below 1e-100 become 0, IN PLACE; returns its argument."""
+    m1[m1 < 1.0e-100] = 0.0
+    return m1
+
+
+def induce_s_pointwise_multiply_clip(d1, d2):
+    """c_array_utils.pyx:43-50: zeros like d2 except at the K = 100 largest cells of d1, where d1 * d2."""
+    d1, d2 = np.asarray(d1), np.asarray(d2)
+    if __debug__:
+        assert np.shape(d1) == np.shape(d2)
+    if K_SPARSE >= d1.size:                      # `(-d1).argpartition(K, axis=None)`
+        raise ValueError('kth(=%d) out of bounds (%d)' % (K_SPARSE, d1.size))
+    x, y = np.unravel_index(_top_k(d1.reshape(-1), K_SPARSE), d1.shape)
+    result = np.zeros_like(d2)
+    result[x, y] = d1[x, y] * d2[x, y]
+    return result
+
+
+def induce_s(m1):
+    """c_array_utils.pyx:53-63: a column vector with everything but its K = 100 largest entries zeroed (a NEW array); a
+    vector of fewer than K entries comes back as it is (the same object)."""
+    if __debug__:
+        assert np.shape(m1)[1] == 1
+    if K_SPARSE > np.size(m1):
+        return m1
+    if K_SPARSE >= np.size(m1):
+        raise ValueError('kth(=%d) out of bounds (%d)' % (K_SPARSE, np.size(m1)))
+    x, y = np.unravel_index(_top_k(np.asarray(m1).reshape(-1), K_SPARSE), np.shape(m1))
+    new_m1 = np.zeros_like(m1)
+    new_m1[x, y] = m1[x, y]
+    return new_m1
+
+
+def induce_s_mutliply_clip(s1, d2):
+    """c_array_utils.pyx:66-75 (the reference's spelling): d2[:, idx] . s1[idx] over the K = 100 entries of s1 largest in
+    magnitude."""
+    if __debug__:
+        assert np.shape(d2)[0] < np.shape(d2)[1]
+        assert np.shape(s1)[0] == np.shape(d2)[1] and np.shape(s1)[1] == 1
+    n = np.size(s1)
+    if K_SPARSE > n:                             # `np.argpartition(s1_abs, -K)`
+        raise ValueError('kth(=%d) out of bounds (%d)' % (n - K_SPARSE, n))
+    idx = _top_k(np.abs(np.asarray(s1)).reshape(n), K_SPARSE)
+    return np.asarray(d2)[:, idx].dot(np.asarray(s1)[idx, :])
+
+
+def make_sparse_and_dot(m1, m2):
+    """c_array_utils.pyx:96-105: {(x, y): m1[x, 0] * m2[0, y]} over the K = 100 largest entries of each."""
+    a, b = np.reshape(m1, np.size(m1)), np.reshape(m2, np.size(m2))
+    for v in (a, b):
+        if K_SPARSE > v.size:
+            raise ValueError('kth(=%d) out of bounds (%d)' % (v.size - K_SPARSE, v.size))
+    xs, ys = _top_k(a, K_SPARSE), _top_k(b, K_SPARSE)
+    return {(x, y): m1[x, 0] * m2[0, y] for x, y in itertools.product(xs, ys)}
+
+
+def sparse_multiply_and_normalize(s_m1, m2):
+    """c_array_utils.pyx:132-142: s_m1 = {(x, y): v}; returns (zeros like m2 with m2[x, y] * v at those cells, normalised
+    over them; the same values as a dict).  The total is accumulated in the dict's iteration order, like the reference."""
+    m2_z = np.zeros_like(m2)
+    m2_d = {}
+    n = 0.0
+    for (x, y), v in s_m1.items():
+        m2_z[x, y] = m2[x, y] * v
+        n += m2_z[x, y]
+    for x, y in s_m1:
+        m2_z[x, y] = m2_z[x, y] / n
+        m2_d[x, y] = m2_z[x, y]
+    return m2_z, m2_d
+
+
+def sd_matrix_multiply(s1, d2):
+    """c_array_utils.pyx:145-146: `s1.dot(d2)` (a scipy sparse matrix times a dense one)."""
+    return s1.dot(d2)
+
+
+def ss_matix_multiply(s1, s2):
+    """c_array_utils.pyx:153-154 (the reference's spelling): `s1.dot(s2)`, sparse times sparse."""
+    return s1.dot(s2)
+
+
+def make_adapt_phi(phi, num_adaptations):
+    """c_array_utils.pyx:157-161: [phi | 0 | ... | 0], num_adaptations zero copies of phi's width behind it."""
+    adapt_phi = np.zeros((np.shape(phi)[0], np.shape(phi)[1] * (num_adaptations + 1)))
+    adapt_phi[:, :np.shape(phi)[1]] = phi
+    return adapt_phi
+
+
+def set_adaptation(f_size, adapt_phi, active_adaptations):
+    """c_array_utils.pyx:164-173: block i (columns i f .. i f + f) := block 0 for every active i, IN PLACE."""
+    f = f_size
+    for i in active_adaptations:
+        adapt_phi[:, i * f:i * f + f] = adapt_phi[:, :f]
+    return adapt_phi
+
+
+def set_adaptation_off(f_size, adapt_phi, active_adaptations):
+    """c_array_utils.pyx:176-184: block i := 0 for every listed i, IN PLACE."""
+    f = f_size
+    for i in active_adaptations:
+        adapt_phi[:, i * f:i * f + f] = 0
+    return adapt_phi
+
+
+def set_original(phi, adapt_phi):
+    """c_array_utils.pyx:187-190: block 0 := phi, IN PLACE."""
+    adapt_phi[:, :np.shape(phi)[1]] = phi
+    return adapt_phi
 
 
 def induce_s_multiply_threshold(s1, d2):

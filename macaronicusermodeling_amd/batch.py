@@ -410,10 +410,14 @@ class FactorGraphBatch:
                 a.pair_slots_host = self._pair_slots_host.ctypes.data
             self._derive_unary_rows()
             if getattr(self, '_row_kind', None) is not None and self._row_kind is not False and F_ee == 3 and F_ed == 6:
-                _ffi.check(_ffi.lib.mlbp_unary_expectations_f64(
-                    self.unary_tables.data_ptr(), int(self.unary_tables.shape[0]), self.X, self._row_kind.data_ptr(),
-                    self._row_obs.data_ptr(), self._phi_t[0].data_ptr(), self._phi_t[1].data_ptr(), self._phi_t[2].data_ptr(),
-                    F_ee, F_ed, int(self.phi_en_de.shape[1]), self._uexp.data_ptr(), _stream_ptr(self.device)))
+                # rows [0, done) were written by the caller's potentials launch (mlbp_potentials_job.expect: the trainer's shared
+                # pots); what is left -- all rows, or the trainer's private plane-patched ones -- is computed here
+                done, n_rows = int(getattr(self, '_uexp_rows_done', 0)), int(self.unary_tables.shape[0])
+                if done < n_rows:
+                    _ffi.check(_ffi.lib.mlbp_unary_expectations_f64(
+                        self.unary_tables[done:].data_ptr(), n_rows - done, self.X, self._row_kind[done:].data_ptr(),
+                        self._row_obs[done:].data_ptr(), self._phi_t[0].data_ptr(), self._phi_t[1].data_ptr(), self._phi_t[2].data_ptr(),
+                        F_ee, F_ed, int(self.phi_en_de.shape[1]), self._uexp[done:].data_ptr(), _stream_ptr(self.device)))
                 a.unary_expect = self._uexp.data_ptr()
         return a
 

@@ -50,6 +50,7 @@ struct GradDev {
   mlbp_gradient_args a;
   int32_t* status;
   int32_t skip_pairs;      // the pairwise factors are handled by the shared-table (MFMA) kernel
+  const uint8_t* only;     // non-NULL (X = 64 kernel): only the graphs whose flag byte is set (the fix-up behind a fused gradient)
 };
 
 // sums[0..n) over the workgroup; result valid in every thread.  scratch: [4][FMAX+1] doubles.
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(WG) void gradient_x64_kernel(GradDev d) {
   __shared__ double wave_out[4][2 * FMAX];
   const mlbp_gradient_args& a = d.a;
   const int g = blockIdx.x;
+  if (d.only && !d.only[g]) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double gee[FEE];
 #pragma unroll
@@ -618,6 +620,22 @@ static bool takes_gemm_pairs(const mlbp_gradient_args* a) {
          mlbp::gemm_path_supports(a->X) && a->F_ee == 3 && a->P > 0 && a->P <= 16 && a->phi_en_en_p && a->phi_en_en_w1_p;
 }
 
+namespace mlbp {
+// The gradient of the graphs whose flag byte is set, by the per-graph X = 64 kernel (every factor of the graph, from the
+// messages in memory): the fix-up behind a shared-table sweep whose epilogue produced the gradient of all the others.
+int gradient_flagged_only(const mlbp_gradient_args* a, const uint8_t* flags, void* stream) {
+  if (!a || a->X != 64 || a->F_ee != 3 || a->F_ed != 6) return fail(MLBP_EINVAL, "gradient_flagged_only: X = 64, F = (3, 6)");
+  GradDev d;
+  d.a = *a;
+  d.skip_pairs = 0;
+  d.only = flags;
+  if (int e = status_word(&d.status)) return e;
+  hipLaunchKernelGGL((gradient_x64_kernel<3, 6>), dim3(a->B), dim3(WG), 0, (hipStream_t)stream, d);
+  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "gradient fix-up launch failed");
+  return MLBP_OK;
+}
+}  // namespace mlbp
+
 extern "C" {
 
 int64_t mlbp_gradient_workspace_bytes(const mlbp_gradient_args* a) {
@@ -644,6 +662,7 @@ int mlbp_gradient_f64(const mlbp_gradient_args* a, void* stream) {
   GradDev d;
   d.a = *a;
   d.skip_pairs = 0;
+  d.only = nullptr;
   if (int e = status_word(&d.status)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (a->X == 64 && (a->flags & MLBP_GRADIENT_APPROX_BELIEFS))

@@ -231,9 +231,23 @@ __device__ __forceinline__ void gradient_epilogue(const SweepDev& d, const GradF
   //      (au.normalize: a total <= 0 gives zero beliefs);
   //   3. G_t[k] = sum_ij V_t[i][j] phi_t[i][j][k]: three accumulators per tensor, the thread's sixteen cells of the tensor
   //      loaded eight at a time.
+  // thread p < P: the label cell's features of pairwise factor p -- two dependent loads, requested first and long finished when
+  // thread 0 adds them up (they used to be the last thing the workgroup waited for, one thread, two round trips)
+  double lf[FEE] = {0.0, 0.0, 0.0};
+  bool lbad = false;
+  if (t < NT && t < d.P) {
+    const int l0 = gf.pair_label[((size_t)g * d.P + t) * 2], l1 = gf.pair_label[((size_t)g * d.P + t) * 2 + 1];
+    if ((unsigned)l0 >= 64u || (unsigned)l1 >= 64u) lbad = true;
+    else {
+      const double* phl = (gf.pair_phi[t] ? gf.phi_en_en_w1 : gf.phi_en_en) + ((size_t)l0 * 64 + l1) * FEE;
+#pragma unroll
+      for (int q = 0; q < FEE; ++q) lf[q] = phl[q];
+    }
+  }
   int which = 0;                                                 // bit p: factor p reads phi_en_en_w1
   double2 W[NT][4][2];
   double* zs = scratch + 512;                                    // [4 waves][NT] (the per-wave results below use scratch[0 .. 4 PER))
+  double* lfs = scratch + 544;                                   // [NT][FEE] the label features, for thread 0's final sum
 #pragma unroll
   for (int p = 0; p < NT; ++p) {
     double z = 0.0;
@@ -258,6 +272,11 @@ __device__ __forceinline__ void gradient_epilogue(const SweepDev& d, const GradF
 #pragma unroll
       for (int r = 0; r < 4; ++r) W[p][r][0] = W[p][r][1] = make_double2(0.0, 0.0);
     }
+  }
+  if (lbad) atomicExch(d.status, 1);
+  if (t < NT && t < d.P) {                                       // (parked in LDS here: kept in registers to the end they spill the tables)
+#pragma unroll
+    for (int q = 0; q < FEE; ++q) lfs[t * FEE + q] = lf[q];
   }
   lds_barrier();
   double2 V[2][4][2];
@@ -311,11 +330,12 @@ __device__ __forceinline__ void gradient_epilogue(const SweepDev& d, const GradF
   double gsum[FEE];                                              // expected features of all pairwise factors (this wave's share)
 #pragma unroll
   for (int q = 0; q < FEE; ++q) gsum[q] = wave_sum(gacc[0][q] + gacc[1][q]);
-  // unary factors: wave w takes factors w, w + 4, ...; three at a time so that their feature slabs are in flight together
+  // unary factors: wave w takes factors w, w + 4, ...; six at a time so that their feature slabs are in flight together (the
+  // tables are dead by now: the registers are there)
   double lab_ee[FEE] = {0.0, 0.0, 0.0}, lab_ed[FED] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // phi at the label (wave-uniform)
   double exp_ee[FEE] = {0.0, 0.0, 0.0}, exp_ed[FED] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // per-lane partial expected features
   bool bad = false;
-  constexpr int UB = 3;
+  constexpr int UB = 6;                                          // (a K3 user graph's 24 unary factors: one round trip per wave)
   const int U = d.U;
   for (int u0 = wave; u0 < U; u0 += 4 * UB) {
     double b[UB], pv[UB][FED];
@@ -385,18 +405,13 @@ __device__ __forceinline__ void gradient_epilogue(const SweepDev& d, const GradF
     double gee[FEE];
 #pragma unroll
     for (int q = 0; q < FEE; ++q) gee[q] = tot[FEE + q] - tot[q];
-    bool lbad = false;
 #pragma unroll
     for (int p = 0; p < NT; ++p) {
       if (p < d.P) {
-        const int l0 = gf.pair_label[((size_t)g * d.P + p) * 2], l1 = gf.pair_label[((size_t)g * d.P + p) * 2 + 1];
-        if ((unsigned)l0 >= 64u || (unsigned)l1 >= 64u) { lbad = true; continue; }
-        const double* phi = gf.pair_phi[p] ? gf.phi_en_en_w1 : gf.phi_en_en;
 #pragma unroll
-        for (int q = 0; q < FEE; ++q) gee[q] += phi[((size_t)l0 * 64 + l1) * FEE + q];
+        for (int q = 0; q < FEE; ++q) gee[q] += lfs[p * FEE + q];
       }
     }
-    if (lbad) atomicExch(d.status, 1);
 #pragma unroll
     for (int q = 0; q < FEE; ++q) gf.grad_en_en[(size_t)g * FEE + q] = gee[q];
 #pragma unroll

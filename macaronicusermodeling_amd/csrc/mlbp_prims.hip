@@ -198,6 +198,27 @@ __global__ void potentials_multi_kernel(PotentialsJobs js) {
   const double* theta = J.theta + (int64_t)blockIdx.z * J.theta_stride;
   double* pot = J.pot ? J.pot + (int64_t)blockIdx.z * J.pot_stride : nullptr;
   double* pot_t = J.pot_t ? J.pot_t + (int64_t)blockIdx.z * J.pot_t_stride : nullptr;
+  if (J.expect && J.rows == 64) {
+    // one wave per column j, lane = row i: the column is a unary factor's table (LBP.py:702-703), so its total and its expected
+    // features come out of the same registers (unary_expectations_kernel's arithmetic: wave sums of v and v * phi_k)
+    double* ex = J.expect + (int64_t)blockIdx.z * J.expect_stride;
+    const int lane = threadIdx.x & 63;
+    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < J.cols; j += gridDim.x * 4) {
+      const int64_t e = (int64_t)lane * J.cols + j;
+      const double* ph = J.phi + e * J.F;
+      double acc = 0.0;
+      for (int k = 0; k < J.F; ++k) acc += ph[k] * theta[k];
+      const double v = exp(acc);
+      if (pot) pot[e] = v;
+      if (pot_t) pot_t[(int64_t)j * 64 + lane] = v;
+      const double Z = wave_sum(v);
+      for (int k = 0; k < J.F && k < 8; ++k) {          // (the features are read again, from L1: kept in an array indexed at run time they live in scratch)
+        const double s = wave_sum(v * ph[k]);
+        if (lane == 0) ex[(int64_t)j * 8 + k] = Z > 0.0 ? s / Z : 0.0;          // au.normalize: zero-sum -> 0
+      }
+    }
+    return;
+  }
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     double acc = 0.0;
     for (int k = 0; k < J.F; ++k) acc += J.phi[e * J.F + k] * theta[k];
@@ -357,6 +378,8 @@ int mlbp_potentials_multi_f64(const mlbp_potentials_job* jobs, int32_t n_jobs, i
     const mlbp_potentials_job& J = jobs[j];
     if (!J.phi || !J.theta || J.rows <= 0 || J.cols <= 0 || J.F <= 0 || (!J.pot && !J.pot_t))
       return fail(MLBP_EINVAL, "mlbp_potentials_multi_f64: bad job %d", j);
+    if (J.expect && (J.rows != 64 || J.F > 8))
+      return fail(MLBP_EUNSUPPORTED, "mlbp_potentials_multi_f64: job %d: expectations need 64 rows and at most 8 features", j);
     js.j[j] = J;
     n_max = std::max<int64_t>(n_max, (int64_t)J.rows * J.cols);
   }

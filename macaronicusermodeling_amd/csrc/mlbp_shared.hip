@@ -1381,6 +1381,13 @@ std::mutex g_attr_mutex;
 
 typedef void (*sweep_fn)(SharedDev, const SharedDev*, const int32_t*, int);
 
+// the gradient-epilogue instances that exist: all-resident two-source, and spilling + wide
+template <int T, bool S, bool W, bool M>
+sweep_fn grad_instance() {
+  if constexpr (S == W) return (sweep_fn)sweep_x64_shared_kernel<T, S, W, M, true>;
+  else return nullptr;
+}
+
 // the instance for (two tables?, spilled tiles?, more than two sources?, groups?); raises its dynamic LDS limit once
 int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, size_t lds, sweep_fn* out) {
   sweep_fn k = nullptr;
@@ -1389,10 +1396,11 @@ int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, si
   k = two ? (grad ? sweep_x64_shared_kernel<2, false, false, false, true> : sweep_x64_shared_kernel<2, false, false, false, false>)
           : (grad ? sweep_x64_shared_kernel<1, false, false, false, true> : sweep_x64_shared_kernel<1, false, false, false, false>);
 #else
-  // (the gradient epilogue comes with at most three pairwise factors and every tile in LDS: a variable with three pairwise
-  // factors has three neighbours, and four variables' tiles do not fit -- so neither spilled tiles nor three-source updates)
-  if (grad && (spill || wide)) return fail(MLBP_EUNSUPPORTED, "shared-table kernel: no instance with the gradient epilogue and spilled tiles or wide updates");
-#define MLBP_SK(T, S, W, M) (grad ? ((S || W) ? (sweep_fn) nullptr : (sweep_fn)sweep_x64_shared_kernel<T, false, false, M, true>) : (sweep_fn)sweep_x64_shared_kernel<T, S, W, M, false>)
+  // (the gradient epilogue comes in two forms: every tile in LDS and two-source updates -- K2, K3 --, or spilled tiles AND
+  // wide updates -- K4 and larger cliques, train_mp.py:272-282: a variable with three pairwise factors has three neighbours, and
+  // four variables' tiles do not fit.  A launch of mixed groups takes the second.)
+  if (grad && spill != wide) { spill = true; wide = true; }
+#define MLBP_SK(T, S, W, M) (grad ? grad_instance<T, S, W, M>() : (sweep_fn)sweep_x64_shared_kernel<T, S, W, M, false>)
 #define MLBP_SK_M(T, S, W) (multi ? MLBP_SK(T, S, W, true) : MLBP_SK(T, S, W, false))
 #define MLBP_SK_W(T, S) (wide ? MLBP_SK_M(T, S, true) : MLBP_SK_M(T, S, false))
 #define MLBP_SK_S(T) (spill ? MLBP_SK_W(T, true) : MLBP_SK_W(T, false))
@@ -1437,11 +1445,16 @@ int resident_tiles(const SharedProgram& sp, size_t* lds) {
 // gradient of the graphs it redoes.  A function of the arguments alone: the dispatcher asks it again after the launch.
 bool shared_gradient_fused(const mlbp_program* prog, const mlbp_sweep_args* a) {
   const mlbp_gradient_args* ga = a->gradient;
-  if (!ga || !exact_kernel_fuses_gradient(prog, a)) return false;
-  return (ga->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && prog->P >= 1 && a->n_pair_tables <= FRAG_TABLES && ga->phi_en_en_p &&
+  if (!ga || a->X != 64 || !a->normalize_messages) return false;
+  if (ga->B != a->B || ga->X != a->X || ga->P != prog->P || ga->U != prog->U || ga->n_msgs != prog->n_msgs || ga->msgs != a->msgs) return false;
+  if (!(ga->F_ee == 3 && ga->F_ed == 6) || (ga->flags & MLBP_GRADIENT_APPROX_BELIEFS)) return false;
+  // graphs the sweep kernel flags get their gradient from the exact kernel's own epilogue (at most three pairwise factors), or
+  // -- larger cliques -- from the per-graph gradient kernel run on the flagged graphs only; both read the transposed tensors
+  if (!(ga->phi_en_en_t && ga->phi_en_en_w1_t && ga->phi_en_de_t)) return false;
+  if (prog->P <= 3 && !exact_kernel_fuses_gradient(prog, a)) return false;
+  return (ga->flags & MLBP_GRADIENT_SHARED_PAIR_TABLES) && prog->P >= 1 && prog->P <= 16 && a->n_pair_tables <= FRAG_TABLES && ga->phi_en_en_p &&
          ga->phi_en_en_w1_p && ga->phi_en_en && ga->phi_en_en_w1 && (prog->U == 0 || (ga->unary_expect && ga->phi_en_de)) && a->msgs &&
-         prog->shared.ok && prog->shared.n_live >= 3 && resident_tiles(prog->shared, nullptr) == prog->shared.n_live &&   // (every tile in LDS,
-         prog->shared.max_sources <= 2;                                                                            //  two-source updates)
+         prog->shared.ok && prog->shared.n_live >= 3 && resident_tiles(prog->shared, nullptr) >= 3;
 }
 
 namespace {
@@ -1585,7 +1598,8 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
     wide |= plans[k].wide; spill |= plans[k].spill; two |= progs[k]->P >= 2; grad |= plans[k].d.gr.enabled != 0;
     max_cprod = std::max(max_cprod, (int)plans[k].q.n_cprod);
   }
-  if (grad && (spill || wide)) return MLBP_OK;       // no such instance (one group spills tiles or has wide updates, another carries the gradient): group by group
+  // (a launch with the gradient epilogue runs the all-resident / two-source instance, or -- as soon as one group spills tiles or
+  // has wider updates: K4 and larger cliques -- the general one: pick_sweep_kernel)
   // table image: [SharedDev x n][PrepareDev x n][sweep starts n + 1][prepare starts n + 1], as 32-bit words
   const size_t w_sd = sizeof(SharedDev) / 4, w_pd = sizeof(PrepareDev) / 4;
   static_assert(sizeof(SharedDev) % 8 == 0 && sizeof(PrepareDev) % 8 == 0, "group tables are copied as words");

@@ -1541,14 +1541,21 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       if (g_shared_predone) shared_done = true;  // mlbp_sweep_groups_f64 ran the shared-table kernels for this group already
       else if (fast && !g_lean_predone)
         if (int e = mlbp::launch_shared_sweep(prog, a, stream, &shared_done)) return e;
-      // (the shared-table kernel ran the gradient as its epilogue: the fix-up pass keeps its own for the graphs it redoes)
-      if (shared_done && !(grad_fused && mlbp::shared_gradient_fused(prog, a))) { grad_fused = false; gf = GradFusedDev{}; }
+      // (the shared-table kernel ran the gradient as its epilogue: the fix-up pass keeps its own for the graphs it redoes -- or,
+      // with more than three pairwise factors, where the exact kernel streams its tables and has no epilogue, the per-graph
+      // gradient kernel follows on the flagged graphs only)
+      bool grad_flagged_fixup = false;
+      if (shared_done) {
+        const bool sg = ga && mlbp::shared_gradient_fused(prog, a);
+        if (sg && !grad_fused) grad_flagged_fixup = true;
+        if (!sg || !grad_fused) { grad_fused = false; gf = GradFusedDev{}; }
+      }
       bool lean_done = false;                  // default path: the lean scale-free kernel (mlbp_lean.hip), up to 8 resident tables
       if (g_lean_predone) lean_done = true;     // mlbp_sweep_groups_f64 ran the lean kernel for this group already
       else if (fast && norm && prog->sf_ok && prog->P >= 1 && prog->P <= 8 && !shared_done)
         if (int e = mlbp::launch_lean_sweep(prog, a, grad_fused ? &gf : nullptr, stream, &lean_done)) return e;
       g_last_kernel = shared_done ? MLBP_KERNEL_SHARED_MFMA : (lean_done ? MLBP_KERNEL_LEAN : MLBP_KERNEL_EXACT);
-      g_last_fused_gradient = grad_fused ? 1 : 0;
+      g_last_fused_gradient = (grad_fused || grad_flagged_fixup) ? 1 : 0;
       FusedDev f;
       f.only = (shared_done || lean_done) ? mp->d_bail : nullptr;     // after a fast pass: flagged graphs only
       f.image = prog->d_fops; f.fsweeps = prog->d_fsweeps;
@@ -1569,8 +1576,11 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       if (int e = ensure_dynamic_lds((const void*)k, lds)) return e;
       hipLaunchKernelGGL(k, dim3(f.only ? (a->B + FIXUP_GRAPHS_PER_WG - 1) / FIXUP_GRAPHS_PER_WG : a->B), dim3(WG), lds, st, d, f, gf);
       HIP_TRY(hipGetLastError());
-      if (ga && !grad_fused)
+      if (ga && grad_flagged_fixup) {
+        if (int e = mlbp::gradient_flagged_only(ga, mp->d_bail, stream)) return e;
+      } else if (ga && !grad_fused) {
         if (int e = gradient_behind_sweeps(prog, ga, stream)) return e;
+      }
       if (a->marginals && !norm)
         return mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
                                   prog->d_readout + prog->n_vars + 1, 0, a->marginals, stream);

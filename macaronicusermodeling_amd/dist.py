@@ -50,3 +50,9 @@ def all_reduce_sum_(buf):
 
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def barrier():
+    """All ranks meet (no-op without a process group): rank 0 joining the ranks' prediction shards into one file."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

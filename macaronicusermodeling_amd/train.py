@@ -18,6 +18,7 @@ table-index indirection; a unary factor's table is a COLUMN of a pot (LBP.py:702
 row of the transposed pot the potentials kernel also writes -- no per-instance copies.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -123,6 +124,14 @@ class UserGraphTrainer:
         self.stats_all = torch.zeros(n_stat * (1 + self.n_dom), dtype=torch.float64, device=dev)
         self.stats = self.stats_all[:n_stat]
         self.stats_dom = self.stats_all[n_stat:].view(self.n_dom, n_stat) if self.n_dom else None
+        # X = 64, shared pots: the potentials launch also writes every shared row's expected features (the gradient's gather
+        # table); only the private (plane-patched) rows still go through mlbp_unary_expectations_f64
+        self._expect_in_potentials = False
+        if X == 64 and topo.U and self.F_ee == 3 and self.F_ed == 6:
+            fb._derive_unary_rows()
+            if getattr(fb, '_row_kind', None) is not None and fb._row_kind is not False:
+                self._expect_in_potentials = True
+                fb._uexp_rows_done = self.n_shared_rows
 
     def _plan_patches(self, planes, unary_kind, obs, labels):
         """Host-side integer work: which (instance, en_de factor) pairs see a plane cell in their
@@ -190,14 +199,19 @@ class UserGraphTrainer:
         t_ee = self.theta_dom_en_en if self.n_dom else self.theta_en_en
         t_ed = self.theta_dom_en_de if self.n_dom else self.theta_en_de
         ut, pt = self.unary_tables, self.pair_tables
+        # ... and, X = 64, every shared row's expected features (what the gradient gathers per unary factor,
+        # mlbp_unary_expectations_f64) out of the same launch: a row of pot^T IS a unary factor's table
+        ue = fb._uexp if self._expect_in_potentials else None
         jobs = (_ffi.PotentialsJob * 3)()
-        for j, (phi, th, F, cols, pot, pot_t) in enumerate((
-                (fb.phi_en_en, t_ee, self.F_ee, X, pt[0].data_ptr(), ut[0:X].data_ptr()),
-                (fb.phi_en_en_w1, t_ee, self.F_ee, X, pt[1].data_ptr(), ut[X:2 * X].data_ptr()),
-                (fb.phi_en_de, t_ed, self.F_ed, self.Vde, None, ut[2 * X:].data_ptr()))):
+        for j, (phi, th, F, cols, pot, pot_t, row0) in enumerate((
+                (fb.phi_en_en, t_ee, self.F_ee, X, pt[0].data_ptr(), ut[0:X].data_ptr(), 0),
+                (fb.phi_en_en_w1, t_ee, self.F_ee, X, pt[1].data_ptr(), ut[X:2 * X].data_ptr(), X),
+                (fb.phi_en_de, t_ed, self.F_ed, self.Vde, None, ut[2 * X:].data_ptr(), 2 * X))):
             jobs[j].phi, jobs[j].theta, jobs[j].pot, jobs[j].pot_t = phi.data_ptr(), th.data_ptr(), pot, pot_t
             jobs[j].theta_stride, jobs[j].pot_stride, jobs[j].pot_t_stride = F, 2 * X * X, self.rows_per_dom * X
             jobs[j].rows, jobs[j].cols, jobs[j].F = X, cols, F
+            if ue is not None:
+                jobs[j].expect, jobs[j].expect_stride = ue[row0:].data_ptr(), self.rows_per_dom * 8
         _ffi.check(_ffi.lib.mlbp_potentials_multi_f64(jobs, 3, nd, st))
         self._patch_tables()
 
@@ -387,7 +401,7 @@ class TiDirTrainer:
     def __init__(self, ti_path, en_vocab, de_vocab, phi_pmi, phi_pmi_w1, phi_ed, phi_ped, device='cuda:0', sweeps=3,
                  rank=0, world=1, use_planes=True, adapt=None, domains=None, reg_param_ua_scale=1.0,
                  use_correct_feat=True, history=True, session_history=True, grouped_sweeps='auto', skip_unchanged=False,
-                 minibatch=None, shuffle_seed=None, load_params=None):
+                 minibatch=None, shuffle_seed=None, load_params=None, share_params_with=None):
         """use_planes switches the three per-instance feature planes on as a whole; use_correct_feat / history /
         session_history gate them one by one as the reference's options of the same names do (train_mp.py:178, 192,
         206: the 'correct', 'full_history' and 'hit_history' planes).
@@ -401,8 +415,13 @@ class TiDirTrainer:
         load_params: a params file (tidir.save_params / the reference's save_params) to start from instead of zeros
         (--load_params, train_mp.py:528-542: the adapt mode's extension is tried first, then the bare name).
         skip_unchanged: the sweeps drop updates that would recompute a message from unchanged inputs (include/mlbp.h
-        MLBP_SWEEP_SKIP_UNCHANGED; equal to the full schedule to rounding, off by default like the C ABI)."""
+        MLBP_SWEEP_SKIP_UNCHANGED; equal to the full schedule to rounding, off by default like the C ABI).
+        share_params_with: another TiDirTrainer whose theta tensors (global and per-domain) this one READS instead of owning
+        its own -- the tune-set evaluator of train(tune=...), train_mp.py:657-684: same vocabularies, features and adapt mode."""
         from . import tidir
+        self._files = dict(en_vocab=en_vocab, de_vocab=de_vocab, phi_pmi=phi_pmi, phi_pmi_w1=phi_pmi_w1, phi_ed=phi_ed, phi_ped=phi_ped)
+        self._options = dict(sweeps=sweeps, use_planes=use_planes, reg_param_ua_scale=reg_param_ua_scale, use_correct_feat=use_correct_feat,
+                             history=history, session_history=session_history, grouped_sweeps=grouped_sweeps, skip_unchanged=skip_unchanged)
         if adapt not in (None, 'user', 'experience'):
             raise ValueError("adapt is None, 'user' or 'experience'")
         self.adapt, self.reg_param_ua_scale = adapt, float(reg_param_ua_scale)
@@ -427,6 +446,13 @@ class TiDirTrainer:
             self.domains = [str(d) for d in domains]
             self.theta_dom_en_en = torch.zeros(len(self.domains), len(tidir.EE_NAMES), dtype=torch.float64, device=dev)  # train_mp.py:524-527
             self.theta_dom_en_de = torch.zeros(len(self.domains), len(tidir.ED_NAMES), dtype=torch.float64, device=dev)
+        if share_params_with is not None:
+            o = share_params_with
+            if o.adapt != adapt or (adapt and list(o.domains) != list(self.domains)):
+                raise ValueError('share_params_with: the other trainer has another adapt mode or domain list')
+            self.theta_en_en, self.theta_en_de = o.theta_en_en, o.theta_en_de
+            if adapt:
+                self.theta_dom_en_en, self.theta_dom_en_de = o.theta_dom_en_en, o.theta_dom_en_de
         if load_params:
             self.load_params(load_params)
         self.minibatch = None if minibatch is None else max(1, int(minibatch))
@@ -538,10 +564,20 @@ class TiDirTrainer:
             lp_sum += lp; n_sum += n
         return lp_sum / max(n_sum, 1.0)
 
-    def train(self, epochs=3, reg_param=0.2, save_params=None, capture=True):
+    def tune_evaluator(self, tune_path):
+        """A second trainer over the instances of `tune_path` (--tune, train_mp.py:463, 571-580) that reads THIS trainer's thetas:
+        its predict() is the per-epoch tune evaluation of train_mp.py:657-684."""
+        return TiDirTrainer(tune_path, self._files['en_vocab'], self._files['de_vocab'], self._files['phi_pmi'], self._files['phi_pmi_w1'],
+                            self._files['phi_ed'], self._files['phi_ped'], device=self.device, rank=self.rank, world=self.world,
+                            adapt=self.adapt, domains=self.domains if self.adapt else None, share_params_with=self, **self._options)
+
+    def train(self, epochs=3, reg_param=0.2, save_params=None, capture=True, tune=None):
         """lr = 0.1 / (1 + 0.3 epoch) (train_mp.py:627-630); regularisation reg_param / N (train_mp.py:160);
         params saved as <save_params><ext>.iter<epoch> and <save_params><ext> with ext = '.user_adapt' / '.exp_adapt' /
         '' by adapt mode (train_mp.py:654-656, 688-690).
+        tune: a TI file (or a tune_evaluator()) evaluated after EVERY epoch under the thetas that epoch left (train_mp.py:657-684:
+        `batch_predictions` over --tune, then the mean log-posterior and precision at 0 / 25 / 50); the per-epoch results --
+        (mean log-posterior, (p@0, p@25, p@50, total)) -- are kept in self.tune_history.
         capture: whole-file epochs (minibatch=None) replay one HIP graph of the step's launches (capture(): same bits as the
         eager launches, 7 % less time per step at 8192 instances) when there are at least three of them."""
         from . import tidir
@@ -550,11 +586,15 @@ class TiDirTrainer:
         if save_params:
             save_params = save_params + {'user': '.user_adapt', 'experience': '.exp_adapt', None: ''}[self.adapt]
         history = []
+        tuner = self.tune_evaluator(tune) if isinstance(tune, str) else tune
+        self.tune_history = []
         for epoch in range(epochs):
             history.append(self.epoch(0.1 / (1.0 + 0.3 * epoch), float(reg_param) / float(self.n_total)))
             if save_params and self.rank == 0:
                 tidir.save_params('%s.iter%d' % (save_params, epoch), self.theta_en_en.cpu().numpy().reshape(1, -1),
                                   self.theta_en_de.cpu().numpy().reshape(1, -1), d2t=self.domain_thetas())
+            if tuner is not None:
+                self.tune_history.append(tuner.predict())
         if save_params and self.rank == 0:
             tidir.save_params(save_params, self.theta_en_en.cpu().numpy().reshape(1, -1),
                               self.theta_en_de.cpu().numpy().reshape(1, -1), d2t=self.domain_thetas())
@@ -563,20 +603,24 @@ class TiDirTrainer:
     # ---- prediction pass (train_mp.py:310-343, 692-770) -------------------------------------------
     def predict(self, save_predictions=None):
         """-> (mean log-posterior, (p@0, p@25, p@50, total)) over ALL ranks' instances (train_mp.py:666-684: sums reduced once).
-        save_predictions: every rank writes its shard's '*SENT_ID:' blocks to '<path><ext>' and '.dist' lines to
-        '<path><ext>.dist' ('.rank<r>' appended when there are several ranks), one block per instance in file order, exactly
-        the text `batch_predictions` returns (train_mp.py:337-338, 752-757) -- formed from the batched top-50 indices and
-        log-marginals, no per-instance graph."""
+        save_predictions: the '*SENT_ID:' blocks go to '<path><ext>' and the '.dist' lines to '<path><ext>.dist', one block per
+        instance in file order, exactly the text `batch_predictions` returns (train_mp.py:337-338, 752-757) -- formed from the
+        batched top-50 indices and log-marginals, no per-instance graph.  With several ranks every rank writes its shard
+        ('.rank<r>') and rank 0 joins the shards into the ONE pair of files the reference writes (train_mp.py:740-760)."""
         from . import tidir
-        lp, counts, n = 0.0, np.zeros(4, dtype=np.int64), 0
+        lp, counts = 0.0, np.zeros(4, dtype=np.int64)
         blocks = {}
         for key, tr in self.trainers.items():
             l, idx, logs, c, logm, label_logs = tr.predict(top=min(50, tr.batch.X), with_logs=True)
-            lp += float(l.sum()); counts += np.array(c); n += len(l)
+            lp += float(l.sum()); counts += np.array(c)
             if save_predictions:
                 rows = self.buckets[key]['rows']
                 for b, row in enumerate(rows):
                     blocks[row['index']] = tidir.prediction_text(row, list(key[1]), self.en, idx[b], logs[b], label_logs[b], logm[b])
+        # the mean's denominator is every instance of the shard -- `/ float(len(testing_instances))`, train_mp.py:684, 764 -- also
+        # the ones without a predicted word, which build no graph here (the reference's workers fail on them and the pool drops
+        # the task silently, train_mp.py:666-680; LBP.py:193-194)
+        n = self._shard[1] - self._shard[0]
         if save_predictions:
             import codecs
             ext = {'user': '.user_adapt', 'experience': '.exp_adapt', None: ''}[self.adapt]
@@ -588,4 +632,19 @@ class TiDirTrainer:
         tot = torch.tensor([lp, float(n)] + [float(v) for v in counts], dtype=torch.float64, device=self.device)
         mdist.all_reduce_sum_(tot)
         tot = tot.cpu().numpy()
+        if save_predictions and self.world > 1:
+            # ONE '<path><ext>' and one '.dist' in instance order, as the reference writes them (train_mp.py:740-760) and eval.py /
+            # get_acc.py read them: the shards are contiguous, so rank order is instance order.  (The all-reduce above is the
+            # barrier: every rank has closed its files.)
+            import shutil
+            ext = {'user': '.user_adapt', 'experience': '.exp_adapt', None: ''}[self.adapt]
+            if self.rank == 0:
+                for suffix in ('', '.dist'):
+                    with open(save_predictions + ext + suffix, 'wb') as out:
+                        for r in range(self.world):
+                            part = '%s%s%s.rank%d' % (save_predictions, ext, suffix, r)
+                            with open(part, 'rb') as f:
+                                shutil.copyfileobj(f, out)
+                            os.remove(part)
+            mdist.barrier()
         return float(tot[0] / max(tot[1], 1.0)), tuple(int(v) for v in tot[2:])

@@ -136,19 +136,23 @@ def _oracle_step(spec, inputs, labels, obs, roots, lr, reg):
     return tot_ee, tot_ed, lp
 
 
-@pytest.mark.parametrize('planes', ['random', 'reference'])
+@pytest.mark.parametrize('planes', ['random', 'reference', 'k4'])
 @pytest.mark.parametrize('B', [6, 53])
 def test_shared_table_sweep_runs_the_gradient_as_its_epilogue(B, planes):
     """Shared pots, K3 user graphs: the gradient of sweep(gradient=...) comes out of the shared-table sweep kernel itself (the
     final variable->factor messages of the workgroup's 16 graphs against T (.) phi_k on the matrix cores, the unary part by
     gather in the launch in front of it) -- the separate gradient launch's values to rounding, the oracle's values, and a graph
     the matrix-core kernel hands to the exact kernel (a zero table column) gets its gradient there.  planes = 'reference': the
-    zero plane and the bias plane of the reference's tensors, which the epilogue recognises and does not contract."""
+    zero plane and the bias plane of the reference's tensors, which the epilogue recognises and does not contract.
+    'k4': four predicted words (train_mp.py:272-282 builds the complete graph over them: 6 pairwise factors, three-source
+    variable updates, 13 of 21 message tiles spilled) -- the same epilogue in the kernel's general instance; a flagged graph
+    gets its gradient from the per-graph kernel run on the flagged graphs only."""
     import copy
     from macaronicusermodeling_amd import _ffi
     from macaronicusermodeling_amd.train import UserGraphTrainer
     from macaronicusermodeling_amd.topology import GraphTopology
-    spec = C.user_spec(10, [1, 4, 7] if planes == 'random' else [1, 2, 7], 64, 48, seed=1)     # ('reference': both pots in use)
+    pred = {'random': [1, 4, 7], 'reference': [1, 2, 7], 'k4': [1, 2, 5, 8]}[planes]
+    spec = C.user_spec(10, pred, 64, 48, seed=1)     # ('reference', 'k4': both pots in use)
     topo = GraphTopology.from_spec(spec)
     inputs = C.make_inputs(spec, 77)
     if planes == 'reference':
@@ -187,6 +191,7 @@ def test_shared_table_sweep_runs_the_gradient_as_its_epilogue(B, planes):
     row = int(fb.unary_tab[B // 2, 0])
     saved = tr.unary_tables[row].clone()
     tr.unary_tables[row] = 0.0
+    fb._uexp_rows_done = 0          # (the table changes behind the trainer's back: the rows' expected features come from the tables again, not from the potentials launch)
     k_ee, k_ed = torch.full_like(g_ee, float('nan')), torch.full_like(g_ed, float('nan'))
     fb.sweep(roots, init=True, marginals=tr._marg, gradient=(k_ee, k_ed), keep_messages=False)
     n_redone = fb.program(roots).exact_count(B)
@@ -498,10 +503,11 @@ def test_tidir_trainer_sweeps_all_sentence_shapes_in_one_launch(tmp_path):
     np.testing.assert_allclose(a.theta_en_de.cpu().numpy(), b.theta_en_de.cpu().numpy(), rtol=1e-8, atol=1e-12)
 
 
-def test_tidir_trainer_groups_with_larger_cliques_fall_back_group_by_group(tmp_path):
-    """Sentences with up to four predicted words: the K4 buckets (six pairwise factors: separate gradient launches, spilled
-    tiles) cannot share a launch with the K2 / K3 buckets that carry the gradient as their sweep kernel's epilogue --
-    mlbp_sweep_groups_f64 then runs group by group.  Same statistics and the same training as per-bucket launches."""
+def test_tidir_trainer_groups_with_larger_cliques_share_the_launch(tmp_path):
+    """Sentences with up to four predicted words: the K4 buckets (six pairwise factors, three-source updates, spilled tiles) share
+    ONE prepare + ONE sweep launch with the K2 / K3 buckets, gradient epilogue included -- the kernel's general instance takes
+    every group (round 3 ran such a mix group by group: no instance carried the epilogue with spilled tiles).  Same statistics
+    and the same training as per-bucket launches."""
     from macaronicusermodeling_amd import tidir
     from macaronicusermodeling_amd.train import TiDirTrainer
     paths = tidir.synthesize(str(tmp_path), n_instances=36, X=64, Vde=64, sent_len=(5, 8), n_predicted=(2, 4), seed=33)
@@ -512,7 +518,10 @@ def test_tidir_trainer_groups_with_larger_cliques_fall_back_group_by_group(tmp_p
     for t in (a, b):
         t.theta_en_en += torch.tensor([0.3, -0.2, 0.1], dtype=torch.float64, device=t.theta_en_en.device)
         t.theta_en_de += torch.tensor([0.2, 0.1, -0.3, 0.05, 0.0, 0.1], dtype=torch.float64, device=t.theta_en_de.device)
-    np.testing.assert_allclose(a.local_statistics().cpu().numpy(), b.local_statistics().cpu().numpy(), rtol=1e-9, atol=1e-12)
+    from macaronicusermodeling_amd import _ffi
+    sa = a.local_statistics().cpu().numpy()
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 3 and _ffi.lib.mlbp_last_sweep_fused_gradient() == 1
+    np.testing.assert_allclose(sa, b.local_statistics().cpu().numpy(), rtol=1e-9, atol=1e-12)
     ha, hb = a.train(epochs=3, reg_param=0.2), b.train(epochs=3, reg_param=0.2)       # (three epochs: replayed from a HIP graph)
     np.testing.assert_allclose(ha, hb, rtol=1e-9)
     np.testing.assert_allclose(a.theta_en_de.cpu().numpy(), b.theta_en_de.cpu().numpy(), rtol=1e-8, atol=1e-12)
@@ -1007,3 +1016,86 @@ def test_two_rank_trainer_epoch_equals_one_process_and_the_reference(tmp_path):
     lp1, c1 = one.predict()
     assert c1 == res[0][8]
     np.testing.assert_allclose(res[0][7], lp1, rtol=1e-11)
+
+
+def _rank_worker_predict(rank, world, port, paths, gold_path, out, q):
+    """One fresh rank process: the prediction pass with --save_predictions, thetas of tidir_batch_reference.json."""
+    import json
+    import os
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    import torch as th
+    from macaronicusermodeling_amd import dist as mdist
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    r, w, _ = mdist.init_from_env(backend='gloo')
+    th.cuda.set_device(0)
+    gold = json.load(open(gold_path, encoding='utf8'))
+    tt = TiDirTrainer(paths['ti'], paths['vocab.en'], paths['vocab.de'], paths['phi.pmi'], paths['phi.pmi_w1'], paths['phi.ed'],
+                      paths['phi.ped'], sweeps=3, rank=r, world=w)
+    tt.theta_en_en.copy_(th.tensor(gold['theta_en_en'], dtype=th.float64).reshape(-1))
+    tt.theta_en_de.copy_(th.tensor(gold['theta_en_de'], dtype=th.float64).reshape(-1))
+    q.put((rank,) + tuple(tt.predict(save_predictions=out)))
+    th.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_write_one_prediction_file_in_instance_order(tmp_path):
+    """train_mp.py:740-760 writes ONE '<save_predictions><ext>' and one '.dist', in instance order, and eval.py:32-60 /
+    get_acc.py:27-46 read exactly those.  Two rank processes each write their shard; rank 0 joins the shards (contiguous, so rank
+    order is instance order) and removes them.  The joined files equal the reference's text for the 12 golden instances
+    character for character, and both ranks return the all-instance mean and counts."""
+    import os
+    import socket
+    import torch.multiprocessing as mp
+    gold = _batch_gold()
+    gold_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tidir_batch_reference.json')
+    paths = _write_tidir(gold, str(tmp_path))
+    out = str(tmp_path / 'pred')
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker_predict, args=(r, 2, port, paths, gold_path, out, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = gold['predictions']
+    assert open(out, encoding='utf8').read() == ''.join(p['block'] + '\n' for p in want)
+    assert open(out + '.dist', encoding='utf8').read() == ''.join(p['dist'] + '\n' for p in want)
+    assert not [f for f in os.listdir(str(tmp_path)) if '.rank' in f]           # the shards are gone
+    for r in res:
+        assert r[2] == tuple(int(sum(p['precision'][k] for p in want)) for k in range(4))
+        np.testing.assert_allclose(r[1], np.mean([p['log_posterior'] for p in want]), rtol=1e-9)
+
+
+def test_tune_set_is_evaluated_after_every_epoch(tmp_path):
+    """train_mp.py:657-684: after every epoch `batch_predictions` runs over the --tune instances under the thetas the epoch
+    left, and the mean log-posterior and precision at 0 / 25 / 50 are reported.  TiDirTrainer.train(tune=path) keeps them in
+    tune_history; here the tune file is the 12-instance golden TI_DIR itself, so that -- started from the golden thetas with a
+    zero learning-rate schedule replaced by one real epoch -- (i) the evaluation BEFORE any update equals the reference's
+    batch_predictions totals (tidir_batch_reference.json) and (ii) every epoch's entry equals what a fresh trainer loaded with
+    that epoch's saved params file predicts."""
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    gold = _batch_gold()
+    paths = _write_tidir(gold, str(tmp_path))
+    want = gold['predictions']
+    tt = _trainer(paths, gold)
+    tuner = tt.tune_evaluator(paths['ti'])
+    assert tuner.theta_en_en is tt.theta_en_en and tuner.theta_en_de is tt.theta_en_de          # reads the trainer's tensors
+    lp0, c0 = tuner.predict()
+    assert c0 == tuple(int(sum(p['precision'][k] for p in want)) for k in range(4))
+    np.testing.assert_allclose(lp0, np.mean([p['log_posterior'] for p in want]), rtol=1e-9)
+    save = str(tmp_path / 'params')
+    hist = tt.train(epochs=2, reg_param=0.2, save_params=save, tune=tuner, capture=False)
+    assert len(hist) == 2 and len(tt.tune_history) == 2 and tt.tune_history[0] != tt.tune_history[1]
+    for epoch in range(2):
+        fresh = TiDirTrainer(paths['ti'], paths['vocab.en'], paths['vocab.de'], paths['phi.pmi'], paths['phi.pmi_w1'], paths['phi.ed'],
+                             paths['phi.ped'], sweeps=3, load_params='%s.iter%d' % (save, epoch))
+        lp, c = fresh.predict()
+        assert c == tt.tune_history[epoch][1]
+        np.testing.assert_allclose(tt.tune_history[epoch][0], lp, rtol=1e-4)           # (the params file keeps six decimals)
+    # a tune FILE is accepted as well
+    t2 = _trainer(paths, gold)
+    t2.train(epochs=1, reg_param=0.2, tune=paths['ti'], capture=False)
+    np.testing.assert_allclose(t2.tune_history[0][0], tt.tune_history[0][0], rtol=1e-9)

@@ -28,15 +28,29 @@ import bench  # noqa: E402
 from macaronicusermodeling_amd.batch import FactorGraphBatch  # noqa: E402
 from macaronicusermodeling_amd.topology import GraphTopology  # noqa: E402
 
-workload = sys.argv[1] if len(sys.argv) > 1 else 'user_k3'
+GRAD = '--gradient' in sys.argv          # the sweep call carries the gradient (lean kernel's GRAD instance): stamp 9 then closes the epilogue
+argv = [a for a in sys.argv[1:] if not a.startswith('--')]
+workload = argv[0] if argv else 'user_k3'
 spec, roots, sweeps, seed = bench.workload_spec(workload)
-X, B = spec['X'], int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+X, B = spec['X'], int(argv[1]) if len(argv) > 1 else 8192
 topo = GraphTopology.from_spec(spec)
 dev = torch.device('cuda:0')
 fb = FactorGraphBatch(topo, X, B, device=dev)
 fb.set_pair_tables(torch.rand(B * topo.P, X, X, dtype=torch.float64, device=dev) + 0.01)
 fb.set_unary_tables(torch.rand(B * topo.U, X, dtype=torch.float64, device=dev) + 0.01)
 marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)
+grad = None
+if GRAD:
+    by_id = {f['id']: f for f in spec['factors']}
+    pair_phi = [0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1 for j in topo.pair_factors]
+    ukind = [2 if by_id[topo.factor_ids[j]]['factor_type'] == 'en_de' else (0 if by_id[topo.factor_ids[j]]['gap'] > 1 else 1) for j in topo.unary_factors]
+    rs = np.random.RandomState(5)
+    fb.set_features(rs.rand(X, X, 3), rs.rand(X, X, 3), rs.rand(X, spec['Vde'], 6), pair_phi, ukind)
+    labels = np.tile(np.array([dict(zip(spec['var_ids'], spec['labels']))[v] for v in topo.var_ids]), (B, 1))
+    fb.set_observations(labels, np.stack([rs.randint(0, spec['Vde'] if k == 2 else X, size=B) for k in ukind], axis=1))
+    grad = (torch.empty(B, 3, dtype=torch.float64, device=dev), torch.empty(B, 6, dtype=torch.float64, device=dev))
+_sweep = fb.sweep
+fb.sweep = lambda r, **kw: _sweep(r, gradient=grad, keep_messages=not GRAD, **kw)
 buf = torch.zeros((B // 64 + 1) * 12, dtype=torch.int64, device=dev)
 masks = [(0, 'full kernel'), (1, '- main loop'), (2, '- final normalisation'), (4, '- message write-back'), (8, '- marginals'),
          (16, '- table loads'), (32, '- unary loads'), (1 | 2, '- loop, final norm'), (1 | 2 | 4 | 8, '- everything but the loads and the prologue'),
@@ -62,7 +76,7 @@ torch.cuda.synchronize()
 raw = buf.cpu().numpy().reshape(-1, 12).astype(np.float64)
 raw = raw[raw[:, 0] > 0]
 names = ['issue loads (unary rows, tables, image), init LDS', 'unary normalisation + sync', 'constant products + sync', 'wait for tables',
-         'main loop', 'read-out + final normalisation', 'sync + write-back issue', 'marginals issue', 'drain stores']
+         'main loop', 'read-out + final normalisation', 'sync + write-back issue', 'marginals issue', 'gradient epilogue + drain stores' if GRAD else 'drain stores']
 d = np.diff(raw[:, :10], axis=1)
 life = raw[:, 9] - raw[:, 0]
 print('B = %d: wave-0 lifetime: mean %.0f cycles (min %.0f, max %.0f) over %d sampled workgroups' % (B, life.mean(), life.min(), life.max(), len(life)))

@@ -21,7 +21,8 @@ def timed(fn, n=10):
     return s.elapsed_time(e) / n
 
 B, X = 8192, 64
-spec = C.user_spec(10, [1, 4, 7], X, 64, seed=1)
+# --k4: four predicted words (six pairwise factors, the shared-table kernel's general instance: spilled tiles, three-source updates)
+spec = C.user_spec(10, [1, 3, 5, 8], X, 64, seed=2) if '--k4' in sys.argv else C.user_spec(10, [1, 4, 7], X, 64, seed=1)
 topo = GraphTopology.from_spec(spec)
 inputs = C.make_inputs(spec, 5)
 if '--random-planes' not in sys.argv:        # the reference's tensors: [pmi, 0, 1] and [pmi, pmi_w1, 1] (train_mp.py:600-606)
@@ -41,6 +42,8 @@ tr._graph = None
 print('   potentials %.3f  sweep+marginals %.3f  gradient %.3f' % (
     timed(tr.build_potentials), timed(lambda: tr.batch.sweep(tr.roots, init=True, marginals=tr._marg)),
     timed(lambda: tr.batch.gradient(tr._g_ee, tr._g_ed))))
+if '--k4' in sys.argv:
+    sys.exit(0)
 # unique tables
 dev = torch.device('cuda:0')
 fb = FactorGraphBatch(topo, X, B, device=dev)

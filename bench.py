@@ -62,7 +62,7 @@ def workload_spec(name):
     import cases as C
     if name in ('user_k3', 'user_k3_shared', 'user_k3_trainlayout'):
         return C.user_spec(10, [1, 4, 7], 64, 64, seed=1), [1, 4, 7], 3, 1236
-    if name in ('user_k4', 'user_k4_shared'):     # four predicted words: K4 = 6 pairwise + 28 unary factors
+    if name in ('user_k4', 'user_k4_shared', 'user_k4_trainlayout'):     # four predicted words: K4 = 6 pairwise + 28 unary factors
         return C.user_spec(10, [1, 3, 5, 8], 64, 64, seed=2), [1, 3, 5], 3, 1237
     if name == 'chain8':
         return C.chain_spec(8, 64), [0] * 10, 10, 1235
@@ -148,6 +148,117 @@ def self_launch(a, argv):
         print(line)
     if proc.returncode != 0 or line is None:
         raise SystemExit(proc.returncode or 1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The outer loop's workload (secondary figures, never `value`): a synthetic TI_DIR of 8192 instances, sentences of eight words
+# with three predicted ones at any positions = 56 sentence shapes (all K3 over the two shared pots), train_mp.py:560-690's epoch.
+# ---------------------------------------------------------------------------------------------------
+TRAIN_EPOCH_TIDIR = dict(n_instances=8192, X=64, Vde=64, sent_len=(8, 8), n_predicted=(3, 3), seed=11)
+
+
+def _cpu_epoch_worker(args):
+    """The reference's per-instance cost model (batch_sgd, train_mp.py:362-402) by the oracle: graph of the instance,
+    initialize, treelike_inference(3), return_gradient, get_posterior_probs -- one instance after the other."""
+    specs, rows, inputs = args
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    import copy
+    from oracle import lbp_oracle as O
+    n = 0
+    for spec, labels, obs in rows:
+        s = copy.deepcopy(specs[spec])
+        g0 = O.Graph(s)
+        s['labels'] = [int(labels[g0.var_order.index(v)]) for v in s['var_ids']]
+        unary_ids = [f['id'] for f in g0.factors if len(f['vars']) == 1]
+        for f in s['factors']:
+            if len(f['vars']) == 1:
+                f['observed_dim'] = int(obs[unary_ids.index(f['id'])])
+        g = O.Graph(s)
+        msgs = O.init_messages(g)
+        roots = [s['var_ids'][i % len(s['var_ids'])] for i in range(3)]
+        O.treelike_inference(g, inputs, msgs, 3, roots, O.has_loops(g, roots[0]))
+        O.return_gradient(g, inputs, msgs, 0.2 / 8192.0, 0.1)
+        O.log_posterior(g, msgs)
+        n += 1
+    return n
+
+
+def cpu_train_epoch(directory, per_worker=512):
+    """instances/s of the per-instance cost model on the host cores, on a bounded sample of the synthetic TI_DIR."""
+    import multiprocessing as mp
+    import numpy as np
+    from macaronicusermodeling_amd import tidir
+    paths = tidir.synthesize(directory, **TRAIN_EPOCH_TIDIR)
+    en, de = tidir.read_vocab(paths['end']), tidir.read_vocab(paths['ded'])
+    phi_ee, phi_w1, phi_ed = tidir.load_features(paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'], paths['phi_ped'])
+    X = len(en)
+    th_ee, th_ed = np.zeros((1, 3)), np.zeros((1, 6))              # the first epoch's thetas (train_mp.py:519-523)
+    inputs = dict(phi_en_en=phi_ee, phi_en_en_w1=phi_w1, phi_en_de=phi_ed, theta_en_en=th_ee, theta_en_de=th_ed,
+                  pot_en_en=np.exp(phi_ee.dot(th_ee.T).reshape(X, X)), pot_en_en_w1=np.exp(phi_w1.dot(th_ee.T).reshape(X, X)),
+                  pot_en_de=np.exp(phi_ed.dot(th_ed.T).reshape(X, -1)))
+    buckets = tidir.bucket_instances(tidir.read_instances(paths['ti']), en, de)
+    specs = {str(k): b['spec'] for k, b in buckets.items()}
+    flat = [(str(k), b['var_labels'][i], b['unary_obs'][i]) for k, b in buckets.items() for i in range(len(b['rows']))]
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))
+    jobs = [(specs, flat[w * per_worker:(w + 1) * per_worker], inputs) for w in range(cores)]
+    with mp.get_context('fork').Pool(cores) as pool:
+        pool.map(_cpu_epoch_worker, [(specs, flat[:2], inputs)] * cores)      # imports and caches
+        t0 = time.perf_counter()
+        done = sum(pool.map(_cpu_epoch_worker, jobs))
+        wall = time.perf_counter() - t0
+    return paths, {'instances_per_s': done / wall, 'cores': cores, 'kind': 'port',
+                   'sample': '%d instances of the same TI_DIR through the oracle\'s per-instance step (graph, initialize, 3 sweeps, '
+                             'return_gradient, posterior: batch_sgd, train_mp.py:362-402), one process per core, %.1f s wall' % (done, wall)}
+
+
+def gpu_train_epoch(paths, dev):
+    """instances/s of TiDirTrainer.epoch on the synthetic TI_DIR: the whole file per update, and minibatches of 256 and 16 (the
+    reference updates once per instance, train_mp.py:631-649) in the trainer's default ('masked') minibatch form, every step a
+    HIP-graph replay."""
+    import torch
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    t0 = time.perf_counter()
+    tt = TiDirTrainer(paths['ti'], paths['end'], paths['ded'], paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'], paths['phi_ped'],
+                      device=dev, sweeps=3, minibatch=256, shuffle_seed=5)
+    build_s = time.perf_counter() - t0
+    # learning rate: the synthetic features are random, and a summed step of 8192 instances at the reference's 0.1 sends theta
+    # (and with it every potential) out of range within two updates -- the run would time the degenerate-graph path.  1e-6 keeps
+    # the optimisation in the regime a real run is in; the launches are the same.
+    lr = 1e-6
+    out = {'instances': tt.n_total, 'sentence_shapes': len(tt.trainers), 'trainer_build_s': build_s,
+           'contents': 'TiDirTrainer.epoch: potentials, 3 sweeps, gradient, posterior, reduction, theta update (train_mp.py:626-656); '
+                       'learning rate %g, reg 0.2 / N; every step one HIP-graph replay over the resident shard' % lr}
+    reg = 0.2 / tt.n_total
+    tt.capture_masked()
+    for mb, epochs in ((256, 3), (16, 1)):
+        tt.minibatch = mb
+        tt.epoch(lr, reg)                       # (warm: allocator, first-use paths)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for e in range(epochs):
+            tt.epoch(lr, reg)
+        torch.cuda.synchronize(dev)
+        el = (time.perf_counter() - t0) / epochs
+        out['minibatch_%d' % mb] = {'instances_per_s': tt.n_total / el, 'ms_per_epoch': el * 1e3,
+                                    'ms_per_update': el * 1e3 / ((tt.n_total + mb - 1) // mb), 'updates_per_epoch': (tt.n_total + mb - 1) // mb}
+    tt.minibatch = None
+    tt.capture()
+    tt.epoch(lr, reg)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for e in range(5):
+        tt.epoch(lr, reg)
+    torch.cuda.synchronize(dev)
+    el = (time.perf_counter() - t0) / 5
+    out['whole_file'] = {'instances_per_s': tt.n_total / el, 'ms_per_epoch': el * 1e3, 'updates_per_epoch': 1}
+    out['graphs_redone_by_the_exact_kernel_in_the_last_step'] = int(sum(tr.batch.program(tr.roots[:tr.n_sweeps_run]).exact_count(tr.batch.B)
+                                                                       for tr in tt.trainers.values()))
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -249,7 +360,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'user_k3_trainlayout', 'user_k4', 'user_k4_shared', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared', 'ring8_x512_shared_f32', 'ring8_x1000', 'ring8_x1000_shared', 'ring8_x2048_shared'],
+    ap.add_argument('--workload', default='user_k3', choices=['user_k3', 'user_k3_shared', 'user_k3_trainlayout', 'user_k4', 'user_k4_shared', 'user_k4_trainlayout', 'chain8', 'ring8', 'ring8_x512', 'ring8_x512_f32', 'ring8_x512_shared', 'ring8_x512_shared_f32', 'ring8_x1000', 'ring8_x1000_shared', 'ring8_x2048_shared'],
                     help='user_k3_shared = the same graphs with the reference\'s table layout: all graphs share the two '
                          'en_en pots (MFMA kernel, reported against the f64 matrix peak)')
     ap.add_argument('--no-writeback', action='store_true', help='shared workload: skip the message write-back (read-out only)')
@@ -258,6 +369,7 @@ def main():
     ap.add_argument('--no-skip-unchanged', action='store_true', help='leave out the secondary measurements -- MLBP_SWEEP_SKIP_UNCHANGED and the train step (profiling runs: only the full schedule of the sweep call is launched)')
     ap.add_argument('--sweeps', type=int, default=None, help='override sweeps per step (roots cycle)')
     ap.add_argument('--variant', type=int, default=None, help='mlbp_set_sweep_variant (A/B measurement)')
+    ap.add_argument('--no-train-epoch', action='store_true', help='leave out the train_epoch figures (the outer loop on a synthetic TI_DIR)')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per sweep launch from a rocprofv3 --pmc pass (profiles/), if known')
     a = ap.parse_args()
@@ -273,6 +385,15 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.workload, 8192)            # before the GPU is touched (fork safety)
+    epoch_paths = epoch_cpu = epoch_dir = None
+    if rank == 0 and world == 1 and not a.no_train_epoch and not a.no_skip_unchanged and a.workload == 'user_k3':
+        import tempfile
+        epoch_dir = tempfile.mkdtemp(prefix='mlbp_bench_tidir_')
+        if a.no_cpu_baseline:
+            from macaronicusermodeling_amd import tidir as _tidir
+            epoch_paths = _tidir.synthesize(epoch_dir, **TRAIN_EPOCH_TIDIR)
+        else:
+            epoch_paths, epoch_cpu = cpu_train_epoch(epoch_dir)          # (also before the GPU is touched)
 
     import numpy as np
     import torch
@@ -604,6 +725,12 @@ def main():
             'train_step': train,
             'stall_attribution': stalls,
         }
+        if epoch_paths is not None:
+            te = gpu_train_epoch(epoch_paths, dev)
+            te['cpu_per_instance_cost_model'] = epoch_cpu
+            out['train_epoch'] = te
+            import shutil
+            shutil.rmtree(epoch_dir, ignore_errors=True)
         if cpu is not None:
             out['parity'] = parity_sample(spec, topo, roots, fb, marg)
         print(json.dumps(out))

@@ -237,20 +237,24 @@ class UserGraphTrainer:
             return self.stats_all if self.n_dom else self.stats
         return self._local_statistics_eager()
 
-    def _local_statistics_eager(self):
+    def _local_statistics_eager(self, select=None):
         fb = self.batch
         self.build_potentials()
         fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg, gradient=(self._g_ee, self._g_ed),
                  keep_messages=False)
-        return self._statistics_after_sweep()
+        return self._statistics_after_sweep(select=select)
 
-    def _statistics_after_sweep(self, gradient_from_messages=False):
+    def _statistics_after_sweep(self, gradient_from_messages=False, select=None):
         """Everything of the step behind the sweeps: gradient (when the sweep launch did not produce it: from the
-        messages in memory), the per-instance plane shares, log-posteriors, the batch sums."""
+        messages in memory), the per-instance plane shares, log-posteriors, the batch sums.
+        select: optional device bool [B] -- only THESE instances enter the sums (a minibatch of a resident shard: every instance
+        is evaluated, the statistics of the others are left out; TiDirTrainer's masked minibatches)."""
         fb = self.batch
         if gradient_from_messages:
             fb.gradient(self._g_ee, self._g_ed)
         self._patch_gradient()
+        if select is not None:
+            return self._selected_statistics(select)
         if not self.n_dom:          # [sum g_ee | sum g_ed | sum log-posterior | count]: log-posteriors and sums in one launch
             _ffi.check(_ffi.lib.mlbp_step_statistics_f64(self._g_ee.data_ptr(), self.F_ee, self._g_ed.data_ptr(), self.F_ed,
                                                          self._marg.data_ptr(), fb._labels.data_ptr(), self.topo.n_vars, fb.X, fb.B,
@@ -268,6 +272,35 @@ class UserGraphTrainer:
             _ffi.check(_ffi.lib.mlbp_segment_sum_rows_f64(r.data_ptr(), fb.B, r.shape[1], self._dom.data_ptr(), self.n_dom,
                                                           self.stats_dom.data_ptr(), _stream_ptr(self.device)))
             return self.stats_all
+        return self.stats
+
+    def _selected_statistics(self, select):
+        """The statistics buffer over the instances with select[b] set: per-instance rows [g_ee | g_ed | log-posterior | 1],
+        summed by segment -- the instance's domain when selected, a dump segment otherwise (mlbp_segment_sum_rows_f64, fixed
+        order)."""
+        fb = self.batch
+        st = _stream_ptr(self.device)
+        _ffi.check(_ffi.lib.mlbp_log_posterior_f64(self._marg.data_ptr(), fb._labels.data_ptr(), fb.B, self.topo.n_vars,
+                                                   fb.X, self._lp.data_ptr(), st))
+        r = self._rows
+        r[:, :self.F_ee] = self._g_ee
+        r[:, self.F_ee:self.F_ee + self.F_ed] = self._g_ed
+        r[:, -2] = self._lp
+        r[:, -1] = 1.0
+        nd = max(self.n_dom, 1)
+        if getattr(self, '_segsum', None) is None:
+            self._segsum = torch.zeros(nd + 1, r.shape[1], dtype=torch.float64, device=self.device)
+            self._seg = torch.empty(fb.B, dtype=torch.int32, device=self.device)
+            self._dump = torch.full((fb.B,), nd, dtype=torch.int32, device=self.device)
+            self._zero_seg = torch.zeros(fb.B, dtype=torch.int32, device=self.device)
+        torch.where(select, self._dom if self.n_dom else self._zero_seg, self._dump, out=self._seg)
+        _ffi.check(_ffi.lib.mlbp_segment_sum_rows_f64(r.data_ptr(), fb.B, r.shape[1], self._seg.data_ptr(), nd + 1,
+                                                      self._segsum.data_ptr(), st))
+        if self.n_dom:
+            self.stats_dom.copy_(self._segsum[:nd])
+            torch.sum(self._segsum[:nd], dim=0, out=self.stats)
+            return self.stats_all
+        self.stats.copy_(self._segsum[0])
         return self.stats
 
     def step(self, learning_rate, reg_param, reg_param_ua_scale=1.0):
@@ -364,20 +397,22 @@ class _BucketSet:
                                                   o.theta_en_en, o.theta_en_de, device=o.device, sweeps=o.sweeps, roots=roots,
                                                   planes=planes, skip_unchanged=o.skip_unchanged, **extra)
 
-    def statistics_into(self, stats, grouped_sweeps):
+    def statistics_into(self, stats, grouped_sweeps, select_of=None):
         """Adds the buckets' statistics to `stats`.  grouped_sweeps: the sweeps of ALL sentence shapes with pairwise factors
         in one launch sequence (batch.sweep_groups -> mlbp_sweep_groups_f64: every bucket its own topology and roots;
         the shared-table kernels take a group table) instead of one launch sequence per bucket; 'auto' groups whenever
-        two or more buckets qualify."""
+        two or more buckets qualify.  select_of: optional callable, bucket trainer -> device bool [B]: only the selected
+        instances enter the sums (masked minibatches)."""
         trs = list(self.trainers.values())
         if not trs:
             return
+        sel = (lambda tr: select_of(tr)) if select_of is not None else (lambda tr: None)
         together = [tr for tr in trs if tr.topo.P >= 1 and tr.batch.X == 64] if grouped_sweeps else []
         if len(together) < 2 and grouped_sweeps is not True:
             together = []
         for tr in trs:
             if not any(tr is t for t in together):
-                stats += tr.local_statistics()
+                stats += tr.local_statistics() if select_of is None else tr._local_statistics_eager(select=sel(tr))
         if not together:
             return
         from .batch import sweep_groups
@@ -387,7 +422,7 @@ class _BucketSet:
                      marginals=[tr._marg for tr in together], gradients=[(tr._g_ee, tr._g_ed) for tr in together],
                      keep_messages=False)
         for tr in together:
-            stats += tr._statistics_after_sweep()
+            stats += tr._statistics_after_sweep(select=sel(tr))
 
 
 class TiDirTrainer:
@@ -401,7 +436,7 @@ class TiDirTrainer:
     def __init__(self, ti_path, en_vocab, de_vocab, phi_pmi, phi_pmi_w1, phi_ed, phi_ped, device='cuda:0', sweeps=3,
                  rank=0, world=1, use_planes=True, adapt=None, domains=None, reg_param_ua_scale=1.0,
                  use_correct_feat=True, history=True, session_history=True, grouped_sweeps='auto', skip_unchanged=False,
-                 minibatch=None, shuffle_seed=None, load_params=None, share_params_with=None):
+                 minibatch=None, shuffle_seed=None, load_params=None, share_params_with=None, minibatch_mode='masked'):
         """use_planes switches the three per-instance feature planes on as a whole; use_correct_feat / history /
         session_history gate them one by one as the reference's options of the same names do (train_mp.py:178, 192,
         206: the 'correct', 'full_history' and 'hit_history' planes).
@@ -412,6 +447,13 @@ class TiDirTrainer:
         a shuffled order (`random.shuffle(training_instances)`, train_mp.py:631) -- a permutation seeded by (shuffle_seed,
         epoch), the same on every rank; shuffle_seed=None keeps the file order -- and cuts it into minibatches; a minibatch is
         sharded contiguously over the ranks, its statistics all-reduced once, theta updated once.
+        minibatch_mode: 'masked' (default) -- the rank's whole shard stays resident as ONE set of bucket trainers (one HIP graph);
+        every minibatch evaluates ALL of them under the current thetas and sums the statistics of the minibatch's instances only
+        (a device-side selection: the epoch's permutation is uploaded once, a minibatch costs one graph replay and no host work
+        per instance; the surplus evaluations are what a GPU that is idle anyway pays for having nothing rebuilt).  'rebuild' --
+        round 3's form: the bucket trainers of every minibatch are built from its instances (shape compile, table upload,
+        programs), which costs tens of milliseconds of host time per minibatch but evaluates nothing twice: for shards far
+        larger than a minibatch times the number of minibatches one can afford to replay.
         load_params: a params file (tidir.save_params / the reference's save_params) to start from instead of zeros
         (--load_params, train_mp.py:528-542: the adapt mode's extension is tried first, then the bare name).
         skip_unchanged: the sweeps drop updates that would recompute a message from unchanged inputs (include/mlbp.h
@@ -456,6 +498,9 @@ class TiDirTrainer:
         if load_params:
             self.load_params(load_params)
         self.minibatch = None if minibatch is None else max(1, int(minibatch))
+        if minibatch_mode not in ('masked', 'rebuild'):
+            raise ValueError("minibatch_mode is 'masked' or 'rebuild'")
+        self.minibatch_mode = minibatch_mode
         self.shuffle_seed = shuffle_seed
         self.n_stat = len(tidir.EE_NAMES) + len(tidir.ED_NAMES) + 2
         self.stats = torch.zeros(self.n_stat * (1 + len(self.domains)), dtype=torch.float64, device=dev)
@@ -466,6 +511,16 @@ class TiDirTrainer:
         self._full = _BucketSet(self, self.instances[lo:hi])
         self.buckets, self.trainers = self._full.buckets, self._full.trainers
         self._mini_sets = {}
+        self._mgraph = None
+        if self.minibatch is not None and self.minibatch_mode == 'masked':
+            # device-side selection of a minibatch: which minibatch every instance of the file belongs to this epoch, the current
+            # minibatch's number, and per bucket the file position of each of its instances
+            self._mb_of = torch.zeros(max(self.n_total, 1), dtype=torch.int32, device=dev)
+            self._m_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
+            for key, tr in self.trainers.items():
+                pos = np.array([lo + r['index'] for r in self.buckets[key]['rows']], dtype=np.int64)
+                tr._file_pos = torch.from_numpy(pos).to(dev)
 
     # ---- parameters -----------------------------------------------------------------------------
     def load_params(self, path):
@@ -548,6 +603,51 @@ class TiDirTrainer:
             self._mini_sets[key] = _BucketSet(self, [self.instances[int(i)] for i in ids[lo:hi]])
         return self._mini_sets[key]
 
+    def _masked_statistics(self):
+        """Statistics of the current minibatch (self._m_dev) over this rank's resident shard."""
+        if self._mgraph is not None:
+            self._mgraph.replay()
+            return self.stats
+        self.stats.zero_()
+        self._full.statistics_into(self.stats, self.grouped_sweeps,
+                                   select_of=lambda tr: torch.index_select(self._mb_of, 0, tr._file_pos) == self._m_dev)
+        return self.stats
+
+    def capture_masked(self):
+        """Records _masked_statistics() into one HIP graph: the minibatch number and the thetas are read from device tensors
+        at every replay, so ONE graph serves every minibatch of every epoch."""
+        self._mgraph = None
+        self._masked_statistics()
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._masked_statistics()
+        self._mgraph = g
+        return self
+
+    def _epoch_masked(self, epoch, learning_rate, reg_param):
+        order = self.epoch_order(epoch)
+        mb = np.empty(self.n_total, dtype=np.int32)
+        mb[order] = np.arange(self.n_total, dtype=np.int64) // self.minibatch
+        self._mb_of.copy_(torch.from_numpy(mb))                  # the epoch's permutation: one upload
+        self._acc.zero_()
+        for m in range((self.n_total + self.minibatch - 1) // self.minibatch):
+            self._m_dev.fill_(m)
+            self._masked_statistics()
+            self._update_on_device(learning_rate, reg_param)
+        lp, cnt = (float(v) for v in self._acc.cpu())                # (read once per epoch: no host round trip per minibatch)
+        return lp / max(cnt, 1.0)
+
+    def _update_on_device(self, learning_rate, reg_param):
+        """_update() without its host read-back: all-reduce, theta updates, the running [sum log-posterior, count]."""
+        mdist.all_reduce_sum_(self.stats)
+        n, F_ee, F_ed = self.n_stat, len(self.theta_en_en), len(self.theta_en_de)
+        apply_update(self.theta_en_en, self.theta_en_de, self.stats[:n], F_ee, F_ed, learning_rate, reg_param)
+        if self.domains:
+            apply_domain_update(self.theta_dom_en_en, self.theta_dom_en_de, self.stats[n:].view(len(self.domains), n), F_ee, F_ed,
+                                learning_rate, reg_param * self.reg_param_ua_scale)
+        self._acc += self.stats[n - 2:n]
+
     def epoch(self, learning_rate, reg_param):
         """One pass over the instances; returns the mean log-posterior (at the thetas each instance was evaluated under)."""
         epoch = self._epochs_done
@@ -556,6 +656,8 @@ class TiDirTrainer:
             self.local_statistics()
             lp, n = self._update(learning_rate, reg_param)
             return lp / max(n, 1.0)
+        if self.minibatch_mode == 'masked':
+            return self._epoch_masked(epoch, learning_rate, reg_param)
         order = self.epoch_order(epoch)
         lp_sum, n_sum = 0.0, 0.0
         for m, m0 in enumerate(range(0, self.n_total, self.minibatch)):
@@ -583,6 +685,9 @@ class TiDirTrainer:
         from . import tidir
         if capture and self.minibatch is None and epochs >= 3 and getattr(self, '_graph', None) is None and self.trainers:
             self.capture()
+        if capture and self.minibatch is not None and self.minibatch_mode == 'masked' and self._mgraph is None and self.trainers and \
+                epochs * ((self.n_total + self.minibatch - 1) // self.minibatch) >= 3:
+            self.capture_masked()
         if save_params:
             save_params = save_params + {'user': '.user_adapt', 'experience': '.exp_adapt', None: ''}[self.adapt]
         history = []

@@ -854,21 +854,36 @@ def test_minibatched_shuffled_epoch_equals_the_reference_sequence(tmp_path):
     ['minibatch'] holds the REFERENCE's own batch_sgd run minibatch by minibatch (4 instances each, a fixed shuffled order,
     every instance of a minibatch at the theta the minibatch starts from, steps added as batch_sgd_accumulate adds them;
     make_batch_golden.py).  TiDirTrainer(minibatch=4) walking the same order must land on the same theta after every
-    minibatch -- shapes are mixed inside a minibatch (grouped sweeps and per-bucket launches both), one update per minibatch."""
+    minibatch -- shapes are mixed inside a minibatch (grouped sweeps and per-bucket launches both), one update per minibatch.
+    Both minibatch forms: 'masked' (round 4, the default: the whole shard resident, every minibatch a device-side selection of
+    its instances' statistics -- eager, and replayed from ONE HIP graph) and 'rebuild' (bucket trainers built per minibatch)."""
     gold = _batch_gold()
     mb = gold['minibatch']
     paths = _write_tidir(gold, str(tmp_path))
-    for grouped in (True, False):
-        tt = _trainer(paths, gold, minibatch=mb['size'], shuffle_seed=3, grouped_sweeps=grouped)
+    for grouped, mode, graph in ((True, 'rebuild', False), (False, 'rebuild', False), (True, 'masked', False), (False, 'masked', False),
+                                 (True, 'masked', True)):
+        tt = _trainer(paths, gold, minibatch=mb['size'], shuffle_seed=3, grouped_sweeps=grouped, minibatch_mode=mode)
         tt.epoch_order = lambda epoch: np.array(mb['order'])
         seen = []
-        update = tt._update
+        if mode == 'rebuild':
+            update = tt._update
 
-        def recording(lr, reg):
-            out = update(lr, reg)
-            seen.append((tt.theta_en_en.cpu().numpy().copy(), tt.theta_en_de.cpu().numpy().copy(), out))
-            return out
-        tt._update = recording
+            def recording(lr, reg):
+                out = update(lr, reg)
+                seen.append((tt.theta_en_en.cpu().numpy().copy(), tt.theta_en_de.cpu().numpy().copy(), out))
+                return out
+            tt._update = recording
+        else:
+            update = tt._update_on_device
+
+            def recording(lr, reg):
+                update(lr, reg)
+                n = tt.n_stat
+                seen.append((tt.theta_en_en.cpu().numpy().copy(), tt.theta_en_de.cpu().numpy().copy(),
+                             (float(tt.stats[n - 2].item()), float(tt.stats[n - 1].item()))))
+            tt._update_on_device = recording
+            if graph:
+                tt.capture_masked()
         mean_lp = tt.epoch(mb['learning_rate'], gold['options']['reg_param'] / len(gold['instances']))
         assert len(seen) == len(mb['steps']) == 3
         for (ee, ed, (lp, n)), step in zip(seen, mb['steps']):

@@ -31,7 +31,7 @@ from .topology import GraphTopology
 class UserGraphTrainer:
     def __init__(self, spec, var_labels, unary_obs, phi_en_en, phi_en_en_w1, phi_en_de, theta_en_en, theta_en_de,
                  device='cuda:0', sweeps=3, roots=None, planes=None, domains=None, theta_dom_en_en=None,
-                 theta_dom_en_de=None, skip_unchanged=False):
+                 theta_dom_en_de=None, skip_unchanged=False, shared=None):
         """spec: a 'trainmp'-style spec (tests/golden/cases.py: factors carry factor_type / gap);
         var_labels [B][n_vars], unary_obs [B][U]: this rank's shard of instances.
         planes: optional per-instance sparse feature planes, a list (one entry per instance) of
@@ -41,6 +41,10 @@ class UserGraphTrainer:
         (train_mp.py:162-171, 226-247): instance i builds its potentials from theta_dom[domains[i]] INSTEAD of the
         global theta; the global theta still receives every instance's step.  Instances of one domain should be
         contiguous (groups of 16 consecutive graphs that share their tables run on the matrix cores).
+        shared: a _SharedTables (the bucket trainers of one TiDirTrainer): the pots, their transposed rows, every bucket's private
+        rows and the per-instance outputs then live in arrays the SET owns -- one potentials launch, one patch launch and one
+        statistics launch per step for all sentence shapes instead of one each per shape; finish_shared() completes the
+        construction once the set has sized them.
         skip_unchanged (off by default, like the C ABI: the default executes every update of the reference's schedule): the
         sweeps drop the updates of the root sequence that would recompute a message from unchanged inputs
         (MLBP_SWEEP_SKIP_UNCHANGED, include/mlbp.h) -- a third of a three-root user graph's contractions; statistics equal
@@ -92,30 +96,46 @@ class UserGraphTrainer:
             self._dom = torch.from_numpy(self._dom_host.astype(np.int32)).to(dev)
         nd = max(self.n_dom, 1)
         self.rows_per_dom = 2 * X + self.Vde
-        self.pair_tables = torch.empty(2 * nd, X, X, dtype=torch.float64, device=dev)
         obs_np = np.asarray(unary_obs, dtype=np.int64).reshape(B, topo.U)
         self._plan_patches(planes, unary_kind, obs_np, np.asarray(var_labels, dtype=np.int64).reshape(B, topo.n_vars))
         self.n_shared_rows = self.rows_per_dom * nd
-        self.unary_tables = torch.empty(self.n_shared_rows + self.n_priv, X, dtype=torch.float64, device=dev)
+        self._pair_phi, self._unary_kind_list, self._obs_np = pair_phi, unary_kind, obs_np
+        self.sweeps = int(sweeps)
+        self.roots = list(roots) if roots is not None else [topo.var_ids[i % topo.n_vars] for i in range(self.sweeps)]
+        fb.is_loopy = topo.has_loops(self.roots[0])
+        self.n_sweeps_run = self.sweeps if fb.is_loopy else 1                            # LBP.py:219
+        self.shared = shared
+        if shared is None:
+            self.pair_tables = torch.empty(2 * nd, X, X, dtype=torch.float64, device=dev)
+            self.unary_tables = torch.empty(self.n_shared_rows + self.n_priv, X, dtype=torch.float64, device=dev)
+            self._finish(priv_row0=self.n_shared_rows, g_ee=torch.empty(B, self.F_ee, dtype=torch.float64, device=dev),
+                         g_ed=torch.empty(B, self.F_ed, dtype=torch.float64, device=dev))
+
+    def finish_shared(self, priv_row0, g_ee, g_ed):
+        """Second half of the construction under a _SharedTables: the set's pots and rows, this bucket's private rows starting
+        at row priv_row0 of the set's row array, its per-instance gradient rows as views of the set's arrays."""
+        self.pair_tables, self.unary_tables = self.shared.pair_tables, self.shared.unary_tables
+        self._finish(priv_row0, g_ee, g_ed)
+
+    def _finish(self, priv_row0, g_ee, g_ed):
+        fb, topo, dev = self.batch, self.topo, self.device
+        X, B = self.spec['X'], fb.B
+        self.priv_row0 = int(priv_row0)
+        pair_phi, unary_kind = self._pair_phi, self._unary_kind_list
         fb.pair_tables = self.pair_tables
         ptab = np.tile(np.array(pair_phi or [0], dtype=np.int64), (B, 1)) + 2 * self._dom_host[:, None]
         fb.pair_tab = torch.from_numpy(ptab.astype(np.int32)).to(dev)
         fb.pair_tables_shared = bool(topo.P)      # every instance reads the two pots: the MFMA kernels apply
         # one row for every instance (no per-domain pots): at X >= 128 the sweeps can run as batched MFMA contractions
         fb._pair_row_host = np.ascontiguousarray(ptab[0], dtype=np.int32) if (topo.P and not self.n_dom) else None
-        obs = obs_np
+        obs = self._obs_np
         base = np.array([0, X, 2 * X], dtype=np.int64)[np.array(unary_kind, dtype=np.int64)] if topo.U else np.zeros(0)
         fb.unary_tables = self.unary_tables
         utab = obs + base[None, :] + self.rows_per_dom * self._dom_host[:, None]
         for r, (b_i, u) in enumerate(self._priv_rows):          # patched factors read their private row
-            utab[b_i, u] = self.n_shared_rows + r
+            utab[b_i, u] = self.priv_row0 + r
         fb.unary_tab = torch.from_numpy(utab.astype(np.int32)).to(dev)
-        self.sweeps = int(sweeps)
-        self.roots = list(roots) if roots is not None else [topo.var_ids[i % topo.n_vars] for i in range(self.sweeps)]
-        fb.is_loopy = topo.has_loops(self.roots[0])
-        self.n_sweeps_run = self.sweeps if fb.is_loopy else 1                            # LBP.py:219
-        self._g_ee = torch.empty(B, self.F_ee, dtype=torch.float64, device=dev)
-        self._g_ed = torch.empty(B, self.F_ed, dtype=torch.float64, device=dev)
+        self._g_ee, self._g_ed = g_ee, g_ed
         self._marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)
         self._lp = torch.empty(B, dtype=torch.float64, device=dev)
         n_stat = self.F_ee + self.F_ed + 2
@@ -128,10 +148,15 @@ class UserGraphTrainer:
         # table); only the private (plane-patched) rows still go through mlbp_unary_expectations_f64
         self._expect_in_potentials = False
         if X == 64 and topo.U and self.F_ee == 3 and self.F_ed == 6:
-            fb._derive_unary_rows()
-            if getattr(fb, '_row_kind', None) is not None and fb._row_kind is not False:
+            if self.shared is not None:                 # the set states the rows' (kind, column) and fills every row's expectations
+                fb._row_kind, fb._row_obs, fb._uexp = self.shared.row_kind, self.shared.row_obs, self.shared.uexp
+                fb._uexp_rows_done = int(self.shared.unary_tables.shape[0])
                 self._expect_in_potentials = True
-                fb._uexp_rows_done = self.n_shared_rows
+            else:
+                fb._derive_unary_rows()
+                if getattr(fb, '_row_kind', None) is not None and fb._row_kind is not False:
+                    self._expect_in_potentials = True
+                    fb._uexp_rows_done = self.n_shared_rows
 
     def _plan_patches(self, planes, unary_kind, obs, labels):
         """Host-side integer work: which (instance, en_de factor) pairs see a plane cell in their
@@ -156,6 +181,7 @@ class UserGraphTrainer:
                     rgraph.append(b_i); rbase.append(2 * X + col + self.rows_per_dom * int(self._dom_host[b_i]))
                     rlabel.append(int(labels[b_i, topo.fac_var[2 * topo.unary_factors[u]]]))
         self._priv_rows, self.n_priv = rows, len(rows)
+        self._priv_cols = [b - 2 * X - self.rows_per_dom * int(self._dom_host[g_i]) for b, g_i in zip(rbase, rgraph)]   # observed column of each private row
         # private rows of one domain must be contiguous (their exponent uses that domain's theta): instances come
         # grouped by domain, so the row list already is; record the ranges
         row_dom = [int(self._dom_host[b_i]) for b_i, _ in rows]
@@ -174,7 +200,7 @@ class UserGraphTrainer:
 
     def _patch_tables(self):
         if self.n_priv:
-            priv = self.unary_tables[self.n_shared_rows:]
+            priv = self.unary_tables[self.priv_row0:]
             for d, lo, hi in self._priv_dom_ranges:          # one launch per domain present (its theta in the exponent)
                 theta = self.theta_dom_en_de[d] if self.n_dom else self.theta_en_de
                 _ffi.check(_ffi.lib.mlbp_patch_unary_tables_f64(
@@ -184,13 +210,18 @@ class UserGraphTrainer:
 
     def _patch_gradient(self):
         if self.n_priv:
-            priv = self.unary_tables[self.n_shared_rows:]
+            priv = self.unary_tables[self.priv_row0:]
             _ffi.check(_ffi.lib.mlbp_patch_gradient_f64(
                 priv.data_ptr(), self._p_off.data_ptr(), self._p_x.data_ptr(), self._p_k.data_ptr(), self._p_val.data_ptr(),
                 self._p_graph.data_ptr(), self._p_label.data_ptr(), self.n_priv, self.spec['X'], self.F_ed,
                 self._g_ed.data_ptr(), _stream_ptr(self.device)))
 
     def build_potentials(self):
+        if self.shared is not None:
+            return self.shared.build([self])
+        return self._build_potentials_into(self.pair_tables, self.unary_tables, self.batch._uexp if self._expect_in_potentials else None)
+
+    def _build_potentials_into(self, pt, ut, ue, patch=True):
         fb, X, st = self.batch, self.spec['X'], _stream_ptr(self.device)
         # all three pots, for the global theta or for every domain's (its theta REPLACES the global one,
         # train_mp.py:226-247), in ONE launch: pot_en_en / pot_en_en_w1 as pairwise tables and transposed rows, pot_en_de
@@ -198,10 +229,8 @@ class UserGraphTrainer:
         nd = max(self.n_dom, 1)
         t_ee = self.theta_dom_en_en if self.n_dom else self.theta_en_en
         t_ed = self.theta_dom_en_de if self.n_dom else self.theta_en_de
-        ut, pt = self.unary_tables, self.pair_tables
-        # ... and, X = 64, every shared row's expected features (what the gradient gathers per unary factor,
+        # ... and, X = 64 (ue given), every shared row's expected features (what the gradient gathers per unary factor,
         # mlbp_unary_expectations_f64) out of the same launch: a row of pot^T IS a unary factor's table
-        ue = fb._uexp if self._expect_in_potentials else None
         jobs = (_ffi.PotentialsJob * 3)()
         for j, (phi, th, F, cols, pot, pot_t, row0) in enumerate((
                 (fb.phi_en_en, t_ee, self.F_ee, X, pt[0].data_ptr(), ut[0:X].data_ptr(), 0),
@@ -213,7 +242,8 @@ class UserGraphTrainer:
             if ue is not None:
                 jobs[j].expect, jobs[j].expect_stride = ue[row0:].data_ptr(), self.rows_per_dom * 8
         _ffi.check(_ffi.lib.mlbp_potentials_multi_f64(jobs, 3, nd, st))
-        self._patch_tables()
+        if patch:
+            self._patch_tables()
 
     def capture(self):
         """Records local_statistics() into a HIP graph (torch.cuda.CUDAGraph over the library's stream-ordered
@@ -237,9 +267,10 @@ class UserGraphTrainer:
             return self.stats_all if self.n_dom else self.stats
         return self._local_statistics_eager()
 
-    def _local_statistics_eager(self, select=None):
+    def _local_statistics_eager(self, select=None, potentials=True):
         fb = self.batch
-        self.build_potentials()
+        if potentials:
+            self.build_potentials()
         fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg, gradient=(self._g_ee, self._g_ed),
                  keep_messages=False)
         return self._statistics_after_sweep(select=select)
@@ -365,6 +396,66 @@ def apply_domain_update(theta_dom_en_en, theta_dom_en_de, stats_dom, F_ee, F_ed,
     return theta_dom_en_en, theta_dom_en_de
 
 
+class _SharedTables:
+    """What the bucket trainers of one set have in common, held ONCE: the pots under the global theta (or every domain's) as
+    pairwise tables and as transposed rows (train_mp.py:220-255 builds them per instance; they depend on theta alone), behind
+    the shared rows every bucket's private plane-patched rows, the rows' expected features, and the per-instance gradient rows
+    of all buckets.  One potentials launch and one expectations launch per step serve every sentence shape."""
+
+    def __init__(self, trainers):
+        t0 = trainers[0]
+        self.trainers = list(trainers)
+        dev, X = t0.device, t0.spec['X']
+        nd = max(t0.n_dom, 1)
+        self.n_shared_rows = t0.n_shared_rows
+        n_priv = sum(t.n_priv for t in trainers)
+        self.pair_tables = torch.empty(2 * nd, X, X, dtype=torch.float64, device=dev)
+        self.unary_tables = torch.empty(self.n_shared_rows + n_priv, X, dtype=torch.float64, device=dev)
+        n_inst = sum(t.batch.B for t in trainers)
+        self.g_ee = torch.empty(n_inst, t0.F_ee, dtype=torch.float64, device=dev)
+        self.g_ed = torch.empty(n_inst, t0.F_ed, dtype=torch.float64, device=dev)
+        # every row's (phi selector, observed column): shared rows by their place in the layout, private rows their base row's
+        rk = np.zeros(self.n_shared_rows + n_priv, dtype=np.int32)
+        ro = np.zeros(self.n_shared_rows + n_priv, dtype=np.int32)
+        for d in range(nd):
+            o = d * t0.rows_per_dom
+            rk[o + X:o + 2 * X] = 1; rk[o + 2 * X:o + t0.rows_per_dom] = 2
+            ro[o:o + X] = np.arange(X); ro[o + X:o + 2 * X] = np.arange(X); ro[o + 2 * X:o + t0.rows_per_dom] = np.arange(t0.Vde)
+        row, inst = self.n_shared_rows, 0
+        self._plans = []
+        for t in trainers:
+            rk[row:row + t.n_priv] = 2
+            ro[row:row + t.n_priv] = np.asarray(t._priv_cols, dtype=np.int32).reshape(-1)
+            self._plans.append((row, inst))
+            row += t.n_priv; inst += t.batch.B
+        self.row_kind = torch.from_numpy(rk).to(dev)
+        self.row_obs = torch.from_numpy(ro).to(dev)
+        self.uexp = torch.zeros(self.n_shared_rows + n_priv, 8, dtype=torch.float64, device=dev)
+        for t, (row, inst) in zip(trainers, self._plans):
+            t.shared = self
+            t.finish_shared(row, self.g_ee[inst:inst + t.batch.B], self.g_ed[inst:inst + t.batch.B])
+
+    def build(self, trainers=None):
+        """The pots (and the shared rows' expected features) under the current thetas, then the private rows of `trainers`
+        (default: all) and THEIR expected features."""
+        t0 = self.trainers[0]
+        expect = t0._expect_in_potentials
+        t0._build_potentials_into(self.pair_tables, self.unary_tables, self.uexp if expect else None, patch=False)
+        trs = self.trainers if trainers is None else trainers
+        for t in trs:
+            t._patch_tables()
+        if not expect:
+            return
+        spans = [(self.n_shared_rows, int(self.unary_tables.shape[0]))] if trainers is None else [(t.priv_row0, t.priv_row0 + t.n_priv) for t in trs]
+        fb = t0.batch
+        for lo, hi in spans:
+            if hi > lo:
+                _ffi.check(_ffi.lib.mlbp_unary_expectations_f64(
+                    self.unary_tables[lo:].data_ptr(), hi - lo, fb.X, self.row_kind[lo:].data_ptr(), self.row_obs[lo:].data_ptr(),
+                    fb._phi_t[0].data_ptr(), fb._phi_t[1].data_ptr(), fb._phi_t[2].data_ptr(), t0.F_ee, t0.F_ed, t0.Vde,
+                    self.uexp[lo:].data_ptr(), _stream_ptr(t0.device)))
+
+
 class _BucketSet:
     """The bucket trainers (one UserGraphTrainer per sentence shape) of a list of instances, sharing the owner's thetas."""
 
@@ -395,7 +486,8 @@ class _BucketSet:
                     planes.append(cells)
             self.trainers[key] = UserGraphTrainer(b['spec'], b['var_labels'], b['unary_obs'], o.phi_ee, o.phi_w1, o.phi_ed_t,
                                                   o.theta_en_en, o.theta_en_de, device=o.device, sweeps=o.sweeps, roots=roots,
-                                                  planes=planes, skip_unchanged=o.skip_unchanged, **extra)
+                                                  planes=planes, skip_unchanged=o.skip_unchanged, shared=True, **extra)
+        self.shared = _SharedTables(list(self.trainers.values())) if self.trainers else None
 
     def statistics_into(self, stats, grouped_sweeps, select_of=None):
         """Adds the buckets' statistics to `stats`.  grouped_sweeps: the sweeps of ALL sentence shapes with pairwise factors
@@ -410,14 +502,13 @@ class _BucketSet:
         together = [tr for tr in trs if tr.topo.P >= 1 and tr.batch.X == 64] if grouped_sweeps else []
         if len(together) < 2 and grouped_sweeps is not True:
             together = []
+        self.shared.build()                           # ONE potentials launch (and one expectations launch) for every shape
         for tr in trs:
             if not any(tr is t for t in together):
-                stats += tr.local_statistics() if select_of is None else tr._local_statistics_eager(select=sel(tr))
+                stats += tr._local_statistics_eager(select=sel(tr), potentials=False)
         if not together:
             return
         from .batch import sweep_groups
-        for tr in together:
-            tr.build_potentials()
         sweep_groups([tr.batch for tr in together], [tr.roots[:tr.n_sweeps_run] for tr in together], init=True,
                      marginals=[tr._marg for tr in together], gradients=[(tr._g_ee, tr._g_ed) for tr in together],
                      keep_messages=False)

@@ -321,6 +321,19 @@ int mlbp_log_posterior_f64(const double* marginals, const int32_t* labels, int32
 int mlbp_log_posterior_sum_f64(const double* marginals, const int32_t* labels, int32_t B, int32_t n_vars,
                                int32_t X, double* out, double* sum_out, void* stream);
 
+/* FactorGraph.get_posterior_probs (LBP.py:247-259) for SEVERAL groups of graphs in one launch -- a minibatch of mixed sentence
+ * shapes, every group its own variable count (train_mp.py:257-299 builds a different K_n per instance): out[start_k + b] is the
+ * log-posterior of graph b of group k.  `groups` is a DEVICE array of n_groups records sorted by `start`, the groups' ranges
+ * [start_k, start_k + B_k) tile [0, n_total).  A label outside [0, X) is skipped and raises mlbp_gradient_status. */
+typedef struct mlbp_posterior_group {
+  const double* marginals;    /* device [B][n_vars][X] */
+  const int32_t* labels;      /* device [B][n_vars]    */
+  int32_t n_vars, B;
+  int64_t start;
+} mlbp_posterior_group;
+int mlbp_log_posterior_groups_f64(const mlbp_posterior_group* groups, int32_t n_groups, int64_t n_total, int32_t X, double* out,
+                                  void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * DEVICE: factor beliefs and the log-linear gradient, batched over graphs
  * ------------------------------------------------------------------------------------------- */

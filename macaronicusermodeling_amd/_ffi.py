@@ -99,6 +99,7 @@ SIGNATURES = {
     'mlbp_marginals_f64': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     'mlbp_log_posterior_f64': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     'mlbp_log_posterior_sum_f64': (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    'mlbp_log_posterior_groups_f64': (C.c_int, [_vp, _i32, _i64, _i32, _vp, _vp]),
     'mlbp_pair_beliefs_f64': (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     'mlbp_gradient_f64': (C.c_int, [C.POINTER(GradientArgs), _vp]),
     'mlbp_gradient_status': (C.c_int, []),

@@ -12,6 +12,9 @@
 // mlbp_sum_rows_f64 (the device half of train_mp.py's accumulate callback).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+#include <vector>
+
 #include "mlbp_internal.h"
 
 using mlbp::fail;
@@ -283,12 +286,36 @@ __device__ __forceinline__ void unary_gradient_x64(const GradDev& d, int g, int 
 }
 
 template <int FEE, int FED>
+__device__ __forceinline__ void gradient_x64_body(const GradDev& d, const int g);
+
+template <int FEE, int FED>
 __global__ __launch_bounds__(WG) void gradient_x64_kernel(GradDev d) {
+  const int g = blockIdx.x;
+  if (d.only && !d.only[g]) return;
+  gradient_x64_body<FEE, FED>(d, g);
+}
+
+// Several groups of graphs in one launch, flagged graphs only (the fix-up behind mlbp_sweep_groups_f64's fused gradients):
+// groups[k] = the group's description, first[k] = its first block (ascending; one block per graph).
+struct GradGroup { GradDev d; int32_t first, pad_; };
+__global__ __launch_bounds__(WG) void gradient_x64_groups_kernel(const GradGroup* groups, int n_groups) {
+  int lo = 0, hi = n_groups - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (groups[mid].first <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int g = (int)blockIdx.x - groups[lo].first;
+  const uint8_t* only = groups[lo].d.only;
+  if (g >= groups[lo].d.a.B || !only || !only[g]) return;
+  const GradDev d = groups[lo].d;
+  gradient_x64_body<3, 6>(d, g);
+}
+
+template <int FEE, int FED>
+__device__ __forceinline__ void gradient_x64_body(const GradDev& d, const int g) {
   __shared__ double scratch[4 * (FMAX + 1)];
   __shared__ double wave_out[4][2 * FMAX];
   const mlbp_gradient_args& a = d.a;
-  const int g = blockIdx.x;
-  if (d.only && !d.only[g]) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double gee[FEE];
 #pragma unroll
@@ -631,6 +658,28 @@ int gradient_flagged_only(const mlbp_gradient_args* a, const uint8_t* flags, voi
   d.only = flags;
   if (int e = status_word(&d.status)) return e;
   hipLaunchKernelGGL((gradient_x64_kernel<3, 6>), dim3(a->B), dim3(WG), 0, (hipStream_t)stream, d);
+  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "gradient fix-up launch failed");
+  return MLBP_OK;
+}
+int gradient_flagged_groups(const mlbp_gradient_args* args, const uint8_t* const* flags, int n_groups, mlbp_program* owner, void* stream) {
+  std::vector<GradGroup> table(n_groups);
+  int blocks = 0;
+  int32_t* status = nullptr;
+  if (int e = status_word(&status)) return e;
+  for (int k = 0; k < n_groups; ++k) {
+    if (args[k].X != 64 || args[k].F_ee != 3 || args[k].F_ed != 6) return fail(MLBP_EINVAL, "gradient_flagged_groups: X = 64, F = (3, 6)");
+    memset(&table[k], 0, sizeof(GradGroup));
+    table[k].d.a = args[k]; table[k].d.status = status; table[k].d.skip_pairs = 0; table[k].d.only = flags[k];
+    table[k].first = blocks;
+    blocks += args[k].B;
+  }
+  static_assert(sizeof(GradGroup) % 4 == 0, "");
+  std::vector<int32_t> words(sizeof(GradGroup) / 4 * (size_t)n_groups + 1);
+  memcpy(words.data(), table.data(), sizeof(GradGroup) * (size_t)n_groups);
+  words.back() = 0x47524144;
+  int32_t* d_table = nullptr;
+  if (int e = group_table_device(owner->stables, words, stream, &d_table)) return e;
+  hipLaunchKernelGGL(gradient_x64_groups_kernel, dim3(blocks), dim3(WG), 0, (hipStream_t)stream, reinterpret_cast<const GradGroup*>(d_table), n_groups);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "gradient fix-up launch failed");
   return MLBP_OK;
 }

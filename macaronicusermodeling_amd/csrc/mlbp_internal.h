@@ -72,6 +72,8 @@ bool exact_kernel_fuses_gradient(const mlbp_program* prog, const mlbp_sweep_args
 // mlbp_grad.hip: the per-graph gradient kernel on the graphs whose flag byte is set (fix-up behind a fused gradient the exact
 // kernel cannot redo: more than three pairwise factors)
 int gradient_flagged_only(const mlbp_gradient_args* a, const uint8_t* flags, void* stream);
+// The same for n_groups groups in ONE launch (table cached with `owner`'s group tables).
+int gradient_flagged_groups(const mlbp_gradient_args* args, const uint8_t* const* flags, int n_groups, mlbp_program* owner, void* stream);
 // The same for several (program, arguments) groups in one launch sequence; *launched false = some group does not qualify.
 int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args* args, int n_groups, void* stream, bool* launched);
 // Pairwise part of the gradient for shared tables (X = 64, F_ee = 3), ADDED to a->grad_en_en.

@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <utility>
 #include <map>
@@ -601,6 +602,33 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
   }
 }
 
+// The fix-up pass for SEVERAL groups of graphs in one launch (mlbp_sweep_groups_f64 behind the shared-table kernels: a
+// minibatch of mixed sentence shapes used to pay one near-empty launch per shape).  groups[k]: the group's descriptions as a
+// single-group fix-up launch would get them, and its first workgroup; tables are streamed (NT = 0: any number of pairwise
+// factors), the gradient of a redone graph comes from gradient_x64_kernel's flagged-only mode (mlbp_grad.hip).
+struct FixupGroup { SweepDev d; FusedDev f; int32_t first_block, pad_; };
+__global__ __launch_bounds__(WG, 4) void sweep_x64_fixup_groups_kernel(const FixupGroup* groups, int n_groups) {
+  int lo = 0, hi = n_groups - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (groups[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const FixupGroup& G = groups[lo];
+  const int base = ((int)blockIdx.x - G.first_block) * FIXUP_GRAPHS_PER_WG;
+  const int mine = base + (threadIdx.x & 63);
+  unsigned long long todo = __ballot(mine < G.f.n_graphs && G.f.only[mine] != 0);
+  if (!todo) return;
+  const SweepDev d = G.d;
+  const FusedDev f = G.f;
+  const GradFusedDev gf = {};
+  while (todo) {
+    const int i = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    sweep_x64_fused_body<true, 0, false>(d, f, gf, base + i);
+    if (todo) __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Any X: messages in LDS when they fit (LDSMSG) else in place in global memory (only this
 // workgroup touches its graph's messages; __syncthreads orders the accesses).
@@ -957,6 +985,30 @@ __global__ __launch_bounds__(LP_WG) void log_posterior_kernel(const double* marg
     *sum_out = v;
     g_lp_done[generation & 1] = 0;                             // ready for the next launch of this parity (a replayed capture keeps its generation)
   }
+}
+
+// The same per-graph sum for several groups of graphs (each its own variable count) in one launch: thread i finds its group
+// by binary search over the groups' first indices.
+__global__ __launch_bounds__(LP_WG) void log_posterior_groups_kernel(const mlbp_posterior_group* groups, int n_groups, long long n_total, int X,
+                                                                     double* out, int32_t* status) {
+  const long long i = (long long)blockIdx.x * LP_WG + threadIdx.x;
+  if (i >= n_total) return;
+  int lo = 0, hi = n_groups - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (groups[mid].start <= i) lo = mid; else hi = mid - 1;
+  }
+  const mlbp_posterior_group g = groups[lo];
+  const long long b = i - g.start;
+  if (b >= g.B) return;
+  double total = 0.0;
+  for (int v = 0; v < g.n_vars; ++v) {
+    const int lab = g.labels[(size_t)b * g.n_vars + v];
+    if ((unsigned)lab >= (unsigned)X) { atomicExch(status, 1); continue; }
+    const double lp = log(g.marginals[((size_t)b * g.n_vars + v) * X + lab]);
+    total += (lp == -__builtin_huge_val()) ? -99.99 : lp;  // LBP.py:254-256
+  }
+  out[i] = total;
 }
 
 // Fused program form (see sweep_x64_fused_kernel).  Input: the validated 4-word op list.
@@ -1681,6 +1733,69 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   return MLBP_OK;
 }
 
+// Behind launch_shared_groups: every group's fix-up pass in ONE launch (and, when the call carries gradients, one launch of
+// the per-graph gradient kernel over the flagged graphs of all groups).  *done false: some group needs the per-group path
+// (messages kept -- the unary write-back ran already, but marginals without normalisation, an LDS image too large, a gradient
+// the shared-table kernel did not produce).
+static int finish_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args* args, int n_groups, void* stream, bool* done) {
+  *done = false;
+  const size_t LDS_MAX = 160 * 1024;
+  std::vector<FixupGroup> table(n_groups);
+  std::vector<mlbp_gradient_args> grads;
+  std::vector<const uint8_t*> grad_flags;
+  size_t lds_max = 0;
+  int blocks = 0;
+  bool any_grad = false;
+  for (int k = 0; k < n_groups; ++k) {
+    const mlbp_program* prog = progs[k];
+    const mlbp_sweep_args* a = &args[k];
+    if (a->X != 64 || !a->normalize_messages || !a->init_messages) return MLBP_OK;
+    if (a->marginals && !prog->d_readout) return MLBP_OK;
+    const int n_ext = 1 + prog->n_cprod;
+    const size_t img_words = (size_t)prog->n_fops * 8 + prog->n_psrcs + 2 * prog->n_hoist + prog->n_cpw + prog->n_written;
+    const size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 64 + 512) * sizeof(double) + (img_words + prog->P + 6 * prog->U + 8) * sizeof(int32_t);
+    if (lds > LDS_MAX) return MLBP_OK;
+    lds_max = std::max(lds_max, lds);
+    if (a->gradient && !mlbp::shared_gradient_fused(prog, a)) return MLBP_OK;
+    mlbp_program* mp = const_cast<mlbp_program*>(prog);
+    FixupGroup& G = table[k];
+    memset(&G, 0, sizeof(G));
+    SweepDev& d = G.d;
+    d.pair_tables = a->pair_tables; d.pair_tab = a->pair_tab; d.unary_tables = a->unary_tables; d.unary_tab = a->unary_tab;
+    d.msgs = a->msgs; d.ops = prog->d_ops; d.srcs = prog->d_srcs; d.sweeps = prog->d_sweeps; d.pairseq = prog->d_fpairseq;
+    d.status = prog->d_status;
+    d.n_sweeps = prog->n_sweeps; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U; d.X = a->X;
+    d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables;
+    d.marginals = a->marginals; d.readout = prog->d_readout; d.n_vars = prog->n_vars;
+    FusedDev& f = G.f;
+    f.only = mp->d_bail; f.image = prog->d_fops; f.fsweeps = prog->d_fsweeps;
+    f.n_fops = prog->n_fops; f.n_psrcs = prog->n_psrcs; f.n_hoist = prog->n_hoist; f.n_cprod = prog->n_cprod; f.n_cpw = prog->n_cpw;
+    f.n_ext = n_ext; f.init = a->init_messages; f.n_graphs = a->B;
+    G.first_block = blocks;
+    blocks += (a->B + FIXUP_GRAPHS_PER_WG - 1) / FIXUP_GRAPHS_PER_WG;
+    if (a->gradient) { any_grad = true; grads.push_back(*a->gradient); grad_flags.push_back(mp->d_bail); }
+  }
+  if (any_grad && (int)grads.size() != n_groups) return MLBP_OK;        // (all groups or none carry a gradient)
+  // the table as 32-bit words in the first program's group-table cache (one device copy per distinct contents)
+  static_assert(sizeof(FixupGroup) % 4 == 0, "");
+  std::vector<int32_t> words(sizeof(FixupGroup) / 4 * (size_t)n_groups + 1);
+  memcpy(words.data(), table.data(), sizeof(FixupGroup) * (size_t)n_groups);
+  words.back() = 0x46495855;                                                  // (keeps this table apart from the sweep kernels' own)
+  mlbp_program* owner = const_cast<mlbp_program*>(progs[0]);
+  int32_t* d_table = nullptr;
+  if (int e = mlbp::group_table_device(owner->stables, words, stream, &d_table)) return e;
+  if (int e = ensure_dynamic_lds((const void*)sweep_x64_fixup_groups_kernel, lds_max)) return e;
+  hipLaunchKernelGGL(sweep_x64_fixup_groups_kernel, dim3(blocks), dim3(WG), lds_max, (hipStream_t)stream,
+                     reinterpret_cast<const FixupGroup*>(d_table), n_groups);
+  HIP_TRY(hipGetLastError());
+  if (any_grad)
+    if (int e = mlbp::gradient_flagged_groups(grads.data(), grad_flags.data(), n_groups, owner, stream)) return e;
+  g_last_kernel = MLBP_KERNEL_SHARED_MFMA;
+  g_last_fused_gradient = any_grad ? 1 : 0;
+  *done = true;
+  return MLBP_OK;
+}
+
 int mlbp_sweep_groups_f64(const mlbp_program* const* progs, const mlbp_sweep_args* args, int32_t n_groups, void* stream) {
   if (!progs || !args || n_groups < 1) return fail(MLBP_EINVAL, "mlbp_sweep_groups_f64: bad arguments");
   bool one_launch = false;
@@ -1695,6 +1810,13 @@ int mlbp_sweep_groups_f64(const mlbp_program* const* progs, const mlbp_sweep_arg
     if (int e = mlbp::launch_shared_groups(progs, args, n_groups, stream, &shared_launch)) return e;
   if (sweep_variant() == 1 && !shared_launch)
     if (int e = mlbp::launch_lean_groups(progs, args, n_groups, stream, &one_launch)) return e;
+  // the shared-table kernels have run every group, gradient included: ONE fix-up launch for the flagged graphs of all groups and
+  // one more for their gradients (a mixed minibatch used to pay both per group)
+  if (shared_launch) {
+    bool done = false;
+    if (int e = finish_shared_groups(progs, args, n_groups, stream, &done)) return e;
+    if (done) return MLBP_OK;
+  }
   // the fast kernel has run every group (one_launch): what is left per group is the fix-up pass over the graphs it
   // flagged; otherwise the groups run one after the other exactly as separate calls would
   int rc = MLBP_OK;
@@ -1913,6 +2035,18 @@ int mlbp_log_posterior_sum_f64(const double* marginals, const int32_t* labels, i
   const unsigned gen = sum_out ? generation.fetch_add(1u) + 1u : 0u;
   hipLaunchKernelGGL(log_posterior_kernel, dim3(blocks), dim3(LP_WG), 0, (hipStream_t)stream, marginals, labels, B, n_vars, X, out,
                      sum_out, status, gen);
+  HIP_TRY(hipGetLastError());
+  return MLBP_OK;
+}
+
+int mlbp_log_posterior_groups_f64(const mlbp_posterior_group* groups, int32_t n_groups, int64_t n_total, int32_t X, double* out,
+                                  void* stream) {
+  if (!groups || !out || n_groups <= 0 || n_total <= 0 || X <= 0) return fail(MLBP_EINVAL, "mlbp_log_posterior_groups_f64: bad arguments");
+  if (int e = check_device()) return e;
+  int32_t* status = nullptr;
+  if (int e = global_status(&status)) return e;
+  hipLaunchKernelGGL(log_posterior_groups_kernel, dim3((unsigned)((n_total + LP_WG - 1) / LP_WG)), dim3(LP_WG), 0, (hipStream_t)stream, groups,
+                     n_groups, (long long)n_total, X, out, status);
   HIP_TRY(hipGetLastError());
   return MLBP_OK;
 }

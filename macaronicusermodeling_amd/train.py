@@ -191,6 +191,7 @@ class UserGraphTrainer:
         for d in sorted(set(row_dom)):
             lo = row_dom.index(d)
             self._priv_dom_ranges.append((d, lo, lo + row_dom.count(d)))
+        self._p_host = (off, ix, ik, iv, rgraph, rlabel, rbase)      # (a _SharedTables joins the sets' plans into one launch)
         if self.n_priv:
             dev = self.device
             as_i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)          # noqa: E731
@@ -267,12 +268,14 @@ class UserGraphTrainer:
             return self.stats_all if self.n_dom else self.stats
         return self._local_statistics_eager()
 
+    def _sweep_with_gradient(self):
+        self.batch.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg, gradient=(self._g_ee, self._g_ed),
+                         keep_messages=False)
+
     def _local_statistics_eager(self, select=None, potentials=True):
-        fb = self.batch
         if potentials:
             self.build_potentials()
-        fb.sweep(self.roots[:self.n_sweeps_run], init=True, marginals=self._marg, gradient=(self._g_ee, self._g_ed),
-                 keep_messages=False)
+        self._sweep_with_gradient()
         return self._statistics_after_sweep(select=select)
 
     def _statistics_after_sweep(self, gradient_from_messages=False, select=None):
@@ -434,6 +437,75 @@ class _SharedTables:
         for t, (row, inst) in zip(trainers, self._plans):
             t.shared = self
             t.finish_shared(row, self.g_ee[inst:inst + t.batch.B], self.g_ed[inst:inst + t.batch.B])
+        self.n_inst, self.n_priv, self.n_dom = n_inst, n_priv, t0.n_dom
+        self.F_ee, self.F_ed, self.X = t0.F_ee, t0.F_ed, X
+        # the buckets' patch plans joined: one mlbp_patch_unary_tables_f64 (one theta: no per-domain thetas) and one
+        # mlbp_patch_gradient_f64 launch for every sentence shape
+        off, ix, ik, iv, rg, rl, rb = [0], [], [], [], [], [], []
+        for t, (row, inst) in zip(trainers, self._plans):
+            o, x, k, v, g, l, b = t._p_host
+            off += [len(ix) + e for e in o[1:]]
+            ix += x; ik += k; iv += v; rl += l; rb += b
+            rg += [inst + gi for gi in g]
+        if n_priv:
+            as_i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=dev)          # noqa: E731
+            self._p_off, self._p_x, self._p_k = as_i32(off), as_i32(ix), as_i32(ik)
+            self._p_val = torch.tensor(iv, dtype=torch.float64, device=dev)
+            self._p_graph, self._p_label, self._p_base = as_i32(rg), as_i32(rl), as_i32(rb)
+        # per-instance outputs of the whole set and the group table of mlbp_log_posterior_groups_f64
+        self.lp = torch.empty(n_inst, dtype=torch.float64, device=dev)
+        n_stat = self.F_ee + self.F_ed + 2
+        self.rows = torch.empty(n_inst, n_stat, dtype=torch.float64, device=dev)
+        self.stats_all = torch.zeros(n_stat * (1 + self.n_dom), dtype=torch.float64, device=dev)
+        gt = np.zeros(len(trainers), dtype=[('m', '<u8'), ('l', '<u8'), ('nv', '<i4'), ('B', '<i4'), ('start', '<i8')])
+        for i, (t, (row, inst)) in enumerate(zip(trainers, self._plans)):
+            gt[i] = (t._marg.data_ptr(), t.batch._labels.data_ptr(), t.topo.n_vars, t.batch.B, inst)
+        self._groups = torch.from_numpy(gt.view(np.uint8).reshape(-1).copy()).to(dev)
+        nd = max(self.n_dom, 1)
+        self._segsum = torch.zeros(nd + 1, n_stat, dtype=torch.float64, device=dev)
+        self._seg = torch.empty(n_inst, dtype=torch.int32, device=dev)
+        self._dump = torch.full((n_inst,), nd, dtype=torch.int32, device=dev)
+        self._seg0 = torch.zeros(n_inst, dtype=torch.int32, device=dev)
+        if self.n_dom:
+            self._dom = torch.cat([t._dom for t in trainers])
+
+    def patch_gradient(self):
+        if self.n_priv:
+            priv = self.unary_tables[self.n_shared_rows:]
+            _ffi.check(_ffi.lib.mlbp_patch_gradient_f64(
+                priv.data_ptr(), self._p_off.data_ptr(), self._p_x.data_ptr(), self._p_k.data_ptr(), self._p_val.data_ptr(),
+                self._p_graph.data_ptr(), self._p_label.data_ptr(), self.n_priv, self.X, self.F_ed,
+                self.g_ed.data_ptr(), _stream_ptr(self.trainers[0].device)))
+
+    def statistics(self, select=None):
+        """[sum g_ee | sum g_ed | sum log-posterior | count] (then the per-domain rows) over every instance of the set -- or over
+        the instances with select[i] set (device bool [n_inst]: a masked minibatch) -- behind the sweeps of all buckets: the
+        planes' gradient share, the log-posteriors of every group and the sums, one launch each."""
+        st = _stream_ptr(self.trainers[0].device)
+        self.patch_gradient()
+        _ffi.check(_ffi.lib.mlbp_log_posterior_groups_f64(self._groups.data_ptr(), len(self.trainers), self.n_inst, self.X, self.lp.data_ptr(), st))
+        n_stat = self.F_ee + self.F_ed + 2
+        if select is None and not self.n_dom:
+            _ffi.check(_ffi.lib.mlbp_sum_rows_cat_f64(self.g_ee.data_ptr(), self.F_ee, self.g_ed.data_ptr(), self.F_ed, self.lp.data_ptr(), 1,
+                                                      self.n_inst, 1, self.stats_all.data_ptr(), st))
+            return self.stats_all
+        r = self.rows
+        r[:, :self.F_ee] = self.g_ee
+        r[:, self.F_ee:self.F_ee + self.F_ed] = self.g_ed
+        r[:, -2] = self.lp
+        r[:, -1] = 1.0
+        nd = max(self.n_dom, 1)
+        code = self._dom if self.n_dom else self._seg0
+        if select is not None:
+            torch.where(select, code, self._dump, out=self._seg)
+            code = self._seg
+        _ffi.check(_ffi.lib.mlbp_segment_sum_rows_f64(r.data_ptr(), self.n_inst, n_stat, code.data_ptr(), nd + 1, self._segsum.data_ptr(), st))
+        if self.n_dom:
+            self.stats_all[n_stat:].view(nd, n_stat).copy_(self._segsum[:nd])
+            torch.sum(self._segsum[:nd], dim=0, out=self.stats_all[:n_stat])
+        else:
+            self.stats_all.copy_(self._segsum[0])
+        return self.stats_all
 
     def build(self, trainers=None):
         """The pots (and the shared rows' expected features) under the current thetas, then the private rows of `trainers`
@@ -442,8 +514,14 @@ class _SharedTables:
         expect = t0._expect_in_potentials
         t0._build_potentials_into(self.pair_tables, self.unary_tables, self.uexp if expect else None, patch=False)
         trs = self.trainers if trainers is None else trainers
-        for t in trs:
-            t._patch_tables()
+        if trainers is None and self.n_priv and not self.n_dom:      # every private row of every shape in one launch
+            priv = self.unary_tables[self.n_shared_rows:]
+            _ffi.check(_ffi.lib.mlbp_patch_unary_tables_f64(
+                self.unary_tables.data_ptr(), self._p_base.data_ptr(), self._p_off.data_ptr(), self._p_x.data_ptr(), self._p_k.data_ptr(),
+                self._p_val.data_ptr(), t0.theta_en_de.data_ptr(), self.n_priv, self.X, priv.data_ptr(), _stream_ptr(t0.device)))
+        else:
+            for t in trs:
+                t._patch_tables()
         if not expect:
             return
         spans = [(self.n_shared_rows, int(self.unary_tables.shape[0]))] if trainers is None else [(t.priv_row0, t.priv_row0 + t.n_priv) for t in trs]
@@ -489,31 +567,29 @@ class _BucketSet:
                                                   planes=planes, skip_unchanged=o.skip_unchanged, shared=True, **extra)
         self.shared = _SharedTables(list(self.trainers.values())) if self.trainers else None
 
-    def statistics_into(self, stats, grouped_sweeps, select_of=None):
-        """Adds the buckets' statistics to `stats`.  grouped_sweeps: the sweeps of ALL sentence shapes with pairwise factors
+    def statistics_into(self, stats, grouped_sweeps, select=None):
+        """Adds the set's statistics to `stats`.  grouped_sweeps: the sweeps of ALL sentence shapes with pairwise factors
         in one launch sequence (batch.sweep_groups -> mlbp_sweep_groups_f64: every bucket its own topology and roots;
         the shared-table kernels take a group table) instead of one launch sequence per bucket; 'auto' groups whenever
-        two or more buckets qualify.  select_of: optional callable, bucket trainer -> device bool [B]: only the selected
-        instances enter the sums (masked minibatches)."""
+        two or more buckets qualify.  select: optional device bool over the set's instances (bucket order): only the selected
+        ones enter the sums (masked minibatches).  One potentials launch in front of the sweeps and three launches behind them
+        (planes' gradient share, log-posteriors, sums) serve every shape."""
         trs = list(self.trainers.values())
         if not trs:
             return
-        sel = (lambda tr: select_of(tr)) if select_of is not None else (lambda tr: None)
+        self.shared.build()                           # ONE potentials launch (and one expectations launch) for every shape
         together = [tr for tr in trs if tr.topo.P >= 1 and tr.batch.X == 64] if grouped_sweeps else []
         if len(together) < 2 and grouped_sweeps is not True:
             together = []
-        self.shared.build()                           # ONE potentials launch (and one expectations launch) for every shape
         for tr in trs:
             if not any(tr is t for t in together):
-                stats += tr._local_statistics_eager(select=sel(tr), potentials=False)
-        if not together:
-            return
-        from .batch import sweep_groups
-        sweep_groups([tr.batch for tr in together], [tr.roots[:tr.n_sweeps_run] for tr in together], init=True,
-                     marginals=[tr._marg for tr in together], gradients=[(tr._g_ee, tr._g_ed) for tr in together],
-                     keep_messages=False)
-        for tr in together:
-            stats += tr._statistics_after_sweep(select=sel(tr))
+                tr._sweep_with_gradient()
+        if together:
+            from .batch import sweep_groups
+            sweep_groups([tr.batch for tr in together], [tr.roots[:tr.n_sweeps_run] for tr in together], init=True,
+                         marginals=[tr._marg for tr in together], gradients=[(tr._g_ee, tr._g_ed) for tr in together],
+                         keep_messages=False)
+        stats += self.shared.statistics(select)
 
 
 class TiDirTrainer:
@@ -609,9 +685,8 @@ class TiDirTrainer:
             self._mb_of = torch.zeros(max(self.n_total, 1), dtype=torch.int32, device=dev)
             self._m_dev = torch.zeros(1, dtype=torch.int32, device=dev)
             self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
-            for key, tr in self.trainers.items():
-                pos = np.array([lo + r['index'] for r in self.buckets[key]['rows']], dtype=np.int64)
-                tr._file_pos = torch.from_numpy(pos).to(dev)
+            pos = [lo + r['index'] for key in self.trainers for r in self.buckets[key]['rows']]      # (bucket order = the set's instance order)
+            self._file_pos = torch.from_numpy(np.array(pos, dtype=np.int64)).to(dev)
 
     # ---- parameters -----------------------------------------------------------------------------
     def load_params(self, path):
@@ -700,8 +775,7 @@ class TiDirTrainer:
             self._mgraph.replay()
             return self.stats
         self.stats.zero_()
-        self._full.statistics_into(self.stats, self.grouped_sweeps,
-                                   select_of=lambda tr: torch.index_select(self._mb_of, 0, tr._file_pos) == self._m_dev)
+        self._full.statistics_into(self.stats, self.grouped_sweeps, select=torch.index_select(self._mb_of, 0, self._file_pos) == self._m_dev)
         return self.stats
 
     def capture_masked(self):

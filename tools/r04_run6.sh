@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 run 6: masked minibatches + the bench line's train_epoch object; K4 in the trainer's layout
 export TMPDIR=/tmp
-T=r04h
+T=r04i
 timeout -k 10 900 python3 -m pytest tests/test_gpu_gradient.py -m gpu -x -q > gpurun_out/${T}_gpu_tests.log 2>&1
 echo "pytest rc=$?"; tail -4 gpurun_out/${T}_gpu_tests.log
 timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${T}_bench_user_k3_b8192.json 2> gpurun_out/${T}_bench.err

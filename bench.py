@@ -476,17 +476,16 @@ def main():
     def step(i=None):
         if i is not None:
             ev[i][0].record()
-        fb.sweep(roots, init=True, marginals=marg, keep_messages=not a.no_writeback)   # initialize + marginal read-out fused into the launch
-        if i is not None:
-            ev[i][1].record()
         k = step_no[0] & 1
         step_no[0] += 1
         if pending[k] is not None:
             pending[k].wait()               # the all-reduce issued two steps ago (long finished)
-        # get_posterior_probs of every graph and their batch total (train_mp.py:400, 405-411) in one launch,
-        # written straight into the statistics buffer this step reduces
-        _ffi.check(_ffi.lib.mlbp_log_posterior_sum_f64(marg.data_ptr(), labels_d.data_ptr(), B, topo.n_vars, X,
-                                                       lp.data_ptr(), stats[k].data_ptr(), _stream_ptr(dev)))
+        # initialize + marginal read-out fused into the launch; get_posterior_probs of every graph and their batch total
+        # (train_mp.py:400, 405-411) ride on the call too -- the fix-up pass behind the fast kernel takes them -- and land
+        # straight in the statistics buffer this step reduces
+        fb.sweep(roots, init=True, marginals=marg, keep_messages=not a.no_writeback, posterior=(labels_d, lp, stats[k][:1]))
+        if i is not None:
+            ev[i][1].record()
         if world > 1:                       # the outer-loop reduction of train_mp.py:405-424: one per step
             pending[k] = dist.all_reduce(stats[k], async_op=True)
 
@@ -635,7 +634,18 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         iters_per_s = world * (B / 8192.0) * sweeps * a.steps / elapsed
-        sweep_ms = sorted(s.elapsed_time(e) for s, e in ev)
+        # the dominant kernel's launch time for the roofline: the sweep call ALONE (fast kernel + its fix-up pass, as in every round's
+        # record), HIP events on the launch stream, K launches right behind the timed windows -- the step's own call also carries the
+        # log-posteriors, which are not that kernel's bytes
+        rev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+        for _ in range(3):
+            fb.sweep(roots, init=True, marginals=marg, keep_messages=not a.no_writeback)
+        for s_ev, e_ev in rev:
+            s_ev.record()
+            fb.sweep(roots, init=True, marginals=marg, keep_messages=not a.no_writeback)
+            e_ev.record()
+        torch.cuda.synchronize()
+        sweep_ms = sorted(s_ev.elapsed_time(e_ev) for s_ev, e_ev in rev)
         avg_ms = sum(sweep_ms) / len(sweep_ms)
         table_elem = 4 if a.workload.endswith('_f32') else 8
         alg_bytes = algorithmic_bytes_per_graph(topo, roots, X, table_elem=table_elem) * B

@@ -176,6 +176,16 @@ int mlbp_program_status(const mlbp_program* p);
  * ------------------------------------------------------------------------------------------- */
 struct mlbp_gradient_args;   /* defined below */
 
+/* FactorGraph.get_posterior_probs of every graph behind the sweeps of the same call (train_mp.py:381-400 calls them back to
+ * back): out[b] = sum_v log(marginals[b][v][labels[b][v]]), -inf replaced by -99.99 (LBP.py:247-259); *sum_out = sum_b out[b]
+ * in a fixed order.  On the fast X = 64 paths the fix-up launch takes it (no launch of its own); elsewhere it is
+ * mlbp_log_posterior_sum_f64 enqueued behind the sweeps. */
+typedef struct mlbp_posterior_args {
+  const int32_t* labels;   /* device [B][n_vars] */
+  double* out;             /* device [B]         */
+  double* sum_out;         /* device [1] or NULL */
+} mlbp_posterior_args;
+
 typedef struct mlbp_sweep_args {
   int32_t B;                  /* graphs                                                           */
   int32_t X;                  /* states per variable (len(v.domain))                              */
@@ -213,6 +223,9 @@ typedef struct mlbp_sweep_args {
   const float* pair_tables_f32;
                               /* device [n_pair_tables][X][X] float32, read instead of pair_tables
                                  when MLBP_SWEEP_PAIR_TABLES_F32 is set                             */
+  const mlbp_posterior_args* posterior;
+                              /* HOST pointer or NULL: the log-posteriors (and their batch sum) of the call;
+                                 needs `marginals`                                                   */
 } mlbp_sweep_args;
 
 /* flags: the caller states that pair_tab[b][p] is the same for every graph b (the reference's own

@@ -48,12 +48,16 @@ class PotentialsJob(C.Structure):
                 ('expect', C.c_void_p), ('expect_stride', C.c_int64)]
 
 
+class PosteriorArgs(C.Structure):
+    _fields_ = [('labels', C.c_void_p), ('out', C.c_void_p), ('sum_out', C.c_void_p)]
+
+
 class SweepArgs(C.Structure):
     _fields_ = [('B', C.c_int32), ('X', C.c_int32), ('n_pair_tables', C.c_int32),
                 ('n_unary_tables', C.c_int32), ('pair_tables', C.c_void_p), ('pair_tab', C.c_void_p),
                 ('unary_tables', C.c_void_p), ('unary_tab', C.c_void_p), ('msgs', C.c_void_p),
                 ('normalize_messages', C.c_int32), ('init_messages', C.c_int32), ('marginals', C.c_void_p), ('gradient', C.c_void_p),
-                ('flags', C.c_int32), ('pair_tab_host', C.c_void_p), ('pair_tables_f32', C.c_void_p)]
+                ('flags', C.c_int32), ('pair_tab_host', C.c_void_p), ('pair_tables_f32', C.c_void_p), ('posterior', C.c_void_p)]
 
 
 SWEEP_SHARED_PAIR_TABLES = 1      # include/mlbp.h MLBP_SWEEP_*

@@ -171,7 +171,7 @@ class FactorGraphBatch:
                 self._programs[key] = Program(self.topo, key, max_graphs=self.B)
         return self._programs[key]
 
-    def sweep(self, roots, init=False, marginals=None, gradient=None, keep_messages=True, skip_unchanged=None, _collect=None):
+    def sweep(self, roots, init=False, marginals=None, gradient=None, keep_messages=True, skip_unchanged=None, posterior=None, _collect=None):
         """Runs len(roots) sweeps, sweep s rooted at variable id roots[s], on every graph, in one
         launch.  init=True starts from uniform messages (initialize() fused into the launch);
         marginals: optional [B][n_vars][X] device tensor that receives every variable's marginal
@@ -179,7 +179,10 @@ class FactorGraphBatch:
         (out_ee [B][F_ee], out_ed [B][F_ed]) device tensors that receive the per-graph gradients
         (set_features / set_observations first), fused into the launch when the kernel allows;
         keep_messages=False lets a launch whose read-outs (marginals, gradient) are fused skip the write-back of
-        self.msgs (their contents are then undefined); skip_unchanged (default: self.skip_unchanged, False) drops the
+        self.msgs (their contents are then undefined); posterior: optional (labels int32 [B][n_vars], out [B], sum_out [1] or
+        None) device tensors -- get_posterior_probs of every graph (LBP.py:247-259) and their batch sum behind the sweeps of
+        the same call (needs `marginals`; on the fast X = 64 paths the fix-up launch takes it);
+        skip_unchanged (default: self.skip_unchanged, False) drops the
         updates of the root sequence that would recompute a message from unchanged inputs (MLBP_SWEEP_SKIP_UNCHANGED:
         same output bits, fewer updates)."""
         prog = self.program(roots)
@@ -222,6 +225,13 @@ class FactorGraphBatch:
         if gradient is not None:
             ga = self._gradient_args(*gradient)
             a.gradient = C.addressof(ga)
+        if posterior is not None:
+            lab, out, tot = posterior
+            if marginals is None or lab.dtype != torch.int32 or tuple(lab.shape) != (self.B, self.topo.n_vars) or out.numel() < self.B:
+                raise ValueError('posterior needs marginals, int32 labels [B][n_vars] and an output of B doubles')
+            pa = _ffi.PosteriorArgs()
+            pa.labels, pa.out, pa.sum_out = lab.data_ptr(), out.data_ptr(), None if tot is None else tot.data_ptr()
+            a.posterior = C.addressof(pa)
         if _collect is not None:                  # sweep_groups(): gather instead of launching
             _collect.append((prog, a, gradient and ga))
             return prog

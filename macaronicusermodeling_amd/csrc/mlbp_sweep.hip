@@ -119,7 +119,23 @@ __device__ __forceinline__ void marginals_from_lds_x64(const SweepDev& d, const 
 using mlbp::FOP_UNARY; using mlbp::FOP_PAIR_TM; using mlbp::FOP_PAIR_MT; using mlbp::FOP_VAR;
 using mlbp::FOP_VAR_PAIR_TM; using mlbp::FOP_VAR_PAIR_MT; using mlbp::FOP_BUNDLED;
 
+constexpr int LP_MAX_BLOCKS = 4096;
+constexpr int LP_WG = 256;
+__device__ double g_lp_partials[LP_MAX_BLOCKS];
+__device__ unsigned g_lp_done[2] = {0, 0};
+
+// FactorGraph.get_posterior_probs (LBP.py:247-259) behind the sweeps of the same call (train_mp.py:381-400 calls one after the
+// other): the fix-up pass, which walks every graph's flag anyway, also takes the log-posteriors and their batch sum.
+struct PosteriorDev {
+  const int32_t* labels;   // [B][n_vars] or NULL (off)
+  double* out;             // [B]
+  double* sum_out;         // [1] or NULL
+  unsigned generation;     // of the batch sum's arrival counter (see log_posterior_kernel)
+  int32_t pad_;
+};
+
 struct FusedDev {
+  PosteriorDev post;
   const uint8_t* only;     // when non-NULL: run only graphs with only[g] != 0 (fix-up pass)
   const int32_t* image;    // fused op headers, source lists, hoist list, constant-product lists (one block)
   const int32_t* fsweeps;  // [n_sweeps][2]
@@ -582,6 +598,51 @@ __device__ __forceinline__ void sweep_x64_fused_body(const SweepDev& d, const Fu
   if (GRAD && NT > 0) gradient_epilogue_x64<(NT > 0 ? NT : 1)>(d, gf, tab, msg, umsg, upos, red, g);
 }
 
+// Log-posteriors of the block's 64 graphs from the marginals in memory (the fast kernel's, or the ones this workgroup has just
+// redone), and -- sum_out given -- their batch sum in a fixed order: lanes, then the blocks' partials by the last block to
+// arrive (the two-counter protocol of log_posterior_kernel).
+__device__ __forceinline__ void posterior_of_block(const SweepDev& d, const PosteriorDev& p, int base, int n_graphs) {
+  __shared__ double part[WG / 64];
+  __shared__ bool last;
+  __syncthreads();                                   // (the marginals of graphs redone above are this workgroup's own stores)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  double total = 0.0;
+  const int g = base + t;
+  if (t < FIXUP_GRAPHS_PER_WG && g < n_graphs) {
+    for (int v = 0; v < d.n_vars; ++v) {
+      const int lab = p.labels[(size_t)g * d.n_vars + v];
+      if ((unsigned)lab >= 64u) { atomicExch(d.status, 1); continue; }
+      const double lp = log(d.marginals[((size_t)g * d.n_vars + v) * 64 + lab]);
+      total += (lp == -__builtin_huge_val()) ? -99.99 : lp;  // LBP.py:254-256
+    }
+    p.out[g] = total;
+  }
+  if (!p.sum_out) return;
+  if (wave == 0) {
+    const double ws = wave_sum(total);
+    if (lane == 0) {
+      g_lp_partials[blockIdx.x] = ws;
+      __threadfence();
+      if (blockIdx.x == 0) g_lp_done[(p.generation + 1) & 1] = 0;
+      last = atomicAdd(&g_lp_done[p.generation & 1], 1u) == gridDim.x - 1;
+    }
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double acc = 0.0;
+  for (unsigned q = t; q < gridDim.x; q += WG) acc += __builtin_nontemporal_load(&g_lp_partials[q]);
+  const double fs = wave_sum(acc);
+  if (lane == 0) part[wave] = fs;
+  __syncthreads();
+  if (t == 0) {
+    double v = part[0];
+    for (int w = 1; w < WG / 64; ++w) v += part[w];
+    *p.sum_out = v;
+    g_lp_done[p.generation & 1] = 0;
+  }
+}
+
 // One workgroup per graph -- or, as the fix-up pass behind a fast kernel (f.only), one workgroup per 64 graphs that
 // walks their flags and redoes the (normally zero) flagged ones: 128 workgroups instead of 8192 that exit at once.
 template <bool NORM, int NT, bool GRAD>
@@ -600,6 +661,7 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
     sweep_x64_fused_body<NORM, NT, GRAD>(d, f, gf, base + i);
     if (todo) __syncthreads();
   }
+  if (f.only && f.post.labels) posterior_of_block(d, f.post, base, f.n_graphs);
 }
 
 // The fix-up pass for SEVERAL groups of graphs in one launch (mlbp_sweep_groups_f64 behind the shared-table kernels: a
@@ -939,10 +1001,6 @@ __global__ __launch_bounds__(WG) void marginals_kernel(const double* msgs, int n
 // generation number, and every launch also zeroes the one it does not use: a launch that was aborted halfway leaves its counter
 // dirty, the next launch (other counter) cleans it, so it cannot wedge a later one -- without the memset that used to precede
 // every launch (4.6 us of every bench step).
-constexpr int LP_MAX_BLOCKS = 4096;
-constexpr int LP_WG = 256;
-__device__ double g_lp_partials[LP_MAX_BLOCKS];
-__device__ unsigned g_lp_done[2] = {0, 0};
 
 __global__ __launch_bounds__(LP_WG) void log_posterior_kernel(const double* marg, const int32_t* labels, int B, int n_vars, int X,
                                                               double* out, double* sum_out, int32_t* status, unsigned generation) {
@@ -1521,6 +1579,18 @@ static int gradient_behind_sweeps(const mlbp_program* prog, const mlbp_gradient_
   return mlbp_gradient_f64(&g, stream);
 }
 
+static unsigned next_lp_generation() {
+  static std::atomic<unsigned> generation{0};
+  return generation.fetch_add(1u) + 1u;
+}
+
+// mlbp_sweep_args.posterior by its own launch (no fix-up pass took it)
+static int posterior_behind_sweeps(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream) {
+  const mlbp_posterior_args* pa = a->posterior;
+  if (!pa) return MLBP_OK;
+  return mlbp_log_posterior_sum_f64(a->marginals, pa->labels, a->B, prog->n_vars, a->X, pa->out, pa->sum_out, stream);
+}
+
 int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* stream) {
   g_last_fused_gradient = 0;
   if (!prog || !a) return fail(MLBP_EINVAL, "mlbp_sweep_f64: NULL program or args");
@@ -1558,6 +1628,8 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   d.only = nullptr; d.fill_uniform = 0; d.approx_k = 0;
   if (a->marginals && !prog->d_readout)
     return fail(MLBP_EINVAL, "mlbp_sweep_f64: marginals requested but mlbp_program_set_readout was not called");
+  if (a->posterior && (!a->marginals || !a->posterior->labels || !a->posterior->out))
+    return fail(MLBP_EINVAL, "mlbp_sweep_f64: posterior needs marginals, labels and an output array");
   hipStream_t st = (hipStream_t)stream;
   const bool norm = a->normalize_messages != 0;
   const size_t LDS_MAX = 160 * 1024;
@@ -1609,7 +1681,16 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       g_last_kernel = shared_done ? MLBP_KERNEL_SHARED_MFMA : (lean_done ? MLBP_KERNEL_LEAN : MLBP_KERNEL_EXACT);
       g_last_fused_gradient = (grad_fused || grad_flagged_fixup) ? 1 : 0;
       FusedDev f;
+      f.post = PosteriorDev{};
       f.only = (shared_done || lean_done) ? mp->d_bail : nullptr;     // after a fast pass: flagged graphs only
+      // get_posterior_probs of the call: taken by the fix-up pass (it visits every graph's flag anyway); without a fix-up pass
+      // -- the exact kernel on every graph -- by its own launch below
+      const mlbp_posterior_args* pa = a->posterior;
+      const bool post_in_fixup = pa && f.only && norm && (a->B + FIXUP_GRAPHS_PER_WG - 1) / FIXUP_GRAPHS_PER_WG <= LP_MAX_BLOCKS;
+      if (post_in_fixup) {
+        f.post.labels = pa->labels; f.post.out = pa->out; f.post.sum_out = pa->sum_out;
+        f.post.generation = pa->sum_out ? next_lp_generation() : 0u;
+      }
       f.image = prog->d_fops; f.fsweeps = prog->d_fsweeps;
       f.n_fops = prog->n_fops; f.n_psrcs = prog->n_psrcs; f.n_hoist = prog->n_hoist;
       f.n_cprod = prog->n_cprod; f.n_cpw = prog->n_cpw; f.n_ext = n_ext;
@@ -1634,8 +1715,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
         if (int e = gradient_behind_sweeps(prog, ga, stream)) return e;
       }
       if (a->marginals && !norm)
-        return mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
-                                  prog->d_readout + prog->n_vars + 1, 0, a->marginals, stream);
+        if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
+                                       prog->d_readout + prog->n_vars + 1, 0, a->marginals, stream)) return e;
+      if (pa && !post_in_fixup) return posterior_behind_sweeps(prog, a, stream);
       return MLBP_OK;
     }
   }
@@ -1657,8 +1739,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
       if (a->marginals)
         if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
                                        prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;
-      if (a->gradient) return gradient_behind_sweeps(prog, a->gradient, stream);
-      return MLBP_OK;
+      if (a->gradient)
+        if (int e = gradient_behind_sweeps(prog, a->gradient, stream)) return e;
+      return posterior_behind_sweeps(prog, a, stream);
     }
   }
   const bool f32_tables = (a->flags & MLBP_SWEEP_PAIR_TABLES_F32) != 0;
@@ -1700,8 +1783,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
     if (a->marginals)
       if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
                                      prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;
-    if (a->gradient) return gradient_behind_sweeps(prog, a->gradient, stream);
-    return MLBP_OK;
+    if (a->gradient)
+      if (int e = gradient_behind_sweeps(prog, a->gradient, stream)) return e;
+    return posterior_behind_sweeps(prog, a, stream);
   }
   // small state spaces (X < 64): the lean X = 64 kernel on zero-padded vectors and tables; the graphs it flags are redone
   // by the generic kernel below in its fix-up mode
@@ -1729,8 +1813,9 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
   if (a->marginals)
     if (int e = mlbp_marginals_f64(a->msgs, a->B, prog->n_msgs, a->X, prog->n_vars, prog->d_readout,
                                    prog->d_readout + prog->n_vars + 1, norm ? 1 : 0, a->marginals, stream)) return e;
-  if (a->gradient) return gradient_behind_sweeps(prog, a->gradient, stream);
-  return MLBP_OK;
+  if (a->gradient)
+    if (int e = gradient_behind_sweeps(prog, a->gradient, stream)) return e;
+  return posterior_behind_sweeps(prog, a, stream);
 }
 
 // Behind launch_shared_groups: every group's fix-up pass in ONE launch (and, when the call carries gradients, one launch of
@@ -2031,8 +2116,7 @@ int mlbp_log_posterior_sum_f64(const double* marginals, const int32_t* labels, i
     return fail(MLBP_EUNSUPPORTED, "mlbp_log_posterior_sum_f64: at most %d graphs with sum_out", LP_MAX_BLOCKS * LP_WG);
   // the block partials live in one device-wide scratch array: launches on DIFFERENT streams must not overlap.  Every
   // launch has its own generation number (the arrival word restarts with it: see the kernel)
-  static std::atomic<unsigned> generation{0};
-  const unsigned gen = sum_out ? generation.fetch_add(1u) + 1u : 0u;
+  const unsigned gen = sum_out ? next_lp_generation() : 0u;
   hipLaunchKernelGGL(log_posterior_kernel, dim3(blocks), dim3(LP_WG), 0, (hipStream_t)stream, marginals, labels, B, n_vars, X, out,
                      sum_out, status, gen);
   HIP_TRY(hipGetLastError());

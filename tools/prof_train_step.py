@@ -8,7 +8,7 @@ import numpy as np, torch
 import cases as C
 from macaronicusermodeling_amd.train import UserGraphTrainer
 B, X = 8192, 64
-spec = C.user_spec(10, [1, 4, 7], X, 64, seed=1)
+spec = C.user_spec(10, [1, 3, 5, 8], X, 64, seed=2) if '--k4' in sys.argv else C.user_spec(10, [1, 4, 7], X, 64, seed=1)
 from macaronicusermodeling_amd.topology import GraphTopology
 topo = GraphTopology.from_spec(spec)
 inputs = C.make_inputs(spec, 5)

@@ -461,6 +461,15 @@ int mlbp_sum_rows_f64(const double* in, int64_t rows, int32_t cols, double* out,
 int mlbp_sum_rows_cat_f64(const double* in0, int32_t cols0, const double* in1, int32_t cols1, const double* in2,
                           int32_t cols2, int64_t rows, int32_t append_count, double* out, void* stream);
 
+/* The same sums over the rows with key[b] == *key_value only (key: DEVICE int32 [rows]; key_value: DEVICE int32 [1], read by the
+ * launch -- so one captured launch serves every value); with append_count the extra entry holds the NUMBER OF SELECTED rows.
+ * key == NULL: mlbp_sum_rows_cat_f64.  The trainer's minibatches of a resident shard: key = the minibatch each instance belongs
+ * to this epoch, *key_value = the current minibatch (train_mp.py:631-649 updates once per instance; a minibatch of k is its
+ * k instances' steps summed, 405-424). */
+int mlbp_select_sum_rows_cat_f64(const double* in0, int32_t cols0, const double* in1, int32_t cols1, const double* in2,
+                                 int32_t cols2, int64_t rows, const int32_t* key, const int32_t* key_value,
+                                 int32_t append_count, double* out, void* stream);
+
 /* One optimisation step's batch statistics in ONE launch: out = [sum_b grad_en_en[b][:] | sum_b grad_en_de[b][:] |
  * sum_b log-posterior(b) | B], the log-posterior of FactorGraph.get_posterior_probs (LBP.py:247-259: sum_v
  * log marginals[b][v][labels[b][v]], -inf replaced by -99.99) computed on the fly -- what mlbp_log_posterior_f64 followed

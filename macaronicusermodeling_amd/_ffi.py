@@ -113,6 +113,7 @@ SIGNATURES = {
     'mlbp_patch_gradient_f64': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     'mlbp_sum_rows_f64': (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     'mlbp_sum_rows_cat_f64': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _vp, _vp]),
+    'mlbp_select_sum_rows_cat_f64': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _vp, _vp, _i32, _vp, _vp]),
     'mlbp_segment_sum_rows_f64': (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp]),
     'mlbp_step_statistics_f64': (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i64, _vp, _vp, _vp]),
     'mlbp_dense_dot_f64': (C.c_int, [_i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _vp, _i64, _i64,

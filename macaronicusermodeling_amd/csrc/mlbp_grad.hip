@@ -413,6 +413,7 @@ __device__ unsigned g_sum_done = 0;
 struct SumCat {
   const double* in[3]; int cols[3];
   const double* marg; const int32_t* labels; int n_vars, X; double* lp_out; int32_t* status;
+  const int32_t* key; const int32_t* key_value;       // optional selection: only the rows with key[b] == *key_value (both DEVICE)
 };
 
 __global__ __launch_bounds__(WG) void sum_rows_kernel(SumCat cat, int64_t rows, int append_count, double* out) {
@@ -423,7 +424,9 @@ __global__ __launch_bounds__(WG) void sum_rows_kernel(SumCat cat, int64_t rows, 
   const int64_t per = (rows + SUM_PARTS - 1) / SUM_PARTS;
   const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int kv = cat.key ? *cat.key_value : 0;
   int jout = 0;
+  double selected = 0.0;                                       // rows of this thread that passed the selection (first pass counts)
   for (int a = 0; a < 3; ++a) {
     const double* in = cat.in[a];
     const int cols = cat.cols[a];
@@ -444,6 +447,8 @@ __global__ __launch_bounds__(WG) void sum_rows_kernel(SumCat cat, int64_t rows, 
         }
       } else
       for (int64_t b = r0 + threadIdx.x; b < r1; b += WG) {
+        if (cat.key && cat.key[b] != kv) continue;
+        if (a == 0 && j0 == 0) selected += 1.0;
         const double* row = in + b * cols + j0;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -457,6 +462,11 @@ __global__ __launch_bounds__(WG) void sum_rows_kernel(SumCat cat, int64_t rows, 
         }
       jout += nj;
     }
+  }
+  if (cat.key && append_count) {                               // the count column of a selection: the rows that passed
+    const double v = wave_sum(selected);
+    if (lane == 0) part[wave][jout] = v;
+    jout += 1;
   }
   __syncthreads();
   if (threadIdx.x < jout) {
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(WG) void sum_rows_kernel(SumCat cat, int64_t rows, 
     for (int q = 0; q < SUM_PARTS; ++q) acc += __builtin_nontemporal_load(&g_sum_partials[q * 64 + threadIdx.x]);
     out[threadIdx.x] = acc;
   }
-  if (threadIdx.x == 0 && append_count) out[jout] = (double)rows;
+  if (threadIdx.x == 0 && append_count && !cat.key) out[jout] = (double)rows;
   if (threadIdx.x == 0) g_sum_done = 0;                       // ready for the next (stream-ordered) launch
 }
 
@@ -547,23 +557,38 @@ __global__ __launch_bounds__(WG) void step_statistics_kernel(SumCat cat, int64_t
   if (threadIdx.x == 0) { out[NC] = (double)rows; g_sum_done = 0; }
 }
 
-// out[s][j] = sum over the rows b with seg_id[b] == s of in[b][j]: one workgroup per segment, fixed order
-// (thread-strided partial sums, then a tree) -- the per-domain half of batch_sgd_accumulate (train_mp.py:413-415).
+// out[s][j] = sum over the rows b with seg_id[b] == s of in[b][j]: one workgroup per segment, fixed order -- every thread adds
+// the matching rows of its stride with ALL columns of a 16-column chunk in registers (one pass over the rows per chunk, where the
+// first version made one pass and an eight-barrier tree per column), then lanes by DPP, the four waves in order: the per-domain
+// half of batch_sgd_accumulate (train_mp.py:413-415), and the minibatch selection of the trainer's resident shard.
 __global__ __launch_bounds__(WG) void segment_sum_rows_kernel(const double* in, int64_t rows, int cols, const int32_t* seg_id,
                                                               double* out) {
-  __shared__ double part[WG];
-  const int seg = blockIdx.x;
-  for (int j = 0; j < cols; ++j) {
-    double acc = 0.0;
-    for (int64_t b = threadIdx.x; b < rows; b += WG)
-      if (seg_id[b] == seg) acc += in[b * cols + j];
-    part[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = WG / 2; s > 0; s >>= 1) {
-      if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
-      __syncthreads();
+  __shared__ double part[WG / 64][16];
+  const int seg = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j0 = 0; j0 < cols; j0 += 16) {
+    const int nj = cols - j0 < 16 ? cols - j0 : 16;
+    double acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+    for (int64_t b = threadIdx.x; b < rows; b += WG) {
+      if (seg_id[b] != seg) continue;
+      const double* row = in + b * cols + j0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (j < nj) acc[j] += row[j];
     }
-    if (threadIdx.x == 0) out[(size_t)seg * cols + j] = part[0];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nj) {
+        const double v = wave_sum(acc[j]);
+        if (lane == 0) part[wave][j] = v;
+      }
+    __syncthreads();
+    if (threadIdx.x < nj) {
+      double v = part[0][threadIdx.x];
+      for (int w = 1; w < WG / 64; ++w) v += part[w][threadIdx.x];
+      out[(size_t)seg * cols + j0 + threadIdx.x] = v;
+    }
     __syncthreads();
   }
 }
@@ -783,7 +808,17 @@ int mlbp_sum_rows_cat_f64(const double* in0, int32_t cols0, const double* in1, i
   if (int e = need_device()) return e;
   if ((int64_t)cols0 + cols1 + cols2 > 64)
     return fail(MLBP_EUNSUPPORTED, "mlbp_sum_rows: at most 64 columns (got %d)", cols0 + cols1 + cols2);
-  SumCat cat = {{in0, in1, in2}, {cols0, cols1, cols2}, nullptr, nullptr, 0, 0, nullptr, nullptr};
+  return mlbp_select_sum_rows_cat_f64(in0, cols0, in1, cols1, in2, cols2, rows, nullptr, nullptr, append_count, out, stream);
+}
+
+int mlbp_select_sum_rows_cat_f64(const double* in0, int32_t cols0, const double* in1, int32_t cols1, const double* in2, int32_t cols2,
+                                 int64_t rows, const int32_t* key, const int32_t* key_value, int32_t append_count, double* out, void* stream) {
+  if (!in0 || !out || rows <= 0 || cols0 <= 0 || cols1 < 0 || cols2 < 0 || (cols1 > 0 && !in1) || (cols2 > 0 && !in2) || ((key != nullptr) != (key_value != nullptr)))
+    return fail(MLBP_EINVAL, "mlbp_select_sum_rows_cat_f64: bad arguments");
+  if (int e = need_device()) return e;
+  if ((int64_t)cols0 + cols1 + cols2 + 1 > 64)
+    return fail(MLBP_EUNSUPPORTED, "mlbp_sum_rows: at most 63 columns (got %d)", cols0 + cols1 + cols2);
+  SumCat cat = {{in0, in1, in2}, {cols0, cols1, cols2}, nullptr, nullptr, 0, 0, nullptr, nullptr, key, key_value};
   // the partials live in one device-wide scratch array: launches on DIFFERENT streams must not overlap
   hipLaunchKernelGGL(sum_rows_kernel, dim3(SUM_PARTS), dim3(WG), 0, (hipStream_t)stream, cat, rows, append_count ? 1 : 0, out);
   HIP_TRY(hipGetLastError());
@@ -796,7 +831,7 @@ int mlbp_step_statistics_f64(const double* grad_en_en, int32_t F_ee, const doubl
     return fail(MLBP_EINVAL, "mlbp_step_statistics_f64: bad arguments");
   if (F_ee + F_ed + 1 > 64) return fail(MLBP_EUNSUPPORTED, "mlbp_step_statistics_f64: at most 63 feature columns (got %d)", F_ee + F_ed);
   if (int e = need_device()) return e;
-  SumCat cat = {{grad_en_en, grad_en_de, marginals}, {F_ee, F_ed, 1}, marginals, labels, n_vars, X, lp_out, nullptr};
+  SumCat cat = {{grad_en_en, grad_en_de, marginals}, {F_ee, F_ed, 1}, marginals, labels, n_vars, X, lp_out, nullptr, nullptr, nullptr};
   if (int e = status_word(&cat.status)) return e;
   // (the partials live in one device-wide scratch array, as for mlbp_sum_rows_cat_f64)
   if (F_ee == 3 && F_ed == 6) hipLaunchKernelGGL((step_statistics_kernel<3, 6>), dim3(SUM_PARTS), dim3(WG), 0, (hipStream_t)stream, cat, B, out);

@@ -479,15 +479,17 @@ class _SharedTables:
 
     def statistics(self, select=None):
         """[sum g_ee | sum g_ed | sum log-posterior | count] (then the per-domain rows) over every instance of the set -- or over
-        the instances with select[i] set (device bool [n_inst]: a masked minibatch) -- behind the sweeps of all buckets: the
-        planes' gradient share, the log-posteriors of every group and the sums, one launch each."""
+        the instances select = (key, value) picks: key device int32 [n_inst], value device int32 [1], instance i counts when
+        key[i] == value (a masked minibatch) -- behind the sweeps of all buckets: the planes' gradient share, the
+        log-posteriors of every group and the sums, one launch each."""
         st = _stream_ptr(self.trainers[0].device)
         self.patch_gradient()
         _ffi.check(_ffi.lib.mlbp_log_posterior_groups_f64(self._groups.data_ptr(), len(self.trainers), self.n_inst, self.X, self.lp.data_ptr(), st))
         n_stat = self.F_ee + self.F_ed + 2
-        if select is None and not self.n_dom:
-            _ffi.check(_ffi.lib.mlbp_sum_rows_cat_f64(self.g_ee.data_ptr(), self.F_ee, self.g_ed.data_ptr(), self.F_ed, self.lp.data_ptr(), 1,
-                                                      self.n_inst, 1, self.stats_all.data_ptr(), st))
+        if not self.n_dom:
+            key, value = (None, None) if select is None else (select[0].data_ptr(), select[1].data_ptr())
+            _ffi.check(_ffi.lib.mlbp_select_sum_rows_cat_f64(self.g_ee.data_ptr(), self.F_ee, self.g_ed.data_ptr(), self.F_ed, self.lp.data_ptr(), 1,
+                                                             self.n_inst, key, value, 1, self.stats_all.data_ptr(), st))
             return self.stats_all
         r = self.rows
         r[:, :self.F_ee] = self.g_ee
@@ -497,7 +499,7 @@ class _SharedTables:
         nd = max(self.n_dom, 1)
         code = self._dom if self.n_dom else self._seg0
         if select is not None:
-            torch.where(select, code, self._dump, out=self._seg)
+            torch.where(select[0] == select[1], code, self._dump, out=self._seg)
             code = self._seg
         _ffi.check(_ffi.lib.mlbp_segment_sum_rows_f64(r.data_ptr(), self.n_inst, n_stat, code.data_ptr(), nd + 1, self._segsum.data_ptr(), st))
         if self.n_dom:
@@ -687,6 +689,7 @@ class TiDirTrainer:
             self._acc = torch.zeros(2, dtype=torch.float64, device=dev)
             pos = [lo + r['index'] for key in self.trainers for r in self.buckets[key]['rows']]      # (bucket order = the set's instance order)
             self._file_pos = torch.from_numpy(np.array(pos, dtype=np.int64)).to(dev)
+            self._key = torch.zeros(max(len(pos), 1), dtype=torch.int32, device=dev)      # minibatch of each resident instance this epoch
 
     # ---- parameters -----------------------------------------------------------------------------
     def load_params(self, path):
@@ -775,7 +778,7 @@ class TiDirTrainer:
             self._mgraph.replay()
             return self.stats
         self.stats.zero_()
-        self._full.statistics_into(self.stats, self.grouped_sweeps, select=torch.index_select(self._mb_of, 0, self._file_pos) == self._m_dev)
+        self._full.statistics_into(self.stats, self.grouped_sweeps, select=(self._key, self._m_dev))
         return self.stats
 
     def capture_masked(self):
@@ -795,6 +798,7 @@ class TiDirTrainer:
         mb = np.empty(self.n_total, dtype=np.int32)
         mb[order] = np.arange(self.n_total, dtype=np.int64) // self.minibatch
         self._mb_of.copy_(torch.from_numpy(mb))                  # the epoch's permutation: one upload
+        torch.index_select(self._mb_of, 0, self._file_pos, out=self._key)
         self._acc.zero_()
         for m in range((self.n_total + self.minibatch - 1) // self.minibatch):
             self._m_dev.fill_(m)

@@ -816,8 +816,8 @@ int mlbp_select_sum_rows_cat_f64(const double* in0, int32_t cols0, const double*
   if (!in0 || !out || rows <= 0 || cols0 <= 0 || cols1 < 0 || cols2 < 0 || (cols1 > 0 && !in1) || (cols2 > 0 && !in2) || ((key != nullptr) != (key_value != nullptr)))
     return fail(MLBP_EINVAL, "mlbp_select_sum_rows_cat_f64: bad arguments");
   if (int e = need_device()) return e;
-  if ((int64_t)cols0 + cols1 + cols2 + 1 > 64)
-    return fail(MLBP_EUNSUPPORTED, "mlbp_sum_rows: at most 63 columns (got %d)", cols0 + cols1 + cols2);
+  if ((int64_t)cols0 + cols1 + cols2 + (append_count ? 1 : 0) > 64)
+    return fail(MLBP_EUNSUPPORTED, "mlbp_sum_rows: at most 64 columns, the appended count included (got %d)", cols0 + cols1 + cols2);
   SumCat cat = {{in0, in1, in2}, {cols0, cols1, cols2}, nullptr, nullptr, 0, 0, nullptr, nullptr, key, key_value};
   // the partials live in one device-wide scratch array: launches on DIFFERENT streams must not overlap
   hipLaunchKernelGGL(sum_rows_kernel, dim3(SUM_PARTS), dim3(WG), 0, (hipStream_t)stream, cat, rows, append_count ? 1 : 0, out);

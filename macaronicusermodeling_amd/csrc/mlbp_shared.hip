@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <type_traits>
@@ -214,18 +216,30 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
     for (int q = 0; q < 8; ++q) if (writes(x, y[8 + q]) || writes(y, x[8 + q])) return false;
     return !(writes(x, y[2]) || writes(x, y[3]));
   };
+  std::vector<int> pairing;                                      // per bundle: its members' indices (the second -1: alone)
   for (int i = 0; i < n_ops;) {
     const int32_t* x = &mem[(size_t)i * MW];
     pack_member(x);
     if (i + 1 < n_ops && disjoint(x, &mem[(size_t)(i + 1) * MW])) {
       pack_member(&mem[(size_t)(i + 1) * MW]);
+      pairing.push_back(i); pairing.push_back(i + 1);
       i += 2;
     } else {
       pack_member(nop);
+      pairing.push_back(i); pairing.push_back(-1);
       i += 1;
     }
   }
   out.n_bundles = (int)bundles.size() / 8;
+  if (getenv("MLBP_DEBUG_SHARED_PROGRAM")) {                     // diagnostic: the member records, one line each
+    for (int i = 0; i < n_ops; ++i) {
+      const int32_t* m = &mem[(size_t)i * MW];
+      fprintf(stderr, "member %2d: flags 0x%03x pair %d dst %d ptile %d pslot %d src", i, m[0], m[1], m[2], m[3], m[4]);
+      for (int q = 0; q < 8; ++q) if (m[8 + q] >= 0 || q == 0) fprintf(stderr, " %d", m[8 + q]);
+      fprintf(stderr, "\n");
+    }
+    fprintf(stderr, "n_live %d n_bundles %d n_cprod %d\n", out.n_live, out.n_bundles, fp.n_cprod);
+  }
   pack_member(nop); pack_member(nop);                            // the kernel prefetches one bundle past the end
   // constant products, flattened: {unary factor, message slot, tile, 1 = first | 2 = last of its product}
   std::vector<int32_t> ent;
@@ -268,6 +282,110 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
     out.image.push_back((int32_t)w);
   }
   for (int q = 0; q < 16; ++q) out.image.push_back(0);
+  // ---- product-fused form.  When every variable update of the program multiplies at most one constant product and one
+  // factor->variable message (variables with at most two pairwise factors: K2, K3, chains, rings), the message F->X is only
+  // ever read as the product  c_X (.) m_{F->X}  (LBP.py:377-389).  The PRODUCER then stores that product -- its 16 rows of the
+  // D fragment times its 16 rows of c_X: four multiplications -- and every contraction reads ONE tile straight into the matrix
+  // cores: no products, half the tile reads, and (float64 vector operations share the matrix cores' pipe) some fifty
+  // operations per update off the dependent chain.  The raw result of the LAST update of each slot goes to a scratch tile
+  // in memory for the read-out.  Member record, 4 words:
+  //   [0] flags | pair slot << 16: 1 contraction, 2 m^T.T, 8 the input S, normalised, is this variable->factor slot's last value:
+  //       to memory, 16 no contraction, 32 last update of the destination slot: raw result to stash [2] >> 8 (when the call writes
+  //       the messages back), 64 store the product
+  //   [1] destination tile | S tile << 8 (0xFF: the uniform vector) | message slot of S << 16   [2] constant-product tile the
+  //       result is multiplied by (0xFF none) | stash index << 8
+  {
+    std::vector<char> is_c(out.n_live, 0);
+    std::vector<int> prod_of_tile(out.n_live, -1);
+    for (int k = 0; k < fp.n_cprod; ++k) { is_c[out.live_of_slot[n_msgs + 1 + k]] = 1; prod_of_tile[out.live_of_slot[n_msgs + 1 + k]] = k; }
+    bool okp = out.max_sources <= 2;
+    std::vector<int> cp(out.n_live, -2);                          // constant product a message tile is read with: -2 never read, -1 none
+    std::vector<int> s_of(n_ops, 0xFF), last_writer(out.n_live, -1);
+    for (int i = 0; i < n_ops && okp; ++i) {
+      const int32_t* m = &mem[(size_t)i * MW];
+      const int n = (m[0] >> 8) & 15;
+      if (m[0] & 4) okp = false;                                  // a variable->factor message kept as a tile of its own
+      int c = -1, mt = -1, nc = 0, nm = 0;
+      for (int q = 0; q < n; ++q) {
+        const int tl = m[8 + q];
+        if (tl < 0) continue;
+        if (is_c[tl]) { c = tl; ++nc; } else { mt = tl; ++nm; }
+      }
+      if (nc > 1 || nm > 1) okp = false;
+      if (nm) {
+        if (cp[mt] == -2) cp[mt] = c; else if (cp[mt] != c) okp = false;
+        s_of[i] = mt;
+      } else if (nc) {
+        s_of[i] = c;
+      }
+      if ((m[0] & 1) && m[2] >= 0) { if (is_c[m[2]]) okp = false; last_writer[m[2]] = i; }
+    }
+    // every stored product needs its constant product (a variable without unary factors: the general form), and a member whose
+    // input is still the uniform vector reads a tile nothing touches before a later bundle writes it, filled by the prologue
+    for (int tl = 0; tl < out.n_live && okp; ++tl)
+      if (!is_c[tl] && cp[tl] == -1) okp = false;
+    std::vector<int32_t> uinit;                                   // tiles the prologue fills with the uniform vector
+    if (okp) {
+      std::vector<int> bundle_of(n_ops, 0), first_touch(out.n_live, n_ops + 1);
+      for (size_t b = 0; b < pairing.size(); b += 2) { bundle_of[pairing[b]] = (int)b / 2; if (pairing[b + 1] >= 0) bundle_of[pairing[b + 1]] = (int)b / 2; }
+      for (int i = n_ops - 1; i >= 0; --i) {
+        const int32_t* m = &mem[(size_t)i * MW];
+        if ((m[0] & 1) && m[2] >= 0) first_touch[m[2]] = bundle_of[i];
+        if (s_of[i] != 0xFF) first_touch[s_of[i]] = bundle_of[i];
+      }
+      for (int q : init_tiles) first_touch[q] = -1;              // (holds c (.) uniform from the start)
+      for (int i = 0; i < n_ops && okp; ++i) {
+        if (s_of[i] != 0xFF) continue;
+        int pick = -1;
+        for (int tl = 0; tl < out.n_live && pick < 0; ++tl)
+          if (!is_c[tl] && first_touch[tl] > bundle_of[i]) pick = tl;
+        if (pick < 0) { okp = false; break; }
+        s_of[i] = pick;
+        if (std::find(uinit.begin(), uinit.end(), pick) == uinit.end()) uinit.push_back(pick);
+      }
+    }
+    out.pf_ok = okp;
+    if (okp) {
+      std::vector<int32_t> stash(out.n_live, -1), pfb, pinit;
+      for (int tl : uinit) { pinit.push_back(tl); pinit.push_back(-1); }
+      for (int tl = 0; tl < out.n_live; ++tl) if (last_writer[tl] >= 0) stash[tl] = out.n_stash++;
+      auto pack_pf = [&](int i) {
+        int32_t w[4] = {0, 0xFFFF, 0xFF, 0};
+        if (i >= 0) {
+          const int32_t* m = &mem[(size_t)i * MW];
+          const int dst = (m[0] & 1) ? m[2] : -1;
+          w[0] = (m[0] & (1 | 2 | 8 | 16)) | (m[1] << 16);
+          if (dst >= 0 && last_writer[dst] == i) w[0] |= 32;
+          if (dst >= 0) w[0] |= 64;                              // (a slot nothing reads as an input is kept for the read-out: the raw result, c absent)
+          w[1] = (dst & 0xFF) | ((s_of[i] & 0xFF) << 8) | (m[4] << 16);
+          w[2] = ((dst >= 0 && cp[dst] >= 0 ? cp[dst] : 0xFF) & 0xFF) | ((dst >= 0 ? stash[dst] : 0) << 8);
+        }
+        pfb.insert(pfb.end(), w, w + 4);
+      };
+      for (size_t b = 0; b < pairing.size(); b += 2) { pack_pf(pairing[b]); pack_pf(pairing[b + 1]); }
+      pack_pf(-1); pack_pf(-1);
+      // message tiles read before the program writes them: c (.) uniform, i.e. a copy of the constant product (or uniform)
+      for (int q = 0; q < (int)init_tiles.size(); ++q) {
+        const int tl = init_tiles[q];
+        if (is_c[tl]) continue;
+        pinit.push_back(tl); pinit.push_back(cp[tl] >= 0 ? prod_of_tile[cp[tl]] : -1);
+      }
+      out.n_pinit = (int)pinit.size() / 2;
+      out.off_pfb = (int)out.image.size();
+      out.image.insert(out.image.end(), pfb.begin(), pfb.end());
+      out.off_stash = (int)out.image.size();
+      out.image.insert(out.image.end(), stash.begin(), stash.end());
+      for (int tl = 0; tl < out.n_live; ++tl) out.image.push_back(cp[tl] >= 0 ? 1 : 0);       // [n_live] behind it: the tile holds c (.) message (else the message)
+      out.off_pinit = (int)out.image.size();
+      out.image.insert(out.image.end(), pinit.begin(), pinit.end());
+      for (int q = 0; q < 16; ++q) out.image.push_back(0);
+      if (getenv("MLBP_DEBUG_SHARED_PROGRAM")) {
+        for (size_t i = 0; i + 3 < pfb.size(); i += 4) fprintf(stderr, "pf member: flags 0x%02x pair %d dst %d S %d slot %d c %d stash %d\n", pfb[i] & 0xFF,
+                                                                pfb[i] >> 16, pfb[i + 1] & 0xFF, (pfb[i + 1] >> 8) & 0xFF, pfb[i + 1] >> 16, pfb[i + 2] & 0xFF, pfb[i + 2] >> 8);
+        fprintf(stderr, "pf: n_stash %d n_pinit %d\n", out.n_stash, out.n_pinit);
+      }
+    }
+  }
   out.why = "";
   out.ok = true;
 }
@@ -398,6 +516,10 @@ struct SharedDev {
   double* spill;                // [workgroups][n_live - n_res][64][16] or NULL
   const double* tfrag;          // [n_pair_tables][2][4096] A fragments of every table (only when there are <= FRAG_TABLES), or NULL
   int32_t off_written, pad_;
+  // product-fused form (SharedProgram::pf_ok): its bundle records, the stash index of every tile, the tiles that start as a copy of
+  // a constant product; stash [workgroups][n_stash][64][16]: the raw result of the last update of every slot
+  int32_t off_pfb, off_stash, off_pinit, n_pinit, n_stash, pad2_;
+  double* stash;
   SharedGradDev gr;
 };
 
@@ -417,11 +539,13 @@ __device__ int g_sh_ablate = 0;      // timing experiments of tools/stamp_shared
 #define STAMP_START
 #define STAMP(i)
 #define STAMP_FLUSH
+#define STAMP_FLUSH_GRAD
 #else
 #define STAMP_DECL unsigned long long _t0 = 0, _ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define STAMP_START { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t0) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #define STAMP(i) { unsigned long long _t1; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t1) :: "memory"); __builtin_amdgcn_sched_barrier(0); _ph[i] += _t1 - _t0; _t0 = _t1; }
-#define STAMP_FLUSH if (g_sh_stamp && blockIdx.x < 64 && (threadIdx.x & 63) == 0) { for (int _i = 0; _i < 12; ++_i) g_sh_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 12 + _i] = _ph[_i]; }
+#define STAMP_FLUSH if (g_sh_stamp && blockIdx.x < 64 && (threadIdx.x & 63) == 0) { for (int _i = 0; _i < 8; ++_i) g_sh_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 12 + _i] = _ph[_i]; }
+#define STAMP_FLUSH_GRAD if (g_sh_stamp && blockIdx.x < 64 && (threadIdx.x & 63) == 0) { for (int _i = 8; _i < 12; ++_i) g_sh_stamp[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 12 + _i] = _ph[_i]; }
 #endif
 #else
 #define ABL(bit) 0
@@ -430,6 +554,7 @@ __device__ int g_sh_ablate = 0;      // timing experiments of tools/stamp_shared
 #define STAMP_START
 #define STAMP(i)
 #define STAMP_FLUSH
+#define STAMP_FLUSH_GRAD
 #endif
 
 // Message tiles: 64 states x 16 graphs as [k-step pair sp][lane][2] doubles -- lane l = (state & 3) * 16 + graph, k-step
@@ -579,7 +704,8 @@ __global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, co
           if (flags & 2) {
             const double sum = wave_sum(cur);
             flagged |= !total_ok(sum) || __any(key > KEY_LIMIT);
-            ptile_lds[(size_t)k_out * TILE + tile_index(lane, col)] = cur * __builtin_amdgcn_rcp(sum);
+            // (a true division: the product-fused sweep kernel takes this tile's total to be 1 when it writes the tile out as a message)
+            ptile_lds[(size_t)k_out * TILE + tile_index(lane, col)] = cur * (1.0 / sum);
             ++k_out;
           }
         }
@@ -628,6 +754,185 @@ __device__ __forceinline__ Words16 sload16(const int32_t* p) {
 __device__ __forceinline__ int half_of(int mode, int sel) { return ((mode == 0 ? 0x6 : (mode == 1 ? 0xC : 0xA)) >> sel) & 1; }
 __device__ __forceinline__ int index_in_half(int mode, int sel) { return ((mode == 0 ? 0xC : (mode == 1 ? 0xA : 0xC)) >> sel) & 1; }
 
+// The gradient epilogue of the sweep kernel (below) as a function of its own -- NOT inlined: the register allocator otherwise
+// carries what this code needs across the sweeps' main loop, whose fragments then go to scratch inside the MFMA sequences.
+template <typename Dev>
+__device__ __attribute__((noinline)) void shared_gradient_epilogue(Dev& d, const int wg) {
+  extern __shared__ double lds[];
+  double* tiles = lds;
+  double* tot = tiles + (size_t)d.n_res * TILE;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int half = wave >> 2, rb = wave & 3;
+  const int g0 = wg * G;
+  const double uniform = 1.0 / 64.0;
+  const const_i32p img = as_const(d.image);
+  const const_i32p row0 = as_const(d.pair_tab + (size_t)g0 * d.P);
+  double fr0[16], fr1[16];
+  STAMP_DECL
+  ABL_DECL
+  STAMP_START
+  __syncthreads();
+  const int NP = min(4, (d.n_res - 1) >> 1);                     // factors per pass: two tiles each, one tile of partial sums
+  double* red = tiles + (size_t)2 * NP * TILE;                   // [factor][k][row block][graph]
+  double* pc = tot;                                              // [factor][graph][3] per-graph terms of a pass (the totals are spent)
+  double out3[3] = {0.0, 0.0, 0.0};                              // thread t < 16: graph g0 + t
+  for (int p0 = 0; p0 < d.P; p0 += NP) {
+    const int np = min(NP, d.P - p0);
+    // thread (factor t >> 4, graph t & 15) of the first np * 16: the factor's labels ...
+    const int lp = p0 + (t >> 4), lg = g0 + (t & 15);
+    const bool l_on = t < np * G && lg < d.B;
+    int m0 = 0, m1 = 0;
+    if (l_on) { m0 = d.gr.pair_label[((size_t)lg * d.P + lp) * 2]; m1 = d.gr.pair_label[((size_t)lg * d.P + lp) * 2 + 1]; }
+    // ... the messages: wave w takes rows i = w + 8 j of the pass's np * 32 (factor i >> 5, side (i >> 4) & 1, graph i & 15), one
+    // 512-byte row each.  The slots (and whether the program ever writes them) come through the scalar cache -- a vector
+    // load here would be one more round of memory latency in front of the rows --, then all the rows are requested
+    // before the first is used.  The half's first A fragment goes out ahead of them.
+    const const_i32p cs = as_const(d.gr.c_slot), rs = as_const(d.gr.r_slot), pf = as_const(d.gr.plane_flags);
+    int slots[8];                                                 // tile q = 2 * factor + side: its message slot, or -1
+#pragma unroll
+    for (int q = 0; q < 8; ++q) slots[q] = q < 2 * np ? ((q & 1) ? cs[p0 + (q >> 1)] : rs[p0 + (q >> 1)]) : -1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool in = (unsigned)slots[q] < (unsigned)d.n_msgs;
+      const int w = img[d.off_written + (in ? slots[q] >> 5 : 0)];
+      if (!in || !((w >> (slots[q] & 31)) & 1)) slots[q] = -1;
+    }
+    const int n_items = 2 * np;
+    auto key = [&](int j) { const int pp = j % np; return row0[p0 + pp] * 2 + (as_const(d.gr.pair_phi)[p0 + pp] ? 1 : 0); };
+    auto fetchw = [&](double (&fr)[16], int j) {
+      const int k = 2 * (j / np) + half;
+      const double* W = d.gr.wfrag + ((size_t)key(j) * 4 + k) * 4096 + rb * 1024 + lane;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) fr[s] = ABL(256) ? 0.5 : W[64 * s];
+    };
+    auto run_end = [&](int j) {                                  // first item behind the run that starts at j
+      int e = j + 1;
+      while (e < n_items && e % np != 0 && key(e) == key(e - 1)) ++e;
+      return e;
+    };
+    // an item whose feature plane is all zeros or all ones needs no contraction (the per-graph terms below use 0 resp. Z)
+    auto needed = [&](int j) { const int k = 2 * (j / np) + half; return k == 3 || pf[(key(j) & 1) * 4 + k] == 0; };
+    auto next_run = [&](int j) {                                  // start of the first needed run at or behind j
+      while (j < n_items && !needed(j)) j = run_end(j);
+      return j;
+    };
+    const int j_first = next_run(0);
+    if (j_first < n_items) fetchw(fr0, j_first);
+    double sv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {                                // row i = wave + 8 j: tile i >> 4 = j >> 1, graph wave + 8 (j & 1)
+      sv[j] = uniform;                                            // never updated: still uniform (LBP.py:211-216)
+      if (j < 4 * np && slots[j >> 1] >= 0 && !ABL(32)) {
+        const int ggc = min(g0 + wave + 8 * (j & 1), d.B - 1);
+        sv[j] = d.msgs[((size_t)ggc * d.n_msgs + slots[j >> 1]) * 64 + lane];
+      }
+    }
+    // ... and the label's feature row (the labels have arrived, the messages are still on their way)
+    double lf[3] = {0.0, 0.0, 0.0};
+    const bool l_ok = l_on && (unsigned)m0 < 64u && (unsigned)m1 < 64u;
+    if (l_on && !l_ok) atomicExch(d.status, 1);
+    if (l_ok) {
+      const double* ph = d.gr.phi[d.gr.pair_phi[lp] ? 1 : 0] + ((size_t)m0 * 64 + m1) * 3;
+      lf[0] = ph[0]; lf[1] = ph[1]; lf[2] = ph[2];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < 4 * np) {
+        tiles[(size_t)(j >> 1) * TILE + tile_index(lane, wave + 8 * (j & 1))] = sv[j];
+      }
+    __syncthreads();
+    STAMP(8)
+    // this half's items in k-major order: j = kk * np + pp  ->  factor p0 + pp, feature k = 2 kk + half.  Consecutive
+    // factors that read the same (table, feature tensor) share one A fragment: it is fetched once per run (a K3 user
+    // graph's three factors are one run: 2 fetches per wave instead of 6), the next run's while this run multiplies; two
+    // items of a run go through the matrix pipe interleaved (two independent accumulation chains).
+    auto finish = [&](const double4_t& acc, int pp, int k) {
+      const double2* ct = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp + 1) * TILE) + 128 * rb + lane;
+      const double2 c0 = ct[0], c1 = ct[64];
+      const double part = column_sum((c0.x * acc.x + c0.y * acc.y) + (c1.x * acc.z + c1.y * acc.w));
+      if ((lane >> 4) == 0) red[((pp * 4 + k) * 4 + rb) * G + (lane & 15)] = part;
+    };
+    auto item = [&](const double (&fr)[16], int j) {
+      const int pp = j % np, k = 2 * (j / np) + half;
+      const double2* rt = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp) * TILE) + lane;
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const double2 v0 = rt[128 * h], v1 = rt[128 * h + 64];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h], v0.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 1], v0.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 2], v1.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 3], v1.y, acc, 0, 0, 0);
+      }
+      finish(acc, pp, k);
+    };
+    auto item2 = [&](const double (&fr)[16], int j) {            // items j and j + 1: the same fragment, the next factor
+      const int pp = j % np, k = 2 * (j / np) + half;
+      const double2* rt = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp) * TILE) + lane;
+      double4_t acc = {0.0, 0.0, 0.0, 0.0}, bcc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const double2 v0 = rt[128 * h], v1 = rt[128 * h + 64], w0 = rt[2 * (TILE / 2) + 128 * h], w1 = rt[2 * (TILE / 2) + 128 * h + 64];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h], v0.x, acc, 0, 0, 0);
+        bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h], w0.x, bcc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 1], v0.y, acc, 0, 0, 0);
+        bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 1], w0.y, bcc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 2], v1.x, acc, 0, 0, 0);
+        bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 2], w1.x, bcc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 3], v1.y, acc, 0, 0, 0);
+        bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 3], w1.y, bcc, 0, 0, 0);
+      }
+      finish(acc, pp, k);
+      finish(bcc, pp + 1, k);
+    };
+    for (int j = ABL(64) ? n_items : j_first; j < n_items;) {
+      int e = run_end(j), nx = next_run(e);
+      if (nx < n_items) fetchw(fr1, nx);
+#pragma unroll 1
+      for (; j + 1 < e; j += 2) item2(fr0, j);
+      if (j < e) item(fr0, j);
+      j = nx;
+      if (j >= n_items) break;
+      e = run_end(j); nx = next_run(e);
+      if (nx < n_items) fetchw(fr0, nx);
+#pragma unroll 1
+      for (; j + 1 < e; j += 2) item2(fr1, j);
+      if (j < e) item(fr1, j);
+      j = nx;
+    }
+    __syncthreads();
+    STAMP(9)
+    if (t < np * G) {                                            // label features minus expected features, per (factor, graph)
+      const double* rp = red + (size_t)(t >> 4) * 16 * G + (t & 15);
+      const double Z = (rp[(12 + 0) * G] + rp[(12 + 1) * G]) + (rp[(12 + 2) * G] + rp[(12 + 3) * G]);
+      const int wh = d.gr.pair_phi[p0 + (t >> 4)] ? 1 : 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int flag = d.gr.plane_flags[wh * 4 + k];
+        const double S = (rp[(4 * k + 0) * G] + rp[(4 * k + 1) * G]) + (rp[(4 * k + 2) * G] + rp[(4 * k + 3) * G]);
+        // expected feature: S / Z; a zero plane 0, the bias plane the normalised belief's total, 1  (au.normalize: zero-sum -> 0)
+        const double ex = Z > 0.0 ? (flag == 0 ? S / Z : (flag == 1 ? 0.0 : 1.0)) : 0.0;
+        pc[t * 3 + k] = l_ok ? lf[k] - ex : 0.0;
+      }
+    }
+    __syncthreads();
+    if (t < G)
+      for (int pp = 0; pp < np; ++pp) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out3[k] += pc[(pp * G + t) * 3 + k];
+      }
+    __syncthreads();
+    STAMP(10)
+  }
+  // the unary factors' terms are in the output already (shared_prepare_kernel: they do not depend on the sweeps)
+  if (t < G && g0 + t < d.B) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.gr.grad_en_en[(size_t)(g0 + t) * 3 + k] += out3[k];
+  }
+  STAMP(11)
+  STAMP_FLUSH_GRAD
+}
+
 // One workgroup = 16 graphs x 8 waves.  Wave w: half h = w >> 2, row block r = w & 3.  Each half keeps TWO of the four
 // (table, orientation) fragment sets in registers (64 VGPRs instead of 128: four waves per SIMD instead of two), and a
 // bundle's two independent updates run side by side, one per half, under one barrier -- the dependent chain of a
@@ -638,8 +943,9 @@ __device__ __forceinline__ int index_in_half(int mode, int sel) { return ((mode 
 // group k's SharedDev, gstart[k] its first workgroup; the workgroup looks its group up and runs as if launched for it alone.
 // (the body: `d` is the kernel argument, or -- MULTI -- a reference into the group table through the scalar data cache, so
 // that in both forms the description sits in SGPRs / is fetched by scalar loads where it is used)
-template <int NTAB, bool SPILL, bool WIDE, bool GRAD, typename Dev>
+template <int NTAB, bool SPILL, bool WIDE, bool GRAD, bool PF, typename Dev>
 __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
+  static_assert(!PF || (!SPILL && !WIDE), "the product-fused form keeps every tile in LDS and reads one tile per update");
   extern __shared__ double lds[];
   double* tiles = lds;                                           // [n_res][64 states][16 graphs]
   double* tot = tiles + (size_t)d.n_res * TILE;                  // [n_live][16 graphs][4 row blocks] partial column sums
@@ -671,7 +977,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   //      independent of every other, one round of latency) ----
   // (the flag words of bundle `lane`, for the partition choice below: requested first, used after everything else)
   const int bundle_fa = lane < d.n_bundles ? d.image[(size_t)lane * 2 * MW] : 0, bundle_fb = lane < d.n_bundles ? d.image[(size_t)lane * 2 * MW + MW] : 0;
-  for (int i = t; i < 2 * MW * (d.n_bundles + 1); i += SWG) limg[i] = d.image[i];
+  for (int i = t; i < 2 * MW * (d.n_bundles + 1); i += SWG) limg[i] = d.image[(PF ? d.off_pfb : 0) + i];
   if (t < 4) dummy[t] = t == 0 ? make_double2(1.0 / 64.0, 1.0 / 64.0) : (t == 1 ? make_double2(1.0, 1.0) : make_double2(0.25, 0.25));
   {
     const double2* src = reinterpret_cast<const double2*>(d.ptiles + (size_t)wg * d.n_cprod * TILE);
@@ -704,6 +1010,15 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   int rankmask = 0;
   for (int p = 0; p < d.P; ++p) rankmask |= (row0[p] != d0 ? 1 : 0) << p;
   // tiles the program reads before writing them start as the uniform vector (FactorGraph.initialize, LBP.py:211-216)
+  if (PF) {
+    // (product-fused: a message tile holds c (.) message; before the first update that is c (.) uniform -- a copy of c)
+    const double2* src = reinterpret_cast<const double2*>(d.ptiles + (size_t)wg * d.n_cprod * TILE);
+    for (int k = 0; k < d.n_pinit; ++k) {
+      const int tile = img[d.off_pinit + 2 * k], prod = img[d.off_pinit + 2 * k + 1];
+      reinterpret_cast<double2*>(TP(tile))[t] = prod >= 0 ? src[(size_t)prod * (TILE / 2) + t] : make_double2(uniform, uniform);
+      if (t < 64) tot[tile * 64 + t] = 0.25;
+    }
+  } else
   for (int k = 0; k < d.n_init; ++k) {
     const int tile = img[d.off_init + k];
     reinterpret_cast<double2*>(TP(tile))[t] = make_double2(uniform, uniform);
@@ -908,6 +1223,89 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
     if (cq == 0) tot[dst * 64 + gl * 4 + rb] = colsum;
     STAMP(3)
   };
+  // Product-fused member (SharedProgram::pf_ok; record layout: build_shared_program).  The input S -- c (.) message, stored by
+  // the message's producer -- goes from LDS straight into the matrix cores; the result is multiplied by this wave's 16 rows of
+  // the destination's constant product and by 1 / total(S) (any positive per-graph scale cancels downstream; this one keeps
+  // the magnitudes where they are) and stored with its partial column sums.  The reciprocal and the scaled c rows are formed
+  // BETWEEN the quarters' MFMAs: float64 vector operations run on the matrix cores' pipe, so behind an MFMA they cost their
+  // own few cycles and in front of the first one a whole wait.
+  double2* const stash_g = PF && d.stash && d.msgs && !d.vf_only ? reinterpret_cast<double2*>(d.stash + (size_t)wg * d.n_stash * TILE) : nullptr;
+  auto run_pf = [&](const int flags, const int w1, const int w2) {
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));
+    const int gl = lane & 15, cq = lane >> 4;
+    const bool mm = (flags & 1) != 0;
+    const int sel = 2 * ((rankmask >> ((flags >> 16) & 15)) & 1) + ((flags >> 1) & 1);
+    const bool second_set = index_in_half(mode, sel) != 0;
+    const int S = (w1 >> 8) & 0xFF, cd = w2 & 0xFF;
+    // (the host gives every member a real S tile -- an input that is still the uniform vector reads a tile the prologue filled --
+    // and every stored product a c tile: each address below is one base register plus immediate offsets)
+    const double2* src = reinterpret_cast<const double2*>(tiles + (size_t)S * TILE) + lane;
+    const double2* tp = reinterpret_cast<const double2*>(tot + S * 64 + gl * 4);
+    const bool noC = cd == 0xFF;                                 // (a slot only the read-out uses: the message itself is stored -- c = {1, 1} from the constants)
+    const double2* cs = noC ? dummy + 1 : reinterpret_cast<const double2*>(tiles + (size_t)cd * TILE) + 128 * rb + lane;
+    const int cof = noC ? 0 : 64;
+    double2 qa0 = src[0], qa1 = src[64], qb0 = src[128], qb1 = src[192], ta = tp[0], tb = tp[1], c0, c1;
+    STAMP(6)
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    double s = 1.0;
+    double k0, k1, k2, k3;
+    // (the totals arrive behind the first two quarters and are spent behind quarter 0's MFMAs, the c rows are requested in front of
+    // quarter 3's: their latency passes under MFMAs and the live registers stay under the 128 of four waves per SIMD)
+#define MLBP_PF_QUARTER(FR, H, V0, V1)                                                         \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(FR[4 * (H)], V0.x, acc, 0, 0, 0);               \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(FR[4 * (H) + 1], V0.y, acc, 0, 0, 0);           \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(FR[4 * (H) + 2], V1.x, acc, 0, 0, 0);           \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(FR[4 * (H) + 3], V1.y, acc, 0, 0, 0);
+#define MLBP_PF_TOTAL                                                                          \
+    { const double total = (ta.x + ta.y) + (tb.x + tb.y); bad |= !total_ok(total); s = __builtin_amdgcn_rcp(total); }
+#define MLBP_PF_BODY(FR)                                                                       \
+    MLBP_PF_QUARTER(FR, 0, qa0, qa1)                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    qa0 = src[256]; qa1 = src[320];                                                            \
+    MLBP_PF_TOTAL                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    MLBP_PF_QUARTER(FR, 1, qb0, qb1)                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    qb0 = src[384]; qb1 = src[448];                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    MLBP_PF_QUARTER(FR, 2, qa0, qa1)                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    c0 = cs[0]; c1 = cs[cof];                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    MLBP_PF_QUARTER(FR, 3, qb0, qb1)                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    k0 = c0.x * s; k1 = c0.y * s; k2 = c1.x * s; k3 = c1.y * s;
+    if (mm && !ABL(1)) {
+      if (!second_set) { MLBP_PF_BODY(fr0) } else { MLBP_PF_BODY(fr1) }
+    } else {
+      MLBP_PF_TOTAL
+    }
+#undef MLBP_PF_BODY
+#undef MLBP_PF_TOTAL
+#undef MLBP_PF_QUARTER
+    STAMP(7)
+    if ((flags & 8) && d.msgs && g0 + gl < d.B && !bad) {        // S, normalised, is the last value of a variable->factor slot: to memory
+      const double2 v0 = src[128 * rb], v1 = src[128 * rb + 64], t0 = tp[0], t1 = tp[1];      // this wave's rows once more (states 16 rb + cq + 4 r = k-steps 4 rb + r)
+      double* out = d.msgs + ((size_t)(g0 + gl) * d.n_msgs + ((w1 >> 16) & 0xFFFF)) * 64 + 16 * rb + cq;
+      const double it = 1.0 / ((t0.x + t0.y) + (t1.x + t1.y));
+      out[0] = v0.x * it; out[4] = v0.y * it; out[8] = v1.x * it; out[12] = v1.y * it;
+    }
+    if (!mm) return;
+    const int dst = w1 & 0xFF;
+    if (flags & 64) {
+      const double p0 = acc.x * k0, p1 = acc.y * k1, p2 = acc.z * k2, p3 = acc.w * k3;
+      double2* out = reinterpret_cast<double2*>(tiles + (size_t)dst * TILE) + 128 * rb + lane;
+      if (!ABL(4)) { out[0] = make_double2(p0, p1); out[64] = make_double2(p2, p3); }
+      const double colsum = column_sum((p0 + p1) + (p2 + p3));
+      if (cq == 0) tot[dst * 64 + gl * 4 + rb] = colsum;
+    }
+    if ((flags & 32) && stash_g) {                               // the slot's last update: the raw result for the read-out (any scale: the epilogue normalises)
+      double2* out = stash_g + (size_t)(w2 >> 8) * (TILE / 2) + 128 * rb + lane;
+      out[0] = make_double2(acc.x, acc.y); out[64] = make_double2(acc.z, acc.w);
+    }
+    STAMP(3)
+  };
   // the bundles sit in LDS; a bundle's 16 words are read (broadcast) one bundle ahead -- LDS reads return in order, so they
   // cost the tile reads behind them nothing (a scalar load from memory would be waited for with them: one counter)
   const int4* li = reinterpret_cast<const int4*>(limg);
@@ -925,18 +1323,121 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
     for (int mi = 0; mi < 2; ++mi) {                             // (one copy of the member code)
       const bool second = mi != 0;
       const int f = second ? b0 : a0;
-      if ((f & 0xFF) != 0 && (second ? hB : hA) == half) run(f, second ? b1 : a1, second ? b2 : a2, second ? b3 : a3);
+      if ((f & 0xFF) != 0 && (second ? hB : hA) == half) {
+        if constexpr (PF) run_pf(f, second ? b1 : a1, second ? b2 : a2);
+        else run(f, second ? b1 : a1, second ? b2 : a2, second ? b3 : a3);
+      }
     }
     // the next bundle's words are requested here, behind the member (its registers are free again) and in front of the
     // barrier (they arrive while the workgroup meets)
     __builtin_amdgcn_sched_barrier(0);
     nA = li[2 * k + 2]; nB = li[2 * k + 3];                      // the image is padded by one bundle
-    __syncthreads();
+    if constexpr (PF) {
+      // LDS traffic only: the stores to memory a member may have issued (stash, last variable->factor values) are read after the
+      // loop, behind a full __syncthreads -- the fence of one here would wait for them in every bundle
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+      __syncthreads();
+    }
     STAMP(4)
   }
 
   // ---- epilogue: marginals, message write-back, verdicts ----
+  // (every lane-derived value is formed again from a laundered thread id: what the epilogues need would otherwise be computed in
+  // front of the loop and held in registers across it -- registers the fragments need)
+  auto tail = [&]() {
+  int t_again = threadIdx.x;
+  asm volatile("" : "+v"(t_again));
+  const int t = t_again, lane = t & 63, gl = lane & 15, cq = lane >> 4, gi = g0 + gl;
+  const bool gvalid = gi < d.B;
+  const int gc = gvalid ? gi : d.B - 1;
   // a bad total met only here (the last update's result) must reach the verdict of every wave
+  if constexpr (PF) {
+    // product-fused: a tile holds c (.) message (or, when no update reads it, the message).  With the variable's constant
+    // product c and P_a = c (.) m_a, P_b = c (.) m_b the marginal c (.) m_a (.) m_b is P_a (.) (P_b / c) -- where c is 0 so is the
+    // marginal --: everything from LDS.  (c (.) m keeps nothing of m where c is 0, so the message WRITE-BACK reads the raw
+    // results the members stashed in memory: the workgroup's own stores, visible behind the fence of a full barrier.)
+    if (stash_g) __syncthreads();
+    const const_i32p rd = as_const(d.readout);
+    if (d.marginals) {
+      for (int v = wave; v < d.n_vars; v += SWG / 64) {
+        const int at = rd[v];
+        const int base = rd[at], n = rd[at + 1];
+        int n_p = 0, n_t = 0;
+        for (int q = 0; q < n; ++q) {
+          const int tl = rd[at + 2 + q];
+          if (img[d.off_stash + tl] >= 0) { ++n_t; n_p += img[d.off_stash + d.n_live + tl]; }
+        }
+        double m[16];
+        if (n_t == 0 || n_p == 0) {                              // c itself (or uniform) times the messages
+          if (base >= 0) {
+            const double2* src = reinterpret_cast<const double2*>(tiles + (size_t)base * TILE) + lane;
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) { const double2 x = src[64 * sp]; m[2 * sp] = x.x; m[2 * sp + 1] = x.y; }
+          } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) m[s] = uniform;
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) m[s] = 1.0;
+        }
+        int p_left = n_p;
+        for (int q = 0; q < n; ++q) {
+          const int tl = rd[at + 2 + q];
+          if (img[d.off_stash + tl] < 0) continue;               // never updated: still uniform, cancels in the normalisation
+          const bool is_p = img[d.off_stash + d.n_live + tl] != 0;
+          const double* tp = tot + tl * 64 + gl * 4;
+          const double total = (tp[0] + tp[1]) + (tp[2] + tp[3]);
+          bad |= !total_ok(total);
+          const double inv = 1.0 / total;
+          const double2* src = reinterpret_cast<const double2*>(tiles + (size_t)tl * TILE) + lane;
+#pragma unroll
+          for (int sp = 0; sp < 8; ++sp) { const double2 x = src[64 * sp]; m[2 * sp] *= x.x * inv; m[2 * sp + 1] *= x.y * inv; }
+          if (is_p && --p_left > 0) {                            // another c (.) message follows: take this one's c out first (no underflow of the pair)
+            const double2* cs = reinterpret_cast<const double2*>(tiles + (size_t)base * TILE) + lane;
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) {
+              const double2 c = cs[64 * sp];
+              m[2 * sp] = c.x > 0.0 ? m[2 * sp] / c.x : 0.0; m[2 * sp + 1] = c.y > 0.0 ? m[2 * sp + 1] / c.y : 0.0;
+            }
+          }
+        }
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) part += m[s];
+        const double tm = column_sum(part);
+        bad |= !total_ok(tm);
+        if (gvalid && !bad) {
+          double* out = d.marginals + ((size_t)gc * d.n_vars + v) * 64 + cq;
+          const double itm = 1.0 / tm;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) out[4 * s] = m[s] * itm;
+        }
+      }
+    }
+    if (d.msgs && !d.vf_only && stash_g)
+      for (int i = wave; i < d.n_back; i += SWG / 64) {
+        const int tl = img[d.off_back + 2 * i], sl = img[d.off_back + 2 * i + 1];
+        const int si = img[d.off_stash + tl];
+        if (si < 0 || (sl & 0x40000000)) continue;               // (this form keeps no variable->factor message as a tile)
+        const double2* src = stash_g + (size_t)si * (TILE / 2) + lane;
+        double2 x[8];
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) x[sp] = src[64 * sp];
+        double part = 0.0;
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) part += x[sp].x + x[sp].y;
+        const double total = column_sum(part);
+        bad |= !total_ok(total);
+        if (gvalid && !bad) {
+          double* out = d.msgs + ((size_t)gc * d.n_msgs + (sl & 0x3FFFFFFF)) * 64 + cq;
+          const double inv = 1.0 / total;
+#pragma unroll
+          for (int sp = 0; sp < 8; ++sp) { out[8 * sp] = x[sp].x * inv; out[8 * sp + 4] = x[sp].y * inv; }
+        }
+      }
+  } else {
   if (d.marginals) {
     const const_i32p rd = as_const(d.readout);
     for (int v = wave; v < d.n_vars; v += SWG / 64) {
@@ -989,6 +1490,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
       for (int sp = 0; sp < 8; ++sp) { const double2 v = src[64 * sp]; out[8 * sp] = v.x * inv; out[8 * sp + 4] = v.y * inv; }
     }
   }
+  }   // !PF
   if (bad && gvalid) d.bail[gi] = 2;                             // any wave that saw it says so (idempotent)
   STAMP(5)
   if (!GRAD || !d.gr.enabled) {                                  // (GRAD is a template parameter: the sweeps-only instances do not carry the epilogue's registers)
@@ -1002,181 +1504,25 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   //      Every wave of the workgroup waits for every load here, so the gathers are issued a phase AHEAD of their use: a
   //      pass's labels and first fragment before its messages, its label features behind them.  (The unary factors'
   //      terms do not depend on the sweeps: shared_prepare_kernel has written them, this adds to them.) ----
-  __syncthreads();
-  const int NP = min(4, (d.n_res - 1) >> 1);                     // factors per pass: two tiles each, one tile of partial sums
-  double* red = tiles + (size_t)2 * NP * TILE;                   // [factor][k][row block][graph]
-  double* pc = tot;                                              // [factor][graph][3] per-graph terms of a pass (the totals are spent)
-  double out3[3] = {0.0, 0.0, 0.0};                              // thread t < 16: graph g0 + t
-  for (int p0 = 0; p0 < d.P; p0 += NP) {
-    const int np = min(NP, d.P - p0);
-    // thread (factor t >> 4, graph t & 15) of the first np * 16: the factor's labels ...
-    const int lp = p0 + (t >> 4), lg = g0 + (t & 15);
-    const bool l_on = t < np * G && lg < d.B;
-    int m0 = 0, m1 = 0;
-    if (l_on) { m0 = d.gr.pair_label[((size_t)lg * d.P + lp) * 2]; m1 = d.gr.pair_label[((size_t)lg * d.P + lp) * 2 + 1]; }
-    // ... the messages: wave w takes rows i = w + 8 j of the pass's np * 32 (factor i >> 5, side (i >> 4) & 1, graph i & 15), one
-    // 512-byte row each.  The slots (and whether the program ever writes them) come through the scalar cache -- a vector
-    // load here would be one more round of memory latency in front of the rows --, then all the rows are requested
-    // before the first is used.  The half's first A fragment goes out ahead of them.
-    const const_i32p cs = as_const(d.gr.c_slot), rs = as_const(d.gr.r_slot), pf = as_const(d.gr.plane_flags);
-    int slots[8];                                                 // tile q = 2 * factor + side: its message slot, or -1
-#pragma unroll
-    for (int q = 0; q < 8; ++q) slots[q] = q < 2 * np ? ((q & 1) ? cs[p0 + (q >> 1)] : rs[p0 + (q >> 1)]) : -1;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const bool in = (unsigned)slots[q] < (unsigned)d.n_msgs;
-      const int w = img[d.off_written + (in ? slots[q] >> 5 : 0)];
-      if (!in || !((w >> (slots[q] & 31)) & 1)) slots[q] = -1;
-    }
-    const int n_items = 2 * np;
-    auto key = [&](int j) { const int pp = j % np; return row0[p0 + pp] * 2 + (as_const(d.gr.pair_phi)[p0 + pp] ? 1 : 0); };
-    auto fetchw = [&](double (&fr)[16], int j) {
-      const int k = 2 * (j / np) + half;
-      const double* W = d.gr.wfrag + ((size_t)key(j) * 4 + k) * 4096 + rb * 1024 + lane;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) fr[s] = ABL(256) ? 0.5 : W[64 * s];
-    };
-    auto run_end = [&](int j) {                                  // first item behind the run that starts at j
-      int e = j + 1;
-      while (e < n_items && e % np != 0 && key(e) == key(e - 1)) ++e;
-      return e;
-    };
-    // an item whose feature plane is all zeros or all ones needs no contraction (the per-graph terms below use 0 resp. Z)
-    auto needed = [&](int j) { const int k = 2 * (j / np) + half; return k == 3 || pf[(key(j) & 1) * 4 + k] == 0; };
-    auto next_run = [&](int j) {                                  // start of the first needed run at or behind j
-      while (j < n_items && !needed(j)) j = run_end(j);
-      return j;
-    };
-    const int j_first = next_run(0);
-    if (j_first < n_items) fetchw(fr0, j_first);
-    double sv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {                                // row i = wave + 8 j: tile i >> 4 = j >> 1, graph wave + 8 (j & 1)
-      sv[j] = uniform;                                            // never updated: still uniform (LBP.py:211-216)
-      if (j < 4 * np && slots[j >> 1] >= 0 && !ABL(32)) {
-        const int ggc = min(g0 + wave + 8 * (j & 1), d.B - 1);
-        sv[j] = d.msgs[((size_t)ggc * d.n_msgs + slots[j >> 1]) * 64 + lane];
-      }
-    }
-    // ... and the label's feature row (the labels have arrived, the messages are still on their way)
-    double lf[3] = {0.0, 0.0, 0.0};
-    const bool l_ok = l_on && (unsigned)m0 < 64u && (unsigned)m1 < 64u;
-    if (l_on && !l_ok) atomicExch(d.status, 1);
-    if (l_ok) {
-      const double* ph = d.gr.phi[d.gr.pair_phi[lp] ? 1 : 0] + ((size_t)m0 * 64 + m1) * 3;
-      lf[0] = ph[0]; lf[1] = ph[1]; lf[2] = ph[2];
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (j < 4 * np) {
-        tiles[(size_t)(j >> 1) * TILE + tile_index(lane, wave + 8 * (j & 1))] = sv[j];
-      }
-    __syncthreads();
-    STAMP(8)
-    // this half's items in k-major order: j = kk * np + pp  ->  factor p0 + pp, feature k = 2 kk + half.  Consecutive
-    // factors that read the same (table, feature tensor) share one A fragment: it is fetched once per run (a K3 user
-    // graph's three factors are one run: 2 fetches per wave instead of 6), the next run's while this run multiplies; two
-    // items of a run go through the matrix pipe interleaved (two independent accumulation chains).
-    auto finish = [&](const double4_t& acc, int pp, int k) {
-      const double2* ct = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp + 1) * TILE) + 128 * rb + lane;
-      const double2 c0 = ct[0], c1 = ct[64];
-      const double part = column_sum((c0.x * acc.x + c0.y * acc.y) + (c1.x * acc.z + c1.y * acc.w));
-      if ((lane >> 4) == 0) red[((pp * 4 + k) * 4 + rb) * G + (lane & 15)] = part;
-    };
-    auto item = [&](const double (&fr)[16], int j) {
-      const int pp = j % np, k = 2 * (j / np) + half;
-      const double2* rt = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp) * TILE) + lane;
-      double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const double2 v0 = rt[128 * h], v1 = rt[128 * h + 64];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h], v0.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 1], v0.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 2], v1.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 3], v1.y, acc, 0, 0, 0);
-      }
-      finish(acc, pp, k);
-    };
-    auto item2 = [&](const double (&fr)[16], int j) {            // items j and j + 1: the same fragment, the next factor
-      const int pp = j % np, k = 2 * (j / np) + half;
-      const double2* rt = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp) * TILE) + lane;
-      double4_t acc = {0.0, 0.0, 0.0, 0.0}, bcc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const double2 v0 = rt[128 * h], v1 = rt[128 * h + 64], w0 = rt[2 * (TILE / 2) + 128 * h], w1 = rt[2 * (TILE / 2) + 128 * h + 64];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h], v0.x, acc, 0, 0, 0);
-        bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h], w0.x, bcc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 1], v0.y, acc, 0, 0, 0);
-        bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 1], w0.y, bcc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 2], v1.x, acc, 0, 0, 0);
-        bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 2], w1.x, bcc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 3], v1.y, acc, 0, 0, 0);
-        bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 3], w1.y, bcc, 0, 0, 0);
-      }
-      finish(acc, pp, k);
-      finish(bcc, pp + 1, k);
-    };
-    for (int j = ABL(64) ? n_items : j_first; j < n_items;) {
-      int e = run_end(j), nx = next_run(e);
-      if (nx < n_items) fetchw(fr1, nx);
-#pragma unroll 1
-      for (; j + 1 < e; j += 2) item2(fr0, j);
-      if (j < e) item(fr0, j);
-      j = nx;
-      if (j >= n_items) break;
-      e = run_end(j); nx = next_run(e);
-      if (nx < n_items) fetchw(fr0, nx);
-#pragma unroll 1
-      for (; j + 1 < e; j += 2) item2(fr1, j);
-      if (j < e) item(fr1, j);
-      j = nx;
-    }
-    __syncthreads();
-    STAMP(9)
-    if (t < np * G) {                                            // label features minus expected features, per (factor, graph)
-      const double* rp = red + (size_t)(t >> 4) * 16 * G + (t & 15);
-      const double Z = (rp[(12 + 0) * G] + rp[(12 + 1) * G]) + (rp[(12 + 2) * G] + rp[(12 + 3) * G]);
-      const int wh = d.gr.pair_phi[p0 + (t >> 4)] ? 1 : 0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int flag = d.gr.plane_flags[wh * 4 + k];
-        const double S = (rp[(4 * k + 0) * G] + rp[(4 * k + 1) * G]) + (rp[(4 * k + 2) * G] + rp[(4 * k + 3) * G]);
-        // expected feature: S / Z; a zero plane 0, the bias plane the normalised belief's total, 1  (au.normalize: zero-sum -> 0)
-        const double ex = Z > 0.0 ? (flag == 0 ? S / Z : (flag == 1 ? 0.0 : 1.0)) : 0.0;
-        pc[t * 3 + k] = l_ok ? lf[k] - ex : 0.0;
-      }
-    }
-    __syncthreads();
-    if (t < G)
-      for (int pp = 0; pp < np; ++pp) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) out3[k] += pc[(pp * G + t) * 3 + k];
-      }
-    __syncthreads();
-    STAMP(10)
-  }
-  // the unary factors' terms are in the output already (shared_prepare_kernel: they do not depend on the sweeps)
-  if (t < G && g0 + t < d.B) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) d.gr.grad_en_en[(size_t)(g0 + t) * 3 + k] += out3[k];
-  }
-  STAMP(11)
   STAMP_FLUSH
+  shared_gradient_epilogue(d, wg);
+  };
+  tail();
 }
 
 typedef const SharedDev __attribute__((address_space(4))) SharedDevConst;
-template <int NTAB, bool SPILL, bool WIDE, bool MULTI, bool GRAD>
+template <int NTAB, bool SPILL, bool WIDE, bool MULTI, bool GRAD, bool PF = false>
 __global__ __launch_bounds__(SWG, 4) void sweep_x64_shared_kernel(SharedDev d, const SharedDev* gtab, const int32_t* gstart, int n_groups) {
   if (MULTI) {
     const int lo = find_group(gstart, n_groups, blockIdx.x);
     SharedDevConst& dg = *(SharedDevConst*)(uintptr_t)(gtab + lo);
-    sweep_x64_shared_body<NTAB, SPILL, WIDE, GRAD>(dg, (int)blockIdx.x - as_const(gstart)[lo]);
+    sweep_x64_shared_body<NTAB, SPILL, WIDE, GRAD, PF>(dg, (int)blockIdx.x - as_const(gstart)[lo]);
   } else {
     // the description is the first kernel argument: read where it is used, through the scalar cache, out of the kernel
     // argument segment -- preloaded as a by-value struct its 80 words crowd the scalar registers of the main loop
     (void)d;
     SharedDevConst& dk = *(SharedDevConst*)__builtin_amdgcn_kernarg_segment_ptr();
-    sweep_x64_shared_body<NTAB, SPILL, WIDE, GRAD>(dk, (int)blockIdx.x);
+    sweep_x64_shared_body<NTAB, SPILL, WIDE, GRAD, PF>(dk, (int)blockIdx.x);
   }
 }
 
@@ -1389,13 +1735,23 @@ sweep_fn grad_instance() {
 }
 
 // the instance for (two tables?, spilled tiles?, more than two sources?, groups?); raises its dynamic LDS limit once
-int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, size_t lds, sweep_fn* out) {
+int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, bool pf, size_t lds, sweep_fn* out) {
   sweep_fn k = nullptr;
+  if (spill || wide) pf = false;
 #ifdef MLBP_STAMPS      // the diagnostic build instantiates the all-resident two-source kernels only
   if (spill || wide || multi) return fail(MLBP_EUNSUPPORTED, "stamps build: no spilling / wide / grouped instance");
+  if (pf)
+    k = two ? (grad ? sweep_x64_shared_kernel<2, false, false, false, true, true> : sweep_x64_shared_kernel<2, false, false, false, false, true>)
+            : (grad ? sweep_x64_shared_kernel<1, false, false, false, true, true> : sweep_x64_shared_kernel<1, false, false, false, false, true>);
+  else
   k = two ? (grad ? sweep_x64_shared_kernel<2, false, false, false, true> : sweep_x64_shared_kernel<2, false, false, false, false>)
           : (grad ? sweep_x64_shared_kernel<1, false, false, false, true> : sweep_x64_shared_kernel<1, false, false, false, false>);
 #else
+  if (pf) {
+#define MLBP_PK(T, M) (grad ? (sweep_fn)sweep_x64_shared_kernel<T, false, false, M, true, true> : (sweep_fn)sweep_x64_shared_kernel<T, false, false, M, false, true>)
+    k = two ? (multi ? MLBP_PK(2, true) : MLBP_PK(2, false)) : (multi ? MLBP_PK(1, true) : MLBP_PK(1, false));
+#undef MLBP_PK
+  } else {
   // (the gradient epilogue comes in two forms: every tile in LDS and two-source updates -- K2, K3 --, or spilled tiles AND
   // wide updates -- K4 and larger cliques, train_mp.py:272-282: a variable with three pairwise factors has three neighbours, and
   // four variables' tiles do not fit.  A launch of mixed groups takes the second.)
@@ -1409,6 +1765,7 @@ int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, si
 #undef MLBP_SK_W
 #undef MLBP_SK_M
 #undef MLBP_SK
+  }
 #endif
   static std::vector<std::pair<const void*, size_t>> granted;
   {
@@ -1421,8 +1778,8 @@ int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, si
       granted.push_back({(const void*)k, lds});
       int per_cu = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, SWG, lds) == hipSuccess)
-        fail(MLBP_OK, "shared-table kernel <%d%s%s%s%s>: %zu bytes of LDS per workgroup, %d workgroups per CU", two ? 2 : 1,
-             spill ? ", spilling" : "", wide ? ", wide" : "", multi ? ", groups" : "", grad ? ", gradient" : "", lds, per_cu);
+        fail(MLBP_OK, "shared-table kernel <%d%s%s%s%s%s>: %zu bytes of LDS per workgroup, %d workgroups per CU", two ? 2 : 1,
+             spill ? ", spilling" : "", wide ? ", wide" : "", multi ? ", groups" : "", grad ? ", gradient" : "", pf ? ", product-fused" : "", lds, per_cu);
     }
   }
   *out = k;
@@ -1461,7 +1818,7 @@ namespace {
 
 // What a shared-table sweep of (prog, a) needs: the two device descriptions, the LDS size, the grid sizes.  *ok false: the
 // kernel does not apply (mlbp_last_error says why).  Allocates the program's scratch on first use.
-struct SharedPlan { SharedDev d; PrepareDev q; size_t lds; int n_wg, n_prep_blocks; bool wide, spill; };
+struct SharedPlan { SharedDev d; PrepareDev q; size_t lds; int n_wg, n_prep_blocks; bool wide, spill, pf; };
 int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, SharedPlan* out) {
   *ok = false;
   memset(out, 0, sizeof(*out));
@@ -1484,7 +1841,10 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   if (n_cprod < 1 || n_cprod > 8) return fail(MLBP_OK, "shared-table kernel not used: %d constant products (1..8)", n_cprod);
   mlbp_program* mp = const_cast<mlbp_program*>(prog);
   const int n_groups = (a->B + G - 1) / G;
-  const size_t spill_doubles = (size_t)n_groups * (sp.n_live - n_res) * TILE;
+  // the product-fused form (diagnostic switch: MLBP_SHARED_NO_PF in the environment keeps the general form)
+  static const bool no_pf = getenv("MLBP_SHARED_NO_PF") != nullptr;
+  const bool pf = sp.pf_ok && !no_pf && n_res == sp.n_live && sp.max_sources <= 2;
+  const size_t spill_doubles = pf ? (size_t)n_groups * sp.n_stash * TILE : (size_t)n_groups * (sp.n_live - n_res) * TILE;
   // (first use at this size allocates -- a stream-capturing caller warms up or reserves first; a block that is outgrown stays
   // alive with the program: program_grow)
   if (spill_doubles > 0)
@@ -1507,6 +1867,9 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   d.ptiles = mp->d_ptiles;
   d.n_res = n_res; d.spill = n_res < sp.n_live ? mp->d_spill : nullptr;
   d.off_written = sp.off_written;
+  d.off_pfb = sp.off_pfb; d.off_stash = sp.off_stash; d.off_pinit = sp.off_pinit; d.n_pinit = sp.n_pinit; d.n_stash = sp.n_stash;
+  d.stash = pf ? mp->d_spill : nullptr;
+  out->pf = pf;
   d.tfrag = nullptr;
   if (a->n_pair_tables <= FRAG_TABLES) {
     if (!mp->d_tfrag) {                            // first use (a stream-capturing caller warms up or reserves first)
@@ -1568,7 +1931,7 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   hipLaunchKernelGGL(shared_prepare_kernel<false>, dim3(pl.n_prep_blocks), dim3(PWG), (size_t)pl.q.n_cprod * TILE * sizeof(double), st, pl.q, nullptr, nullptr, 0);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
   sweep_fn k = nullptr;
-  if (int e = pick_sweep_kernel(prog->P >= 2, pl.spill, pl.wide, false, pl.d.gr.enabled != 0, pl.lds, &k)) return e;
+  if (int e = pick_sweep_kernel(prog->P >= 2, pl.spill, pl.wide, false, pl.d.gr.enabled != 0, pl.pf, pl.lds, &k)) return e;
   hipLaunchKernelGGL(k, dim3(pl.n_wg), dim3(SWG), pl.lds, st, pl.d, nullptr, nullptr, 0);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed");
   if (int e = enqueue_unary_writeback(prog, a, pl.d, st)) return e;
@@ -1585,7 +1948,7 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   if (n_groups < 1) return MLBP_OK;
   std::vector<SharedPlan> plans(n_groups);
   size_t lds = 0;
-  bool wide = false, spill = false, two = false, grad = false;
+  bool wide = false, spill = false, two = false, grad = false, pf = true;
   int max_cprod = 1;
   for (int k = 0; k < n_groups; ++k) {
     if (!progs[k]) return MLBP_OK;
@@ -1595,7 +1958,7 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
     if (int e = shared_plan(progs[k], &args[k], &ok, &plans[k])) return e;
     if (!ok) return MLBP_OK;
     lds = std::max(lds, plans[k].lds);
-    wide |= plans[k].wide; spill |= plans[k].spill; two |= progs[k]->P >= 2; grad |= plans[k].d.gr.enabled != 0;
+    wide |= plans[k].wide; spill |= plans[k].spill; two |= progs[k]->P >= 2; grad |= plans[k].d.gr.enabled != 0; pf &= plans[k].pf;
     max_cprod = std::max(max_cprod, (int)plans[k].q.n_cprod);
   }
   // (a launch with the gradient epilogue runs the all-resident / two-source instance, or -- as soon as one group spills tiles or
@@ -1623,7 +1986,7 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), (size_t)max_cprod * TILE * sizeof(double), st, plans[0].q, d_pd, d_starts + n_groups + 1, n_groups);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
   sweep_fn k = nullptr;
-  if (int e = pick_sweep_kernel(two, spill, wide, true, grad, lds, &k)) return e;
+  if (int e = pick_sweep_kernel(two, spill, wide, true, grad, pf, lds, &k)) return e;
   hipLaunchKernelGGL(k, dim3(wg), dim3(SWG), lds, st, plans[0].d, d_sd, d_starts, n_groups);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed");
   for (int g = 0; g < n_groups; ++g)

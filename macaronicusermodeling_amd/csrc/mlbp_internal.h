@@ -154,10 +154,13 @@ struct mlbp_program {
   int32_t* d_simage;      // SharedProgram::image
   int32_t* d_sreadout;    // per variable: base tile, count, live tiles (4-word aligned lists) or NULL
   int32_t n_sreadout;
+  bool sreadout_all_based = false;   // every variable of the read-out has a constant product (the product-fused read-out needs it)
   double* d_tfrag;        // [32][2][4096] table fragments in MFMA operand order (lazily allocated)
   double* d_spill = nullptr;   // message tiles of the shared-table kernel that do not fit LDS (lazily allocated)
   double* d_wfrag = nullptr;   // the gradient epilogue's weighted table fragments [n_pair_tables][2][4][4096] (lazily allocated)
   size_t wfrag_cap = 0;          // in BYTES (program_grow); spill_cap / ptiles_cap / stable_cap / gtable_cap likewise
+  int32_t* d_header = nullptr; // the prepare launch's per-group headers for the sweep kernel [groups][8] (lazily allocated)
+  size_t header_cap = 0;       // in bytes
   double* d_ptiles = nullptr;  // constant-product tiles of the shared-table kernel [groups][n_cprod][1024] (lazily allocated)
   size_t ptiles_cap = 0;       // in doubles
   size_t spill_cap = 0;        // in doubles

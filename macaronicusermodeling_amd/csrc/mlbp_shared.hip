@@ -520,6 +520,7 @@ struct SharedDev {
   // a constant product; stash [workgroups][n_stash][64][16]: the raw result of the last update of every slot
   int32_t off_pfb, off_stash, off_pinit, n_pinit, n_stash, pad2_;
   double* stash;
+  const int32_t* header;        // [groups][HDR] shared_prepare_kernel's verdict on each group of 16 graphs and its fragment sets
   SharedGradDev gr;
 };
 
@@ -531,7 +532,8 @@ struct SharedDev {
 
 #ifdef MLBP_STAMPS
 __device__ unsigned long long* g_sh_stamp = nullptr;
-__device__ int g_sh_ablate = 0;      // timing experiments of tools/stamp_shared.py (results become wrong): 1 no MFMAs, 2 no tile reads, 4 no result stores
+__device__ int g_sh_ablate = 0;      // timing experiments of tools/stamp_shared.py (results become wrong): 1 no MFMAs, 2 no tile reads, 4 no result stores,
+                                     // 8 / 16 prepare kernel without its row loads / copy-out, 512 no marginal read-out, 1024 no fragment loads, 2048 no main loop
 #define ABL(bit) (abl_ & (bit))
 #define ABL_DECL const int abl_ = __builtin_amdgcn_readfirstlane(g_sh_ablate);
 #ifdef MLBP_STAMPS_LIGHT      // ablations only: no clock reads in the kernel
@@ -566,6 +568,12 @@ __device__ __forceinline__ int tile_index(int state, int graph) {
   return (((s >> 1) * 64 + cq * 16 + graph) << 1) | (s & 1);
 }
 
+// Which half of the workgroup holds (table rank, orientation) pair `sel` = 2 * rank + mt, under partition `mode`:
+//   mode 0: {T0.m, m.T1 | m.T0, T1.m}   mode 1: {T0.m, m.T0 | T1.m, m.T1}   mode 2: {T0.m, T1.m | m.T0, m.T1}
+// and its position (0 / 1) among the two that half holds.
+__device__ __forceinline__ int half_of(int mode, int sel) { return ((mode == 0 ? 0x6 : (mode == 1 ? 0xC : 0xA)) >> sel) & 1; }
+__device__ __forceinline__ int index_in_half(int mode, int sel) { return ((mode == 0 ? 0xC : (mode == 1 ? 0xA : 0xC)) >> sel) & 1; }
+
 // Everything of a shared-table sweep that does not depend on the sweeps, as ONE streaming launch in front of it:
 //   one wave per graph: the constant products of the graph -- per variable the product of its unary factors' table columns
 //     (LBP.py:494-498, 381-386), normalised -- written as its column of its group's message tiles in `ptiles`
@@ -590,7 +598,14 @@ struct PrepareDev {
   const double* unary_tables; const int32_t* unary_tab; const int32_t* ent;      // ent: [E][4] unary factor, slot, tile, first | last flags
   double* ptiles; uint8_t* bail; int32_t* status;
   int32_t B, U, n_unary_tables, E, n_cprod, n_groups;
+  // ... and the group's HEADER for the sweep kernel, header[group][HDR] = {verdict: 0 run | 1 a table index out of range | 2 the 16
+  // graphs do not name the same tables (or more than two distinct ones), first table, second table (= the first: one), bit p =
+  // pairwise factor p reads the second, partition of the fragment sets over the halves}: what the sweep kernel used to work out
+  // from the same data at the start of its single round, one dependent round of memory latency in front of its fragment loads
+  const int32_t* pair_tab; const int32_t* image; int32_t* header;
+  int32_t P, n_pair_tables, n_bundles, pad_;
 };
+constexpr int HDR = 8;
 // MULTI: several groups of graphs (mlbp_sweep_groups_f64: every group its own program, tables, messages) in one launch;
 // gtab[k] = the group's PrepareDev, gstart[k] = its first block (ascending; gstart[n_groups] = the grid size).
 template <bool MULTI>
@@ -648,6 +663,13 @@ __global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, co
   const int g = block * PGB + wave;
   const bool on = g < d.B;
   const int col = wave;
+  // the group's header: wave w compares graph w's table indices with the group's first graph's (lane p: pairwise factor p) ...
+  __shared__ int hdr_ok[PGB], hdr_same[PGB];
+  // (one register -- lanes 0..P-1: this graph's row, lanes 16..16+P-1: the group's first graph's; P <= 16 -- requested here, looked
+  // at behind the products: nothing below waits for it, and the kernel's 64 registers hold it without a spill)
+  int pair_rows = 0;
+  if (d.header && (lane & 15) < d.P && lane < 32)
+    pair_rows = d.pair_tab[(size_t)(lane < 16 ? min(g, d.B - 1) : block * PGB) * d.P + (lane & 15)];
   if (on) {
   constexpr int RB = 8;
   constexpr unsigned KEY_LIMIT = 0x7A11A0FCu;                    // high word of 1e280
@@ -729,11 +751,50 @@ __global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, co
     if (lane < 6) d.grad_en_de[(size_t)g * 6 + lane] = u_ed;
   }
   }   // if (on)
+  int first_row = 0;
+  if (d.header) {
+    first_row = __shfl(pair_rows, (lane & 15) + 16);
+    const bool mine_lane = lane < 16 && lane < d.P;
+    const int all_in_range = __all(!mine_lane || (unsigned)pair_rows < (unsigned)d.n_pair_tables), all_same = __all(!mine_lane || pair_rows == first_row);
+    if (lane == 0) { hdr_ok[wave] = all_in_range ? 1 : 0; hdr_same[wave] = all_same ? 1 : 0; }
+  }
   __syncthreads();
   if (!ABL(16)) {
     const double2* src = reinterpret_cast<const double2*>(ptile_lds);
     double2* dst = reinterpret_cast<double2*>(d.ptiles + (size_t)block * d.n_cprod * TILE);
     for (int i = t; i < d.n_cprod * (TILE / 2); i += PWG) dst[i] = src[i];          // (columns of graphs beyond B: whatever LDS held; never read as results)
+  }
+  if (d.header && wave == PWG / 64 - 1) {
+    // ... and wave 0 finishes it: the distinct tables, which factor reads which, and the partition that splits most bundles
+    const bool ok = __all(lane >= PGB || hdr_ok[lane & (PGB - 1)] != 0), same = __all(lane >= PGB || hdr_same[lane & (PGB - 1)] != 0);
+    const int d0 = __builtin_amdgcn_readfirstlane(first_row);
+    const unsigned long long in_p = d.P >= 64 ? ~0ull : ((1ull << d.P) - 1);
+    const unsigned long long second = __ballot(first_row != d0) & in_p;
+    const int d1 = second ? __shfl(first_row, __builtin_ctzll(second)) : d0;
+    const bool over = (__ballot(first_row != d0 && first_row != d1) & in_p) != 0;
+    const int rankmask = (int)second;
+    int mode = 1;
+    if (d1 != d0) {
+      int c0 = 0, c1 = 0, c2 = 0;
+      for (int b0 = 0; b0 < d.n_bundles; b0 += 64) {
+        const int i = b0 + lane;
+        bool p0 = false, p1 = false, p2 = false;
+        if (i < d.n_bundles) {
+          const int fa = d.image[(size_t)i * 2 * MW], fb = d.image[(size_t)i * 2 * MW + MW];
+          if ((fa & 1) && (fb & 1)) {
+            const int sa = 2 * ((rankmask >> ((fa >> 16) & 15)) & 1) + ((fa >> 1) & 1);
+            const int sb = 2 * ((rankmask >> ((fb >> 16) & 15)) & 1) + ((fb >> 1) & 1);
+            p0 = half_of(0, sa) != half_of(0, sb); p1 = half_of(1, sa) != half_of(1, sb); p2 = half_of(2, sa) != half_of(2, sb);
+          }
+        }
+        c0 += __popcll(__ballot(p0)); c1 += __popcll(__ballot(p1)); c2 += __popcll(__ballot(p2));
+      }
+      mode = (c0 >= c1 && c0 >= c2) ? 0 : (c1 >= c2 ? 1 : 2);
+    }
+    if (lane < HDR) {
+      const int w = lane == 0 ? (!ok ? 1 : ((!same || over) ? 2 : 0)) : (lane == 1 ? d0 : (lane == 2 ? d1 : (lane == 3 ? rankmask : (lane == 4 ? mode : 0))));
+      d.header[(size_t)block * HDR + lane] = w;
+    }
   }
 }
 
@@ -748,16 +809,11 @@ __device__ __forceinline__ Words16 sload16(const int32_t* p) {
   return r;
 }
 
-// Which half of the workgroup holds (table rank, orientation) pair `sel` = 2 * rank + mt, under partition `mode`:
-//   mode 0: {T0.m, m.T1 | m.T0, T1.m}   mode 1: {T0.m, m.T0 | T1.m, m.T1}   mode 2: {T0.m, T1.m | m.T0, m.T1}
-// and its position (0 / 1) among the two that half holds.
-__device__ __forceinline__ int half_of(int mode, int sel) { return ((mode == 0 ? 0x6 : (mode == 1 ? 0xC : 0xA)) >> sel) & 1; }
-__device__ __forceinline__ int index_in_half(int mode, int sel) { return ((mode == 0 ? 0xC : (mode == 1 ? 0xA : 0xC)) >> sel) & 1; }
-
-// The gradient epilogue of the sweep kernel (below) as a function of its own -- NOT inlined: the register allocator otherwise
-// carries what this code needs across the sweeps' main loop, whose fragments then go to scratch inside the MFMA sequences.
+// The gradient epilogue of the sweep kernel (below).  It forms every lane-derived value again from the thread id: values shared with
+// the code in front of the main loop would be held in registers across it, and the loop's fragments would go to scratch inside the
+// MFMA sequences.  (As a real function call it paid the ABI's callee-saved registers and spills of its own: 70 -> 95 us.)
 template <typename Dev>
-__device__ __attribute__((noinline)) void shared_gradient_epilogue(Dev& d, const int wg) {
+__device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
   extern __shared__ double lds[];
   double* tiles = lds;
   double* tot = tiles + (size_t)d.n_res * TILE;
@@ -967,55 +1023,110 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   const int gc = gvalid ? gi : d.B - 1;                          // tail columns replay the last graph, outputs masked
   const double uniform = 1.0 / 64.0;
   const const_i32p img = as_const(d.image);
-  const const_i32p row0 = as_const(d.pair_tab + (size_t)g0 * d.P);       // the group's table of every pairwise factor
 
   STAMP_DECL
   ABL_DECL
   STAMP_START
-  // ---- phase A: the group's tables (every graph must name the same ones, at most NTAB distinct), the bundles, and the
-  //      constant products shared_prepare_kernel left as tiles (plain 16-byte copies: every load of the prologue is
-  //      independent of every other, one round of latency) ----
-  // (the flag words of bundle `lane`, for the partition choice below: requested first, used after everything else)
-  const int bundle_fa = lane < d.n_bundles ? d.image[(size_t)lane * 2 * MW] : 0, bundle_fb = lane < d.n_bundles ? d.image[(size_t)lane * 2 * MW + MW] : 0;
-  for (int i = t; i < 2 * MW * (d.n_bundles + 1); i += SWG) limg[i] = d.image[(PF ? d.off_pfb : 0) + i];
-  if (t < 4) dummy[t] = t == 0 ? make_double2(1.0 / 64.0, 1.0 / 64.0) : (t == 1 ? make_double2(1.0, 1.0) : make_double2(0.25, 0.25));
+  // ---- prologue: ONE round of loads.  shared_prepare_kernel has left the group's header (verdict on the 16 graphs' table
+  //      indices, the distinct tables, which factor reads which, the partition of the fragment sets over the halves -- read through
+  //      the scalar cache), the constant products as tiles and the per-graph verdicts; the bundle records, the product tiles
+  //      and the verdicts are requested before the header is waited for, the fragments as soon as it is here ----
+  const const_i32p hd = as_const(d.header + (size_t)wg * HDR);
+  const int verdict = hd[0], d0 = hd[1], d1 = hd[2], rankmask = hd[3];
+  const int mode = hd[4];
+  // the bundle records go to LDS RESOLVED: slot [bundle][half] = the member that half runs (flag bit 7: its fragments are the half's
+  // second set), so the main loop reads one record and decides nothing.  Two members whose fragment sets one half holds (two
+  // tables, a bundle the partition does not split): that half's record carries CHAIN and the other slot the second member parked
+  // (its flag byte moved to bits 24-31) -- the half runs both, one after the other.
+  constexpr int CHAIN = 1 << 30;
   {
-    const double2* src = reinterpret_cast<const double2*>(d.ptiles + (size_t)wg * d.n_cprod * TILE);
-    for (int k = 0; k < d.n_cprod; ++k) {
-      const int tile = img[d.off_ptile + k];
-      reinterpret_cast<double2*>(TP(tile))[t] = src[(size_t)k * (TILE / 2) + t];        // SWG threads x 16 bytes = one tile
-      if (t < 64) tot[tile * 64 + t] = 0.25;                     // four partials of a total of 1
+    const bool single_ = d1 == d0;
+    const int32_t* gb = d.image + (PF ? d.off_pfb : 0);
+    int4* lo = reinterpret_cast<int4*>(limg);
+    for (int k = t; k < d.n_bundles + 1; k += SWG) {
+      const int32_t* b = gb + 2 * MW * (size_t)k;
+      int4 A = make_int4(b[0], b[1], b[2], b[3]), B = make_int4(b[4], b[5], b[6], b[7]);
+      const int sa = 2 * ((rankmask >> ((A.x >> 16) & 15)) & 1) + ((A.x >> 1) & 1), sb = 2 * ((rankmask >> ((B.x >> 16) & 15)) & 1) + ((B.x >> 1) & 1);
+      int hA = ((A.x & 1) && !single_) ? half_of(mode, sa) : -1, hB = ((B.x & 1) && !single_) ? half_of(mode, sb) : -1;
+      if (hA < 0) hA = hB >= 0 ? 1 - hB : 0;                     // a member that can run anywhere goes to the idle half
+      if (hB < 0) hB = 1 - hA;
+      const bool runA = (A.x & 0x7F) != 0, runB = (B.x & 0x7F) != 0;
+      if (A.x & 1) A.x |= index_in_half(mode, sa) << 7;
+      if (B.x & 1) B.x |= index_in_half(mode, sb) << 7;
+      const int4 nop4 = make_int4(0, 0, 0, 0);
+      int4 s0 = nop4, s1 = nop4;
+      if (!(runA && runB && hA == hB)) {
+        if (runA) { if (hA == 0) s0 = A; else s1 = A; }
+        if (runB) { if (hB == 0) s0 = B; else s1 = B; }
+      } else {                                                   // both on half hA
+        int4 parked = B;
+        parked.x = (int)(((unsigned)B.x & 0xFFu) << 24) | (B.x & 0x00FFFF00);
+        A.x |= CHAIN;
+        if (hA == 0) { s0 = A; s1 = parked; } else { s1 = A; s0 = parked; }
+      }
+      lo[2 * k] = s0; lo[2 * k + 1] = s1;
     }
   }
-  bool ok = true, same = true;
-  for (int i = t; i < G * d.P; i += SWG) {
-    const int gg = i / d.P, p = i - gg * d.P;
-    const int v = d.pair_tab[(size_t)min(g0 + gg, d.B - 1) * d.P + p];
-    ok &= (unsigned)v < (unsigned)d.n_pair_tables;
-    same &= v == row0[p];
-  }
+  if (t < 4) dummy[t] = t == 0 ? make_double2(1.0 / 64.0, 1.0 / 64.0) : (t == 1 ? make_double2(1.0, 1.0) : make_double2(0.25, 0.25));
   bool bad = d.bail[gc] != 0;                                    // the prepare kernel's verdict on this lane's graph
-  const int d0 = row0[0];
-  int d1 = d0;
-  bool over = false;
-  for (int p = 1; p < d.P; ++p) {
-    const int v = row0[p];
-    if (v != d0) {
-      if (d1 == d0) d1 = v;
-      else if (v != d1) over = true;
+  const double2* psrc = reinterpret_cast<const double2*>(d.ptiles + (size_t)wg * d.n_cprod * TILE);
+  double2 pv[8];                                                 // (n_cprod <= 8: shared_plan)
+  int ptile[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    ptile[k] = k < d.n_cprod ? img[d.off_ptile + k] : 0;
+    pv[k] = k < d.n_cprod ? psrc[(size_t)k * (TILE / 2) + t] : make_double2(0.0, 0.0);       // SWG threads x 16 bytes = one tile
+  }
+  // which fragment sets this half keeps, then the fragments (lane: row l & 15, k l >> 4).  One table: BOTH halves keep its two
+  // orientations (partition 1 with T1 = T0), so any member runs on either half and a bundle always splits
+  const bool ok = verdict == 0 && !(NTAB == 1 && d1 != d0);
+  double fr0[16], fr1[16];
+#pragma unroll
+  for (int idx = 0; idx < 2; ++idx) {
+    int sel = 0;
+    for (int q = 0; q < 4; ++q)
+      if (half_of(mode, q) == half && index_in_half(mode, q) == idx) sel = q;
+    const int ti = (sel >> 1) ? d1 : d0, mt = sel & 1;
+    double (&fr)[16] = idx ? fr1 : fr0;
+    if (ok && d.tfrag) {
+      // copies in operand order (shared_prepare_kernel): one contiguous 512-byte read per fragment
+      const double* F = d.tfrag + ((size_t)ti * 2 + mt) * 4096 + rb * 1024 + lane;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) fr[s] = ABL(1024) ? 0.5 : F[64 * s];
+    } else if (ok) {
+      const double* T = d.pair_tables + (size_t)ti * 4096;
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        fr[s] = mt ? T[(4 * s + cq) * 64 + 16 * rb + gl]          // (m^T.T)[x]: A[x][y] = T[y][x]
+                   : T[(16 * rb + gl) * 64 + 4 * s + cq];         // (T.m)[x]  : A[x][y] = T[x][y]
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) fr[s] = 0.0;
     }
   }
-  if (NTAB == 1 && d1 != d0) over = true;
-  // bit p = pairwise factor p reads the group's second table
-  int rankmask = 0;
-  for (int p = 0; p < d.P; ++p) rankmask |= (row0[p] != d0 ? 1 : 0) << p;
+  if (verdict == 1) {                                            // a table index out of range
+    if (t == 0) atomicExch(d.status, 1);
+    return;
+  }
+  if (!ok) {                                                     // not a shared-table batch: the exact kernel takes all 16
+    if (t < G && g0 + t < d.B) d.bail[g0 + t] = 4;
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < d.n_cprod) {
+      reinterpret_cast<double2*>(TP(ptile[k]))[t] = pv[k];
+      if (t < 64) tot[ptile[k] * 64 + t] = 0.25;                 // four partials of a total of 1
+    }
   // tiles the program reads before writing them start as the uniform vector (FactorGraph.initialize, LBP.py:211-216)
   if (PF) {
     // (product-fused: a message tile holds c (.) message; before the first update that is c (.) uniform -- a copy of c)
-    const double2* src = reinterpret_cast<const double2*>(d.ptiles + (size_t)wg * d.n_cprod * TILE);
     for (int k = 0; k < d.n_pinit; ++k) {
       const int tile = img[d.off_pinit + 2 * k], prod = img[d.off_pinit + 2 * k + 1];
-      reinterpret_cast<double2*>(TP(tile))[t] = prod >= 0 ? src[(size_t)prod * (TILE / 2) + t] : make_double2(uniform, uniform);
+      double2 v = make_double2(uniform, uniform);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if (q == prod) v = pv[q];
+      reinterpret_cast<double2*>(TP(tile))[t] = v;
       if (t < 64) tot[tile * 64 + t] = 0.25;
     }
   } else
@@ -1030,61 +1141,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
       if (g0 + gg < d.B) d.msgs[((size_t)(g0 + gg) * d.n_msgs + d.image[d.off_fill + k]) * 64 + x] = uniform;
     }
   STAMP(0)
-  // ---- phase C: which fragment sets each half keeps, then the fragments (lane: row l & 15, k l >> 4) ----
-  // one table: BOTH halves keep its two orientations (partition 1 with T1 = T0), so any member runs on either half and
-  // a bundle always splits
-  const bool single = d1 == d0;
-  int mode = 1;
-  if (!single) {
-    int c0 = 0, c1 = 0, c2 = 0;
-    for (int base = 0; base < d.n_bundles; base += 64) {
-      const int i = base + lane;
-      bool p0 = false, p1 = false, p2 = false;
-      if (i < d.n_bundles) {
-        const int fa = base == 0 ? bundle_fa : d.image[(size_t)i * 2 * MW], fb = base == 0 ? bundle_fb : d.image[(size_t)i * 2 * MW + MW];
-        if ((fa & 1) && (fb & 1)) {
-          const int sa = 2 * ((rankmask >> ((fa >> 16) & 15)) & 1) + ((fa >> 1) & 1);
-          const int sb = 2 * ((rankmask >> ((fb >> 16) & 15)) & 1) + ((fb >> 1) & 1);
-          p0 = half_of(0, sa) != half_of(0, sb); p1 = half_of(1, sa) != half_of(1, sb); p2 = half_of(2, sa) != half_of(2, sb);
-        }
-      }
-      c0 += __popcll(__ballot(p0)); c1 += __popcll(__ballot(p1)); c2 += __popcll(__ballot(p2));
-    }
-    mode = (c0 >= c1 && c0 >= c2) ? 0 : (c1 >= c2 ? 1 : 2);
-  }
-  mode = __builtin_amdgcn_readfirstlane(mode);
-  double fr0[16], fr1[16];
-#pragma unroll
-  for (int idx = 0; idx < 2; ++idx) {
-    int sel = 0;
-    for (int q = 0; q < 4; ++q)
-      if (half_of(mode, q) == half && index_in_half(mode, q) == idx) sel = q;
-    const int ti = (sel >> 1) ? d1 : d0, mt = sel & 1;
-    double (&fr)[16] = idx ? fr1 : fr0;
-    if (ok && d.tfrag) {
-      // copies in operand order (table_fragments_kernel): one contiguous 512-byte read per fragment
-      const double* F = d.tfrag + ((size_t)ti * 2 + mt) * 4096 + rb * 1024 + lane;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) fr[s] = F[64 * s];
-    } else if (ok) {
-      const double* T = d.pair_tables + (size_t)ti * 4096;
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-        fr[s] = mt ? T[(4 * s + cq) * 64 + 16 * rb + gl]          // (m^T.T)[x]: A[x][y] = T[y][x]
-                   : T[(16 * rb + gl) * 64 + 4 * s + cq];         // (T.m)[x]  : A[x][y] = T[x][y]
-    } else {
-#pragma unroll
-      for (int s = 0; s < 16; ++s) fr[s] = 0.0;
-    }
-  }
-  if (!__syncthreads_and(ok ? 1 : 0)) {
-    if (t == 0) atomicExch(d.status, 1);
-    return;
-  }
-  if (!__syncthreads_and(same ? 1 : 0) || over) {                // not a shared-table batch: exact kernel takes all 16
-    if (t < G && g0 + t < d.B) d.bail[g0 + t] = 4;
-    return;
-  }
+  __syncthreads();
   if (SPILL) __syncthreads();                                    // (spilled tiles were written through global memory)
   STAMP(1)
 
@@ -1106,8 +1163,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
     const int gl = lane & 15, cq = lane >> 4;
     const int nsrc = (flags >> 8) & 15;
     const bool want = (flags & (4 | 8 | 16)) != 0, mm = (flags & 1) != 0;
-    const int sel = 2 * ((rankmask >> ((flags >> 16) & 15)) & 1) + ((flags >> 1) & 1);
-    const bool second_set = index_in_half(mode, sel) != 0;
+    const bool second_set = (flags & 0x80) != 0;                 // (resolved by the prologue)
     const int s0 = w3 & 0xFF, s1 = (w3 >> 8) & 0xFF;
     const bool has0 = s0 != 0xFF && !ABL(2), has1 = nsrc > 1 && !ABL(2);
     // an absent source reads a 16-byte constant instead (every lane the same address, stride 0): {1/64, 1/64} for a first
@@ -1235,8 +1291,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
     asm volatile("" : "+v"(lane));
     const int gl = lane & 15, cq = lane >> 4;
     const bool mm = (flags & 1) != 0;
-    const int sel = 2 * ((rankmask >> ((flags >> 16) & 15)) & 1) + ((flags >> 1) & 1);
-    const bool second_set = index_in_half(mode, sel) != 0;
+    const bool second_set = (flags & 0x80) != 0;                 // (resolved by the prologue)
     const int S = (w1 >> 8) & 0xFF, cd = w2 & 0xFF;
     // (the host gives every member a real S tile -- an input that is still the uniform vector reads a tile the prologue filled --
     // and every stored product a c tile: each address below is one base register plus immediate offsets)
@@ -1308,30 +1363,28 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   };
   // the bundles sit in LDS; a bundle's 16 words are read (broadcast) one bundle ahead -- LDS reads return in order, so they
   // cost the tile reads behind them nothing (a scalar load from memory would be waited for with them: one counter)
-  const int4* li = reinterpret_cast<const int4*>(limg);
-  int4 nA = li[0], nB = li[1];
-  for (int k = 0; k < d.n_bundles; ++k) {
-    const int a0 = __builtin_amdgcn_readfirstlane(nA.x), a1 = __builtin_amdgcn_readfirstlane(nA.y), a2 = __builtin_amdgcn_readfirstlane(nA.z),
-              a3 = __builtin_amdgcn_readfirstlane(nA.w);
-    const int b0 = __builtin_amdgcn_readfirstlane(nB.x), b1 = __builtin_amdgcn_readfirstlane(nB.y), b2 = __builtin_amdgcn_readfirstlane(nB.z),
-              b3 = __builtin_amdgcn_readfirstlane(nB.w);
-    int hA = ((a0 & 1) && !single) ? half_of(mode, 2 * ((rankmask >> ((a0 >> 16) & 15)) & 1) + ((a0 >> 1) & 1)) : -1;
-    int hB = ((b0 & 1) && !single) ? half_of(mode, 2 * ((rankmask >> ((b0 >> 16) & 15)) & 1) + ((b0 >> 1) & 1)) : -1;
-    if (hA < 0) hA = hB >= 0 ? 1 - hB : 0;                       // a member that can run anywhere goes to the idle half
-    if (hB < 0) hB = 1 - hA;
+  const int4* li = reinterpret_cast<const int4*>(limg) + half;  // this half's slot of bundle k: li[2 k]
+  int4 nx = li[0];
+  for (int k = 0; k < (ABL(2048) ? 0 : d.n_bundles); ++k) {
+    int cf = __builtin_amdgcn_readfirstlane(nx.x), c1 = __builtin_amdgcn_readfirstlane(nx.y), c2 = __builtin_amdgcn_readfirstlane(nx.z),
+        c3 = __builtin_amdgcn_readfirstlane(nx.w);
+    const bool chain = (cf & CHAIN) != 0;
 #pragma unroll 1
-    for (int mi = 0; mi < 2; ++mi) {                             // (one copy of the member code)
-      const bool second = mi != 0;
-      const int f = second ? b0 : a0;
-      if ((f & 0xFF) != 0 && (second ? hB : hA) == half) {
-        if constexpr (PF) run_pf(f, second ? b1 : a1, second ? b2 : a2);
-        else run(f, second ? b1 : a1, second ? b2 : a2, second ? b3 : a3);
+    for (int rep = 0; rep < 2; ++rep) {                          // (one copy of the member code; the second round only behind CHAIN)
+      if ((cf & 0x7F) != 0) {
+        if constexpr (PF) run_pf(cf, c1, c2);
+        else run(cf, c1, c2, c3);
       }
+      if (rep == 1 || !chain) break;
+      const int4 o = reinterpret_cast<const int4*>(limg)[2 * k + 1 - half];      // the member parked in the other half's slot
+      const int ox = __builtin_amdgcn_readfirstlane(o.x);
+      cf = (int)((unsigned)ox >> 24) | (ox & 0x00FFFF00);
+      c1 = __builtin_amdgcn_readfirstlane(o.y); c2 = __builtin_amdgcn_readfirstlane(o.z); c3 = __builtin_amdgcn_readfirstlane(o.w);
     }
     // the next bundle's words are requested here, behind the member (its registers are free again) and in front of the
     // barrier (they arrive while the workgroup meets)
     __builtin_amdgcn_sched_barrier(0);
-    nA = li[2 * k + 2]; nB = li[2 * k + 3];                      // the image is padded by one bundle
+    nx = li[2 * k + 2];                                          // the image is padded by one bundle
     if constexpr (PF) {
       // LDS traffic only: the stores to memory a member may have issued (stash, last variable->factor values) are read after the
       // loop, behind a full __syncthreads -- the fence of one here would wait for them in every bundle
@@ -1359,61 +1412,89 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
     // results the members stashed in memory: the workgroup's own stores, visible behind the fence of a full barrier.)
     if (stash_g) __syncthreads();
     const const_i32p rd = as_const(d.readout);
-    if (d.marginals) {
-      for (int v = wave; v < d.n_vars; v += SWG / 64) {
-        const int at = rd[v];
-        const int base = rd[at], n = rd[at + 1];
-        int n_p = 0, n_t = 0;
-        for (int q = 0; q < n; ++q) {
-          const int tl = rd[at + 2 + q];
-          if (img[d.off_stash + tl] >= 0) { ++n_t; n_p += img[d.off_stash + d.n_live + tl]; }
-        }
-        double m[16];
-        if (n_t == 0 || n_p == 0) {                              // c itself (or uniform) times the messages
-          if (base >= 0) {
-            const double2* src = reinterpret_cast<const double2*>(tiles + (size_t)base * TILE) + lane;
+    if (d.marginals && !ABL(512)) {
+      // jobs (variable v, quarter h of its states: k-steps 4 h .. 4 h + 3) over the eight waves; a job's values stay in registers
+      // while the quarters' column sums meet in LDS (the totals row of the variable's c tile is free: 4 x 16 doubles)
+      constexpr int JW = 4;                                      // jobs a wave may hold (4 n_vars <= 32 jobs: n_vars <= 8; beyond, the rest in a second pass)
+      const int n_jobs = 4 * d.n_vars;
+      for (int j0 = 0; j0 < n_jobs; j0 += JW * (SWG / 64)) {
+        double m[JW][4];
 #pragma unroll
-            for (int sp = 0; sp < 8; ++sp) { const double2 x = src[64 * sp]; m[2 * sp] = x.x; m[2 * sp + 1] = x.y; }
-          } else {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) m[s] = uniform;
+        for (int q = 0; q < JW; ++q) {
+          const int j = j0 + wave + q * (SWG / 64);
+          if (j >= n_jobs) continue;
+          const int v = j >> 2, h = j & 3;
+          const int at = rd[v];
+          const int base = rd[at], n = rd[at + 1];
+          int n_p = 0, n_t = 0;
+          for (int k = 0; k < n; ++k) {
+            const int tl = rd[at + 2 + k];
+            if (img[d.off_stash + tl] >= 0) { ++n_t; n_p += img[d.off_stash + d.n_live + tl]; }
           }
-        } else {
+          double2 c0 = make_double2(uniform, uniform), c1 = c0;
+          if (base >= 0) {
+            const double2* src = reinterpret_cast<const double2*>(tiles + (size_t)base * TILE) + 128 * h + lane;
+            c0 = src[0]; c1 = src[64];
+          }
+          const bool from_c = n_t == 0 || n_p == 0;              // c itself (or uniform) times the messages
+          m[q][0] = from_c ? c0.x : 1.0; m[q][1] = from_c ? c0.y : 1.0; m[q][2] = from_c ? c1.x : 1.0; m[q][3] = from_c ? c1.y : 1.0;
+          int p_left = n_p;
+          for (int k = 0; k < n; ++k) {
+            const int tl = rd[at + 2 + k];
+            if (img[d.off_stash + tl] < 0) continue;             // never updated: still uniform, cancels in the normalisation
+            const bool is_p = img[d.off_stash + d.n_live + tl] != 0;
+            const double2* tp = reinterpret_cast<const double2*>(tot + tl * 64 + gl * 4);
+            const double2 ta = tp[0], tb = tp[1];
+            const double2* src = reinterpret_cast<const double2*>(tiles + (size_t)tl * TILE) + 128 * h + lane;
+            const double2 x0 = src[0], x1 = src[64];
+            const double total = (ta.x + ta.y) + (tb.x + tb.y);
+            bad |= !total_ok(total);
+            const double inv = __builtin_amdgcn_rcp(total);      // (any positive scale: it cancels below)
+            m[q][0] *= x0.x * inv; m[q][1] *= x0.y * inv; m[q][2] *= x1.x * inv; m[q][3] *= x1.y * inv;
+            if (is_p && --p_left > 0) {                          // another c (.) message follows: take this one's c out first (no underflow of the pair)
+              const double cc[4] = {c0.x, c0.y, c1.x, c1.y};
 #pragma unroll
-          for (int s = 0; s < 16; ++s) m[s] = 1.0;
-        }
-        int p_left = n_p;
-        for (int q = 0; q < n; ++q) {
-          const int tl = rd[at + 2 + q];
-          if (img[d.off_stash + tl] < 0) continue;               // never updated: still uniform, cancels in the normalisation
-          const bool is_p = img[d.off_stash + d.n_live + tl] != 0;
-          const double* tp = tot + tl * 64 + gl * 4;
-          const double total = (tp[0] + tp[1]) + (tp[2] + tp[3]);
-          bad |= !total_ok(total);
-          const double inv = 1.0 / total;
-          const double2* src = reinterpret_cast<const double2*>(tiles + (size_t)tl * TILE) + lane;
-#pragma unroll
-          for (int sp = 0; sp < 8; ++sp) { const double2 x = src[64 * sp]; m[2 * sp] *= x.x * inv; m[2 * sp + 1] *= x.y * inv; }
-          if (is_p && --p_left > 0) {                            // another c (.) message follows: take this one's c out first (no underflow of the pair)
-            const double2* cs = reinterpret_cast<const double2*>(tiles + (size_t)base * TILE) + lane;
-#pragma unroll
-            for (int sp = 0; sp < 8; ++sp) {
-              const double2 c = cs[64 * sp];
-              m[2 * sp] = c.x > 0.0 ? m[2 * sp] / c.x : 0.0; m[2 * sp + 1] = c.y > 0.0 ? m[2 * sp + 1] / c.y : 0.0;
+              for (int r = 0; r < 4; ++r) {                      // m / c by the hardware reciprocal and one Newton step (3e-17 relative)
+                double rc = __builtin_amdgcn_rcp(cc[r]);
+                rc = __builtin_fma(__builtin_fma(-cc[r], rc, 1.0), rc, rc);
+                m[q][r] = cc[r] > 1e-290 ? m[q][r] * rc : 0.0;
+              }
             }
           }
+          const double part = column_sum((m[q][0] + m[q][1]) + (m[q][2] + m[q][3]));
+          // the meeting place: the totals row of the variable's c tile (nothing reads a c tile's totals behind the main loop; the
+          // launcher takes this form only when every variable of the read-out has a constant product)
+          if (cq == 0) tot[base * 64 + h * G + gl] = part;
         }
-        double part = 0.0;
+        __syncthreads();
+        // the normalised values go through LDS once more (the tiles are spent: every job has read its own), so that they leave as
+        // whole 512-byte rows, one per (graph, variable): written from this layout they were 32-byte pieces of sixteen rows per
+        // store, and the launch spent 6 us draining 12.6 MB of them
+        double* stage = tiles;                                   // [variable of this pass][graph][65]
 #pragma unroll
-        for (int s = 0; s < 16; ++s) part += m[s];
-        const double tm = column_sum(part);
-        bad |= !total_ok(tm);
-        if (gvalid && !bad) {
-          double* out = d.marginals + ((size_t)gc * d.n_vars + v) * 64 + cq;
+        for (int q = 0; q < JW; ++q) {
+          const int j = j0 + wave + q * (SWG / 64);
+          if (j >= n_jobs) continue;
+          const int v = j >> 2, h = j & 3;
+          const double* rp = tot + rd[rd[v]] * 64 + gl;
+          const double tm = (rp[0] + rp[G]) + (rp[2 * G] + rp[3 * G]);
+          bad |= !total_ok(tm);
           const double itm = 1.0 / tm;
+          double* o = stage + ((size_t)(v - (j0 >> 2)) * G + gl) * 65 + 16 * h + cq;
 #pragma unroll
-          for (int s = 0; s < 16; ++s) out[4 * s] = m[s] * itm;
+          for (int r = 0; r < 4; ++r) o[4 * r] = m[q][r] * itm;
         }
+        __syncthreads();
+        {
+          const unsigned long long flagged = __ballot(bad);
+          const int v0 = j0 >> 2, nv = min(d.n_vars - v0, JW * (SWG / 64) / 4);
+          for (int row = wave; row < nv * G; row += SWG / 64) {
+            const int g = row & (G - 1), v = v0 + (row >> 4);
+            if (g0 + g < d.B && !((flagged >> g) & 0x0001000100010001ull))
+              __builtin_nontemporal_store(stage[(size_t)row * 65 + lane], &d.marginals[((size_t)(g0 + g) * d.n_vars + v) * 64 + lane]);
+          }
+        }
+        if (j0 + JW * (SWG / 64) < n_jobs) __syncthreads();
       }
     }
     if (d.msgs && !d.vf_only && stash_g)
@@ -1843,7 +1924,7 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   const int n_groups = (a->B + G - 1) / G;
   // the product-fused form (diagnostic switch: MLBP_SHARED_NO_PF in the environment keeps the general form)
   static const bool no_pf = getenv("MLBP_SHARED_NO_PF") != nullptr;
-  const bool pf = sp.pf_ok && !no_pf && n_res == sp.n_live && sp.max_sources <= 2;
+  const bool pf = sp.pf_ok && !no_pf && n_res == sp.n_live && sp.max_sources <= 2 && (!a->marginals || prog->sreadout_all_based) && prog->n_vars <= 8;     // (the read-out stages 8 variables' rows in the spent tiles)
   const size_t spill_doubles = pf ? (size_t)n_groups * sp.n_stash * TILE : (size_t)n_groups * (sp.n_live - n_res) * TILE;
   // (first use at this size allocates -- a stream-capturing caller warms up or reserves first; a block that is outgrown stays
   // alive with the program: program_grow)
@@ -1851,6 +1932,7 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
     if (int e = program_grow(mp, reinterpret_cast<void**>(&mp->d_spill), &mp->spill_cap, spill_doubles * sizeof(double))) return e;
   const size_t ptile_doubles = (size_t)n_groups * n_cprod * TILE;
   if (int e = program_grow(mp, reinterpret_cast<void**>(&mp->d_ptiles), &mp->ptiles_cap, ptile_doubles * sizeof(double))) return e;
+  if (int e = program_grow(mp, reinterpret_cast<void**>(&mp->d_header), &mp->header_cap, (size_t)n_groups * HDR * sizeof(int32_t))) return e;
   if (mp->bail_cap < a->B)
     if (int e = mlbp_program_reserve(mp, a->B)) return e;
   SharedDev& d = out->d;
@@ -1869,6 +1951,7 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   d.off_written = sp.off_written;
   d.off_pfb = sp.off_pfb; d.off_stash = sp.off_stash; d.off_pinit = sp.off_pinit; d.n_pinit = sp.n_pinit; d.n_stash = sp.n_stash;
   d.stash = pf ? mp->d_spill : nullptr;
+  d.header = mp->d_header;
   out->pf = pf;
   d.tfrag = nullptr;
   if (a->n_pair_tables <= FRAG_TABLES) {
@@ -1884,6 +1967,7 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   q.unary_tables = a->unary_tables; q.unary_tab = a->unary_tab; q.ent = prog->d_simage + sp.off_ent;
   q.ptiles = mp->d_ptiles; q.bail = mp->d_bail; q.status = prog->d_status;
   q.B = a->B; q.U = prog->U; q.n_unary_tables = a->n_unary_tables; q.E = sp.n_cpw / 4; q.n_cprod = n_cprod; q.n_groups = n_groups;
+  q.pair_tab = a->pair_tab; q.image = prog->d_simage; q.header = mp->d_header; q.P = prog->P; q.n_pair_tables = a->n_pair_tables; q.n_bundles = sp.n_bundles;
   // the gradient as the sweep kernel's epilogue (the prepare launch also writes its weighted table fragments)
   if (shared_gradient_fused(prog, a)) {
     const mlbp_gradient_args* ga = a->gradient;

@@ -601,14 +601,39 @@ __device__ __forceinline__ void sweep_x64_fused_body(const SweepDev& d, const Fu
 // Log-posteriors of the block's 64 graphs from the marginals in memory (the fast kernel's, or the ones this workgroup has just
 // redone), and -- sum_out given -- their batch sum in a fixed order: lanes, then the blocks' partials by the last block to
 // arrive (the two-counter protocol of log_posterior_kernel).
-__device__ __forceinline__ void posterior_of_block(const SweepDev& d, const PosteriorDev& p, int base, int n_graphs) {
+// The label thread t reads when the block's variables fit one wave each (n_vars <= WG / 64: wave v takes variable v of the
+// block's 64 graphs), requested by the caller TOGETHER with the flags -- one round of memory latency instead of two; -1: none.
+__device__ __forceinline__ int posterior_prefetch_label(const SweepDev& d, const PosteriorDev& p, int base, int n_graphs) {
+  const int t = threadIdx.x, v = t >> 6, g = base + (t & 63);
+  if (!p.labels || d.n_vars > WG / 64 || v >= d.n_vars || g >= n_graphs) return -1;
+  return p.labels[(size_t)g * d.n_vars + v];
+}
+__device__ __forceinline__ void posterior_of_block(const SweepDev& d, const PosteriorDev& p, int base, int n_graphs, int my_label) {
   __shared__ double part[WG / 64];
+  __shared__ double lpv[WG];
   __shared__ bool last;
   __syncthreads();                                   // (the marginals of graphs redone above are this workgroup's own stores)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   double total = 0.0;
   const int g = base + t;
-  if (t < FIXUP_GRAPHS_PER_WG && g < n_graphs) {
+  if (d.n_vars <= WG / 64) {
+    // thread (variable t >> 6, graph t & 63): label (here already) -> marginal entry -> log, all the block's entries in ONE round
+    // of latency; then the graph's terms are added in variable order, as the loop below adds them
+    double lp = 0.0;
+    if (wave < d.n_vars && base + lane < n_graphs) {
+      if ((unsigned)my_label >= 64u) atomicExch(d.status, 1);
+      else {
+        lp = log(d.marginals[((size_t)(base + lane) * d.n_vars + wave) * 64 + my_label]);
+        if (lp == -__builtin_huge_val()) lp = -99.99;        // LBP.py:254-256
+      }
+    }
+    lpv[t] = lp;
+    __syncthreads();
+    if (t < FIXUP_GRAPHS_PER_WG && g < n_graphs) {
+      for (int v = 0; v < d.n_vars; ++v) total += lpv[v * 64 + t];
+      p.out[g] = total;
+    }
+  } else if (t < FIXUP_GRAPHS_PER_WG && g < n_graphs) {
     for (int v = 0; v < d.n_vars; ++v) {
       const int lab = p.labels[(size_t)g * d.n_vars + v];
       if ((unsigned)lab >= 64u) { atomicExch(d.status, 1); continue; }
@@ -650,9 +675,11 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
   // fix-up mode: all 64 flags in one load (lane i of every wave reads flag i; the ballot is the same in the four waves)
   int base = blockIdx.x;
   unsigned long long todo = 1;
+  int my_label = -1;
   if (f.only) {
     base = blockIdx.x * FIXUP_GRAPHS_PER_WG;
     const int mine = base + (threadIdx.x & 63);
+    my_label = posterior_prefetch_label(d, f.post, base, f.n_graphs);      // (requested with the flags)
     todo = __ballot(mine < f.n_graphs && f.only[mine] != 0);
   }
   while (todo) {
@@ -661,7 +688,7 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
     sweep_x64_fused_body<NORM, NT, GRAD>(d, f, gf, base + i);
     if (todo) __syncthreads();
   }
-  if (f.only && f.post.labels) posterior_of_block(d, f.post, base, f.n_graphs);
+  if (f.only && f.post.labels) posterior_of_block(d, f.post, base, f.n_graphs, my_label);
 }
 
 // The fix-up pass for SEVERAL groups of graphs in one launch (mlbp_sweep_groups_f64 behind the shared-table kernels: a
@@ -1555,7 +1582,7 @@ int mlbp_program_destroy(mlbp_program* p) {
   (void)hipFree(p->d_ops); (void)hipFree(p->d_srcs); (void)hipFree(p->d_sweeps);
   (void)hipFree(p->d_pairseq); (void)hipFree(p->d_status);
   (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq); (void)hipFree(p->d_bail); (void)hipFree(p->d_readout);
-  (void)hipFree(p->d_limage); (void)hipFree(p->d_lreadout); (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout); (void)hipFree(p->d_tfrag); (void)hipFree(p->d_spill); (void)hipFree(p->d_ptiles); (void)hipFree(p->d_wfrag);
+  (void)hipFree(p->d_limage); (void)hipFree(p->d_lreadout); (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout); (void)hipFree(p->d_tfrag); (void)hipFree(p->d_spill); (void)hipFree(p->d_ptiles); (void)hipFree(p->d_wfrag); (void)hipFree(p->d_header);
   (void)hipFree(p->d_gfrag); (void)hipFree(p->d_gxbuf); (void)hipFree(p->d_gwork);
   for (void* q : p->retired) (void)hipFree(q);
   mlbp::group_tables_free(p->gtables); mlbp::group_tables_free(p->stables);
@@ -2029,7 +2056,10 @@ int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_
   p->d_sreadout = nullptr;
   p->n_sreadout = 0;
   std::vector<int32_t> simg;
+  p->sreadout_all_based = false;
   if (p->shared.ok && mlbp::build_shared_readout(p->shared, p->n_msgs, n_vars, in_off, in_slots, simg)) {
+    p->sreadout_all_based = true;
+    for (int v = 0; v < n_vars; ++v) p->sreadout_all_based &= simg[simg[v]] >= 0;
     HIP_TRY(hipMalloc(&p->d_sreadout, simg.size() * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(p->d_sreadout, simg.data(), simg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     p->n_sreadout = (int)simg.size();

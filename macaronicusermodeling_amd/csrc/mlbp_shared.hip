@@ -608,6 +608,10 @@ struct PrepareDev {
 constexpr int HDR = 8;
 // MULTI: several groups of graphs (mlbp_sweep_groups_f64: every group its own program, tables, messages) in one launch;
 // gtab[k] = the group's PrepareDev, gstart[k] = its first block (ascending; gstart[n_groups] = the grid size).
+// (Measured and not kept, round 4: a STAGED form -- one 1024-thread workgroup per CU copies the unary tables, 96 KB for the trainer's
+// pots, into LDS once and takes every n-th group of 16 graphs, rows out of LDS, next group's indices prefetched, two sets of
+// tiles -- 14.6 us against 13.0: sixteen waves per CU walk their chains of round trips one group after the other, thirty-two
+// overlap them.)
 template <bool MULTI>
 __global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, const PrepareDev* gtab, const int32_t* gstart, int n_groups) {
   extern __shared__ double ptile_lds[];                          // [n_cprod][1024] the group's product tiles, assembled here and stored as whole lines
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, co
     block -= as_const(gstart)[lo];
     n_blocks = as_const(gstart)[lo + 1] - as_const(gstart)[lo];
   }
-  for (int q = block; q < 2 * d.n_frag_tables; q += n_blocks) {
+  for (int q = block; q < (ABL(16384) ? 0 : 2 * d.n_frag_tables); q += n_blocks) {
     const int ti = q >> 1, mt = q & 1;
     const double* T = d.pair_tables + (size_t)ti * 4096;
     double* o = d.tfrag + ((size_t)ti * 2 + mt) * 4096;
@@ -660,26 +664,28 @@ __global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, co
   // one workgroup = one group of 16 graphs, one wave per graph: a wave writes its column of the group's tiles into LDS, and the
   // workgroup stores each tile as whole cache lines (a wave's column alone is 16 bytes in each of 32 lines per tile: the
   // partial-line stores of 16 different waves into the same lines were what this launch spent most of its time on)
+  __shared__ int hdr_ok[PGB], hdr_same[PGB];
+  // (the first 64 entries of the constant-product list: program data -- requested up front)
+  const int ent_u0 = d.ent[4 * min(lane, d.E - 1)], ent_flags0 = d.ent[4 * min(lane, d.E - 1) + 3];
   const int g = block * PGB + wave;
   const bool on = g < d.B;
   const int col = wave;
   // the group's header: wave w compares graph w's table indices with the group's first graph's (lane p: pairwise factor p) ...
-  __shared__ int hdr_ok[PGB], hdr_same[PGB];
   // (one register -- lanes 0..P-1: this graph's row, lanes 16..16+P-1: the group's first graph's; P <= 16 -- requested here, looked
   // at behind the products: nothing below waits for it, and the kernel's 64 registers hold it without a spill)
   int pair_rows = 0;
-  if (d.header && (lane & 15) < d.P && lane < 32)
+  if (d.header && (lane & 15) < d.P && lane < 32 && !ABL(32768))
     pair_rows = d.pair_tab[(size_t)(lane < 16 ? min(g, d.B - 1) : block * PGB) * d.P + (lane & 15)];
+  // lane u holds the table row of the graph's unary factor u (U <= 64: build_shared_program), lane e entry e of the
+  // constant-product list; both loads are independent, the entry's row then comes through the lane crossbar
+  int my_row = (on && lane < d.U && !ABL(4096)) ? d.unary_tab[(size_t)g * d.U + lane] : 0;
   if (on) {
   constexpr int RB = 8;
   constexpr unsigned KEY_LIMIT = 0x7A11A0FCu;                    // high word of 1e280
   double cur = 1.0;
   unsigned key = 0;
   int k_out = 0;
-  bool flagged = false;
-  // lane u holds the table row of the graph's unary factor u (U <= 64: build_shared_program), lane e entry e of the
-  // constant-product list; both loads are independent, the entry's row then comes through the lane crossbar
-  int my_row = lane < d.U ? d.unary_tab[(size_t)g * d.U + lane] : 0;
+  bool flagged = false, open_product = false;
   if ((unsigned)my_row >= (unsigned)d.n_unary_tables) { flagged = true; my_row = 0; }    // the exact kernel meets it again and reports it
   // the unary factors' gradient terms (LBP.py:592-619 with the belief's expectation taken once per table row): eight lanes
   // per factor -- lane 8 j + k takes feature k of factor 8 c + j -- so that a factor's row of expected features and its
@@ -702,44 +708,72 @@ __global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, co
       if (kind == 2) u_ed += v; else u_ee += v;
     }
   }
-  for (int c0 = 0; c0 < d.E; c0 += 64) {                          // (more than 64 entries: a chunk at a time)
+  for (int c0 = 0; c0 < (ABL(8192) ? 0 : d.E); c0 += 64) {        // (more than 64 entries: a chunk at a time)
     const int el = min(c0 + lane, d.E - 1), n_here = min(64, d.E - c0);
-    const int ent_u = d.ent[4 * el], ent_flags = d.ent[4 * el + 3];
+    const int ent_u = c0 == 0 ? ent_u0 : d.ent[4 * el], ent_flags = c0 == 0 ? ent_flags0 : d.ent[4 * el + 3];
     const int row = __shfl(my_row, ent_u);
-    // The scale of a unary message cancels in everything downstream (only its normalised form is ever stored, by
-    // unary_writeback_kernel), so the raw columns are multiplied and the PRODUCT is normalised once (hardware
-    // reciprocal: only the magnitude matters).  A column Message.renormalize would replace by the uniform vector
-    // (total <= 0, LBP.py:655-657) zeroes the product, and an entry that is negative, not finite or huge shows in the
-    // high words: either sends the graph to the exact kernel, decided once per product.
-    auto fetch = [&](double (&r)[RB], int e0) {
-#pragma unroll
-      for (int j = 0; j < RB; ++j) r[j] = ABL(8) ? 0.5 : d.unary_tables[(size_t)__builtin_amdgcn_readlane(row, min(e0 + j, n_here - 1)) * 64 + lane];
+    // The entries of one product are consecutive; the products' ends are the set bits of `ends`.  Batches of up to RB rows of ONE
+    // product, two batches in flight (the next one -- of this product or the first of the next -- is requested before this one is
+    // multiplied), every test on an entry a SCALAR one: the flag-driven form of this loop was some twenty vector instructions per
+    // row and sixteen copies of the product's finish, and the launch was bound by instruction issue (eight waves per SIMD).
+    const unsigned long long real_ends = __ballot((ent_flags & 2) != 0 && lane < n_here);
+    unsigned long long ends = real_ends | (1ull << (n_here - 1));        // (a product that runs on into the next chunk of 64 entries pauses at the chunk's end)
+    int e_next = 0, p_last = -1;                                 // next entry to hand out; last entry of the product being handed out
+    auto next_batch = [&](int& b0, int& b1) {                    // false: no entries left
+      if (e_next > p_last) {
+        if (!ends) return false;
+        p_last = __builtin_ctzll(ends);
+        ends &= ends - 1;
+      }
+      b0 = e_next; b1 = min(e_next + RB - 1, p_last); e_next = b1 + 1;
+      return true;
     };
-    auto reduce = [&](const double (&r)[RB], int e0) {
+    auto fetch = [&](double (&r)[RB], int b0, int b1) {
 #pragma unroll
       for (int j = 0; j < RB; ++j) {
-        if (e0 + j < n_here) {
-          const int flags = __builtin_amdgcn_readlane(ent_flags, e0 + j);
-          if (flags & 1) { cur = 1.0; key = 0; }
-          key = max(key, (unsigned)__double2hiint(r[j]));
-          cur *= r[j];
-          if (flags & 2) {
-            const double sum = wave_sum(cur);
-            flagged |= !total_ok(sum) || __any(key > KEY_LIMIT);
-            // (a true division: the product-fused sweep kernel takes this tile's total to be 1 when it writes the tile out as a message)
-            ptile_lds[(size_t)k_out * TILE + tile_index(lane, col)] = cur * (1.0 / sum);
-            ++k_out;
-          }
-        }
+        const int rj = __builtin_amdgcn_readlane(row, min(b0 + j, b1));
+        r[j] = ABL(8) ? 0.5 : d.unary_tables[(size_t)rj * 64 + lane];
       }
     };
-    double ra[RB], rc[RB];                                        // two batches of rows: one in flight behind the one being reduced
-    fetch(ra, 0);
-    for (int e0 = 0; e0 < n_here; e0 += 2 * RB) {
-      if (e0 + RB < n_here) fetch(rc, e0 + RB);
-      reduce(ra, e0);
-      if (e0 + 2 * RB < n_here) fetch(ra, e0 + 2 * RB);
-      if (e0 + RB < n_here) reduce(rc, e0 + RB);
+    auto reduce = [&](const double (&r)[RB], int b0, int b1, bool first, bool last) {
+      if (first) { cur = 1.0; key = 0; }
+#pragma unroll
+      for (int j = 0; j < RB; ++j)
+        if (b0 + j <= b1) { key = max(key, (unsigned)__double2hiint(r[j])); cur *= r[j]; }
+      if (last) {
+        // The scale of a unary message cancels in everything downstream (only its normalised form is ever stored, by
+        // unary_writeback_kernel), so the raw columns are multiplied and the PRODUCT is normalised once.  A column
+        // Message.renormalize would replace by the uniform vector (total <= 0, LBP.py:655-657) zeroes the product, and an entry
+        // that is negative, not finite or huge shows in the high words: either sends the graph to the exact kernel, decided once
+        // per product.
+        const double sum = wave_sum(cur);
+        flagged |= !total_ok(sum) || __any(key > KEY_LIMIT);
+        // (1 / sum by the hardware reciprocal and one Newton step, 2^-54: the product-fused sweep kernel takes this tile's total to
+        // be 1 when it writes the tile out as a message)
+        double inv_sum = __builtin_amdgcn_rcp(sum);
+        inv_sum = __builtin_fma(__builtin_fma(-sum, inv_sum, 1.0), inv_sum, inv_sum);
+        if (!ABL(65536)) ptile_lds[(size_t)k_out * TILE + tile_index(lane, col)] = cur * inv_sum;
+        ++k_out;
+      }
+    };
+    double ra[RB], rc[RB];
+    int a0 = 0, a1 = 0, c0_ = 0, c1_ = 0;
+    bool have_a = next_batch(a0, a1), have_c = false;
+    bool a_first = !open_product;
+    if (have_a) fetch(ra, a0, a1);
+    while (have_a) {
+      const bool a_last = ((real_ends >> a1) & 1) != 0;
+      have_c = next_batch(c0_, c1_);
+      if (have_c) fetch(rc, c0_, c1_);
+      reduce(ra, a0, a1, a_first, a_last);
+      open_product = !a_last;
+      if (!have_c) break;
+      const bool c_first = a_last, c_last = ((real_ends >> c1_) & 1) != 0;
+      have_a = next_batch(a0, a1);
+      if (have_a) fetch(ra, a0, a1);
+      reduce(rc, c0_, c1_, c_first, c_last);
+      a_first = c_last;
+      open_product = !c_last;
     }
   }
   if (__any(flagged)) flagged = true;
@@ -764,7 +798,7 @@ __global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, co
     double2* dst = reinterpret_cast<double2*>(d.ptiles + (size_t)block * d.n_cprod * TILE);
     for (int i = t; i < d.n_cprod * (TILE / 2); i += PWG) dst[i] = src[i];          // (columns of graphs beyond B: whatever LDS held; never read as results)
   }
-  if (d.header && wave == PWG / 64 - 1) {
+  if (d.header && wave == PWG / 64 - 1 && !ABL(32768)) {
     // ... and wave 0 finishes it: the distinct tables, which factor reads which, and the partition that splits most bundles
     const bool ok = __all(lane >= PGB || hdr_ok[lane & (PGB - 1)] != 0), same = __all(lane >= PGB || hdr_same[lane & (PGB - 1)] != 0);
     const int d0 = __builtin_amdgcn_readfirstlane(first_row);

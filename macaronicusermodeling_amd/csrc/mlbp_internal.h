@@ -53,7 +53,8 @@ struct SharedProgram {
   // product-fused form (degree <= 2 variables: K2, K3, chains, rings): the producer of a factor->variable message stores it
   // already multiplied by the destination variable's constant product, so a contraction reads ONE tile and multiplies nothing
   bool pf_ok = false;
-  int off_pfb = 0, off_stash = 0, off_pinit = 0, n_stash = 0, n_pinit = 0;
+  int off_pfb = 0, off_stash = 0, off_pinit = 0, n_stash = 0, n_pinit = 0, off_vftile = 0;
+  bool vf_direct = false;             // the gradient epilogue may read the final variable->factor messages from the message tiles
   std::vector<int32_t> sweeps;         // {first op, count} of the transformed op list (one sequence: sweep boundaries mean nothing here)
   std::vector<int32_t> image;          // bundles [n_bundles + 1][2][16] | cprod entries [n_cpw] | write-back pairs [n_back][2] | fill slots [n_fill] | uniform tiles [n_init]
   std::vector<int32_t> live_of_slot;   // [n_msgs + 1 + n_cprod] LDS tile of a slot (ext slots included) or -1

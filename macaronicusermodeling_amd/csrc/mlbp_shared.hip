@@ -371,6 +371,26 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
         pinit.push_back(tl); pinit.push_back(cp[tl] >= 0 ? prod_of_tile[cp[tl]] : -1);
       }
       out.n_pinit = (int)pinit.size() / 2;
+      // The gradient epilogue takes a factor's two variable->factor messages straight from LDS when every such slot's last value
+      // (the input S of its flag-8 member) is a message tile no later member rewrites: vftile[slot] = that tile, -1 = never updated
+      // (uniform), and the form is off (vf_direct false) when some slot has no such tile or its S is a constant-product tile (the
+      // read-out stages the marginals there).
+      std::vector<int32_t> vftile(n_msgs, -1);
+      out.vf_direct = true;
+      for (int i = 0; i < n_ops; ++i) {
+        const int32_t* m = &mem[(size_t)i * MW];
+        if (!(m[0] & 8)) continue;
+        const int tl = s_of[i];
+        bool intact = tl != 0xFF && !is_c[tl];
+        for (int j = i; j < n_ops && intact; ++j) {               // (member i itself included: its own result must land elsewhere)
+          const int32_t* mj = &mem[(size_t)j * MW];
+          if ((mj[0] & 1) && mj[2] == tl) intact = false;
+        }
+        if (!intact) { out.vf_direct = false; break; }
+        vftile[m[4]] = tl;
+      }
+      for (int c = 0; c < n_msgs && out.vf_direct; ++c)
+        if (out.hoisted[c] < 0 && is_vf[c] && vftile[c] < 0) out.vf_direct = false;      // (a slot some variable update writes but no flag-8 member hands out)
       out.off_pfb = (int)out.image.size();
       out.image.insert(out.image.end(), pfb.begin(), pfb.end());
       out.off_stash = (int)out.image.size();
@@ -378,6 +398,8 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
       for (int tl = 0; tl < out.n_live; ++tl) out.image.push_back(cp[tl] >= 0 ? 1 : 0);       // [n_live] behind it: the tile holds c (.) message (else the message)
       out.off_pinit = (int)out.image.size();
       out.image.insert(out.image.end(), pinit.begin(), pinit.end());
+      out.off_vftile = (int)out.image.size();
+      out.image.insert(out.image.end(), vftile.begin(), vftile.end());
       for (int q = 0; q < 16; ++q) out.image.push_back(0);
       if (getenv("MLBP_DEBUG_SHARED_PROGRAM")) {
         for (size_t i = 0; i + 3 < pfb.size(); i += 4) fprintf(stderr, "pf member: flags 0x%02x pair %d dst %d S %d slot %d c %d stash %d\n", pfb[i] & 0xFF,
@@ -521,6 +543,8 @@ struct SharedDev {
   int32_t off_pfb, off_stash, off_pinit, n_pinit, n_stash, pad2_;
   double* stash;
   const int32_t* header;        // [groups][HDR] shared_prepare_kernel's verdict on each group of 16 graphs and its fragment sets
+  int32_t off_vftile, vf_direct;  // product-fused + gradient: the epilogue reads the final variable->factor messages from the message tiles
+  int32_t lds_bytes, pad3_;     // the workgroup's dynamic LDS
   SharedGradDev gr;
 };
 
@@ -846,7 +870,11 @@ __device__ __forceinline__ Words16 sload16(const int32_t* p) {
 // The gradient epilogue of the sweep kernel (below).  It forms every lane-derived value again from the thread id: values shared with
 // the code in front of the main loop would be held in registers across it, and the loop's fragments would go to scratch inside the
 // MFMA sequences.  (As a real function call it paid the ABI's callee-saved registers and spills of its own: 70 -> 95 us.)
-template <typename Dev>
+// DIRECT (product-fused kernel, SharedProgram::vf_direct): a factor's two variable->factor messages are message tiles the sweeps
+// left in LDS -- c (.) message, unnormalised: any positive per-graph scale cancels in S / Z -- so nothing is written to the message
+// buffer during the sweeps and nothing read back here; partial sums and per-graph terms live in the totals' rows (spent) and the
+// spare LDS behind them.
+template <bool DIRECT, typename Dev>
 __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
   extern __shared__ double lds[];
   double* tiles = lds;
@@ -861,10 +889,15 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
   STAMP_DECL
   ABL_DECL
   STAMP_START
+  if (DIRECT && t == 0) *reinterpret_cast<double2*>(reinterpret_cast<char*>(lds) + d.lds_bytes - 16) = make_double2(uniform, uniform);
   __syncthreads();
-  const int NP = min(4, (d.n_res - 1) >> 1);                     // factors per pass: two tiles each, one tile of partial sums
-  double* red = tiles + (size_t)2 * NP * TILE;                   // [factor][k][row block][graph]
-  double* pc = tot;                                              // [factor][graph][3] per-graph terms of a pass (the totals are spent)
+  // factors per pass -- memory form: two tiles each, one tile of partial sums; direct form: what the totals' rows and the spare LDS
+  // behind them hold (per factor 256 partial sums + 48 per-graph terms)
+  const int NP = DIRECT ? min(4, (int)((d.lds_bytes - 16 - (size_t)d.n_res * TILE * sizeof(double)) / ((256 + 48) * sizeof(double)))) : min(4, (d.n_res - 1) >> 1);
+  double* red = DIRECT ? tot : tiles + (size_t)2 * NP * TILE;    // [factor][k][row block][graph]
+  double* pc = DIRECT ? tot + (size_t)NP * 256 : tot;            // [factor][graph][3] per-graph terms of a pass (the totals are spent)
+  // (direct form: the uniform vector's 16 bytes at the very end of the workgroup's LDS -- the sweeps' constants lie inside `red`)
+  const double2* const uni2 = reinterpret_cast<const double2*>(reinterpret_cast<const char*>(lds) + d.lds_bytes - 16);
   double out3[3] = {0.0, 0.0, 0.0};                              // thread t < 16: graph g0 + t
   for (int p0 = 0; p0 < d.P; p0 += NP) {
     const int np = min(NP, d.P - p0);
@@ -887,6 +920,10 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
       const int w = img[d.off_written + (in ? slots[q] >> 5 : 0)];
       if (!in || !((w >> (slots[q] & 31)) & 1)) slots[q] = -1;
     }
+    // direct form: tile q's LDS tile (or -1: the uniform vector, read from the constants with stride 0)
+    int vt[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) vt[q] = (DIRECT && slots[q] >= 0) ? img[d.off_vftile + slots[q]] : -1;
     const int n_items = 2 * np;
     auto key = [&](int j) { const int pp = j % np; return row0[p0 + pp] * 2 + (as_const(d.gr.pair_phi)[p0 + pp] ? 1 : 0); };
     auto fetchw = [&](double (&fr)[16], int j) {
@@ -909,6 +946,7 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
     const int j_first = next_run(0);
     if (j_first < n_items) fetchw(fr0, j_first);
     double sv[16];
+    if constexpr (!DIRECT) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {                                // row i = wave + 8 j: tile i >> 4 = j >> 1, graph wave + 8 (j & 1)
       sv[j] = uniform;                                            // never updated: still uniform (LBP.py:211-216)
@@ -916,6 +954,7 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
         const int ggc = min(g0 + wave + 8 * (j & 1), d.B - 1);
         sv[j] = d.msgs[((size_t)ggc * d.n_msgs + slots[j >> 1]) * 64 + lane];
       }
+    }
     }
     // ... and the label's feature row (the labels have arrived, the messages are still on their way)
     double lf[3] = {0.0, 0.0, 0.0};
@@ -925,30 +964,55 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
       const double* ph = d.gr.phi[d.gr.pair_phi[lp] ? 1 : 0] + ((size_t)m0 * 64 + m1) * 3;
       lf[0] = ph[0]; lf[1] = ph[1]; lf[2] = ph[2];
     }
+    if constexpr (!DIRECT) {
 #pragma unroll
     for (int j = 0; j < 16; ++j)
       if (j < 4 * np) {
         tiles[(size_t)(j >> 1) * TILE + tile_index(lane, wave + 8 * (j & 1))] = sv[j];
       }
     __syncthreads();
+    }
     STAMP(8)
+    // tile q = 2 * factor + side of this pass: where it is read from (16 bytes per lane and k-step pair), and the strides of a read
+    auto tile_ptr = [&](int q) -> const double2* {
+      if constexpr (DIRECT) {
+        int tl = -1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (i == q) tl = vt[i];
+        return tl >= 0 ? reinterpret_cast<const double2*>(tiles + (size_t)tl * TILE) + lane : uni2;
+      } else {
+        return reinterpret_cast<const double2*>(tiles + (size_t)q * TILE) + lane;
+      }
+    };
+    auto tile_on = [&](int q) -> bool {                          // false: the uniform constants (every read the same 16 bytes)
+      if constexpr (DIRECT) {
+        int tl = -1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (i == q) tl = vt[i];
+        return tl >= 0;
+      } else {
+        return true;
+      }
+    };
     // this half's items in k-major order: j = kk * np + pp  ->  factor p0 + pp, feature k = 2 kk + half.  Consecutive
     // factors that read the same (table, feature tensor) share one A fragment: it is fetched once per run (a K3 user
     // graph's three factors are one run: 2 fetches per wave instead of 6), the next run's while this run multiplies; two
     // items of a run go through the matrix pipe interleaved (two independent accumulation chains).
     auto finish = [&](const double4_t& acc, int pp, int k) {
-      const double2* ct = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp + 1) * TILE) + 128 * rb + lane;
-      const double2 c0 = ct[0], c1 = ct[64];
+      const bool on_c = tile_on(2 * pp + 1);
+      const double2* ct = tile_ptr(2 * pp + 1) + (on_c ? 128 * rb : 0);
+      const double2 c0 = ct[0], c1 = ct[on_c ? 64 : 0];
       const double part = column_sum((c0.x * acc.x + c0.y * acc.y) + (c1.x * acc.z + c1.y * acc.w));
       if ((lane >> 4) == 0) red[((pp * 4 + k) * 4 + rb) * G + (lane & 15)] = part;
     };
     auto item = [&](const double (&fr)[16], int j) {
       const int pp = j % np, k = 2 * (j / np) + half;
-      const double2* rt = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp) * TILE) + lane;
+      const double2* rt = tile_ptr(2 * pp);
+      const int rs_ = tile_on(2 * pp) ? 128 : 0, ro_ = tile_on(2 * pp) ? 64 : 0;
       double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
-        const double2 v0 = rt[128 * h], v1 = rt[128 * h + 64];
+        const double2 v0 = rt[rs_ * h], v1 = rt[rs_ * h + ro_];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h], v0.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 1], v0.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 2], v1.x, acc, 0, 0, 0);
@@ -958,11 +1022,13 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
     };
     auto item2 = [&](const double (&fr)[16], int j) {            // items j and j + 1: the same fragment, the next factor
       const int pp = j % np, k = 2 * (j / np) + half;
-      const double2* rt = reinterpret_cast<const double2*>(tiles + (size_t)(2 * pp) * TILE) + lane;
+      const double2* rt = tile_ptr(2 * pp);
+      const double2* rt2 = tile_ptr(2 * pp + 2);
+      const int rs_ = tile_on(2 * pp) ? 128 : 0, ro_ = tile_on(2 * pp) ? 64 : 0, rs2 = tile_on(2 * pp + 2) ? 128 : 0, ro2 = tile_on(2 * pp + 2) ? 64 : 0;
       double4_t acc = {0.0, 0.0, 0.0, 0.0}, bcc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int h = 0; h < 4; ++h) {
-        const double2 v0 = rt[128 * h], v1 = rt[128 * h + 64], w0 = rt[2 * (TILE / 2) + 128 * h], w1 = rt[2 * (TILE / 2) + 128 * h + 64];
+        const double2 v0 = rt[rs_ * h], v1 = rt[rs_ * h + ro_], w0 = rt2[rs2 * h], w1 = rt2[rs2 * h + ro2];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h], v0.x, acc, 0, 0, 0);
         bcc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h], w0.x, bcc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr[4 * h + 1], v0.y, acc, 0, 0, 0);
@@ -1374,7 +1440,8 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
 #undef MLBP_PF_TOTAL
 #undef MLBP_PF_QUARTER
     STAMP(7)
-    if ((flags & 8) && d.msgs && g0 + gl < d.B && !bad) {        // S, normalised, is the last value of a variable->factor slot: to memory
+    if ((flags & 8) && d.msgs && !(GRAD && d.vf_direct && d.vf_only) && g0 + gl < d.B && !bad) {        // S, normalised, is the last value of a variable->factor slot: to memory
+      // (not when only the gradient epilogue wanted it and reads the tiles themselves: vf_direct)
       const double2 v0 = src[128 * rb], v1 = src[128 * rb + 64], t0 = tp[0], t1 = tp[1];      // this wave's rows once more (states 16 rb + cq + 4 r = k-steps 4 rb + r)
       double* out = d.msgs + ((size_t)(g0 + gl) * d.n_msgs + ((w1 >> 16) & 0xFFFF)) * 64 + 16 * rb + cq;
       const double it = 1.0 / ((t0.x + t0.y) + (t1.x + t1.y));
@@ -1504,7 +1571,8 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
         // the normalised values go through LDS once more (the tiles are spent: every job has read its own), so that they leave as
         // whole 512-byte rows, one per (graph, variable): written from this layout they were 32-byte pieces of sixteen rows per
         // store, and the launch spent 6 us draining 12.6 MB of them
-        double* stage = tiles;                                   // [variable of this pass][graph][65]
+        // (variable v's sixteen rows in ITS constant product's tile -- 16 x 64 doubles, spent: every job has read its own --, so
+        // that the message tiles stay what the gradient epilogue reads)
 #pragma unroll
         for (int q = 0; q < JW; ++q) {
           const int j = j0 + wave + q * (SWG / 64);
@@ -1514,20 +1582,11 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
           const double tm = (rp[0] + rp[G]) + (rp[2 * G] + rp[3 * G]);
           bad |= !total_ok(tm);
           const double itm = 1.0 / tm;
-          double* o = stage + ((size_t)(v - (j0 >> 2)) * G + gl) * 65 + 16 * h + cq;
+          double* o = tiles + (size_t)rd[rd[v]] * TILE + gl * 64;  // (state s of graph gl at s ^ gl: the sixteen graphs of a store on sixteen banks)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[4 * r] = m[q][r] * itm;
+          for (int r = 0; r < 4; ++r) o[(16 * h + cq + 4 * r) ^ gl] = m[q][r] * itm;
         }
         __syncthreads();
-        {
-          const unsigned long long flagged = __ballot(bad);
-          const int v0 = j0 >> 2, nv = min(d.n_vars - v0, JW * (SWG / 64) / 4);
-          for (int row = wave; row < nv * G; row += SWG / 64) {
-            const int g = row & (G - 1), v = v0 + (row >> 4);
-            if (g0 + g < d.B && !((flagged >> g) & 0x0001000100010001ull))
-              __builtin_nontemporal_store(stage[(size_t)row * 65 + lane], &d.marginals[((size_t)(g0 + g) * d.n_vars + v) * 64 + lane]);
-          }
-        }
         if (j0 + JW * (SWG / 64) < n_jobs) __syncthreads();
       }
     }
@@ -1608,6 +1667,22 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   }   // !PF
   if (bad && gvalid) d.bail[gi] = 2;                             // any wave that saw it says so (idempotent)
   STAMP(5)
+  if constexpr (PF) {
+    // the gradient epilogue in front of the marginals' way out: it reads the message tiles (intact: the marginals are staged in
+    // the constant products' tiles) and nothing it waits for is behind 12.6 MB of stores
+    if constexpr (GRAD) {
+      if (d.gr.enabled && d.vf_direct) shared_gradient_epilogue<true>(d, wg);
+    }
+    if (d.marginals && !ABL(512)) {
+      const const_i32p rd = as_const(d.readout);
+      const unsigned long long flagged = __ballot(bad);
+      for (int row = wave; row < d.n_vars * G; row += SWG / 64) {
+        const int g = row & (G - 1), v = row >> 4;
+        if (g0 + g < d.B && !((flagged >> g) & 0x0001000100010001ull))
+          __builtin_nontemporal_store(tiles[(size_t)rd[rd[v]] * TILE + g * 64 + (lane ^ g)], &d.marginals[((size_t)(g0 + g) * d.n_vars + v) * 64 + lane]);
+      }
+    }
+  }
   if (!GRAD || !d.gr.enabled) {                                  // (GRAD is a template parameter: the sweeps-only instances do not carry the epilogue's registers)
     STAMP_FLUSH
     return;
@@ -1620,7 +1695,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   //      pass's labels and first fragment before its messages, its label features behind them.  (The unary factors'
   //      terms do not depend on the sweeps: shared_prepare_kernel has written them, this adds to them.) ----
   STAMP_FLUSH
-  shared_gradient_epilogue(d, wg);
+  if (!(PF && d.vf_direct)) shared_gradient_epilogue<false>(d, wg);
   };
   tail();
 }
@@ -1986,6 +2061,11 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   d.off_pfb = sp.off_pfb; d.off_stash = sp.off_stash; d.off_pinit = sp.off_pinit; d.n_pinit = sp.n_pinit; d.n_stash = sp.n_stash;
   d.stash = pf ? mp->d_spill : nullptr;
   d.header = mp->d_header;
+  d.off_vftile = sp.off_vftile;
+  d.vf_direct = 0;                                 // (set below when the gradient is this launch's epilogue)
+  // the product-fused form takes the whole half of the CU's LDS: the spare bytes behind the totals are the gradient epilogue's
+  if (pf) lds = std::max(lds, (size_t)79 * 1024 + 512);
+  d.lds_bytes = (int32_t)lds;
   out->pf = pf;
   d.tfrag = nullptr;
   if (a->n_pair_tables <= FRAG_TABLES) {
@@ -2018,6 +2098,7 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
     q.phi_i0 = ga->phi_en_en; q.phi_i1 = ga->phi_en_en_w1; q.phi_ed = ga->phi_en_de;
     q.grad_en_en = ga->grad_en_en; q.grad_en_de = ga->grad_en_de; q.Vde = ga->Vde; q.grad_on = 1;
     d.msgs = a->msgs;                               // the epilogue reads the stored variable->factor messages back
+    d.vf_direct = (pf && sp.vf_direct && a->marginals) ? 1 : 0;      // ... or, product-fused, takes them from the message tiles
   }
   out->lds = lds; out->n_wg = n_groups; out->n_prep_blocks = (a->B + PGB - 1) / PGB;       // (= n_groups)
   out->wide = sp.max_sources > 2; out->spill = d.spill != nullptr;

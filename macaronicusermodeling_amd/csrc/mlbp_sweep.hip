@@ -2059,7 +2059,10 @@ int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_
   p->sreadout_all_based = false;
   if (p->shared.ok && mlbp::build_shared_readout(p->shared, p->n_msgs, n_vars, in_off, in_slots, simg)) {
     p->sreadout_all_based = true;
-    for (int v = 0; v < n_vars; ++v) p->sreadout_all_based &= simg[simg[v]] >= 0;
+    for (int v = 0; v < n_vars; ++v) {
+      p->sreadout_all_based &= simg[simg[v]] >= 0;
+      for (int u = 0; u < v; ++u) p->sreadout_all_based &= simg[simg[u]] != simg[simg[v]];      // (and its own: the read-out stages a variable's rows there)
+    }
     HIP_TRY(hipMalloc(&p->d_sreadout, simg.size() * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(p->d_sreadout, simg.data(), simg.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     p->n_sreadout = (int)simg.size();

@@ -30,7 +30,7 @@ from macaronicusermodeling_amd.batch import FactorGraphBatch  # noqa: E402
 from macaronicusermodeling_amd.topology import GraphTopology  # noqa: E402
 
 mask = int(sys.argv[1])
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+B = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 8192
 spec, roots, sweeps, seed = bench.workload_spec('user_k3_shared')
 X = spec['X']
 topo = GraphTopology.from_spec(spec)
@@ -42,7 +42,19 @@ fb.set_pair_tables(torch.rand(2, X, X, dtype=torch.float64, device=dev) + 0.01, 
 fb.set_unary_tables(torch.rand(192, X, dtype=torch.float64, device=dev) + 0.01, np.random.RandomState(0).randint(0, 192, size=(B, topo.U)))
 marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=dev)
 assert ffi.lib.mlbp_debug_set_shared_stamp_buffer(None, mask) == 0
-for _ in range(300):
-    fb.sweep(roots, init=True, marginals=marg, keep_messages=False)
+if '--gradient' in sys.argv:            # the trainer's step: gradient as the sweep kernel's epilogue
+    import cases as CS
+    from macaronicusermodeling_amd.train import UserGraphTrainer
+    spec = CS.user_spec(10, [1, 4, 7], X, 64, seed=1)
+    topo = GraphTopology.from_spec(spec)
+    inputs = CS.reference_planes(CS.make_inputs(spec, 5))
+    rs = np.random.RandomState(0)
+    tr = UserGraphTrainer(spec, rs.randint(0, X, size=(B, topo.n_vars)), rs.randint(0, 64, size=(B, topo.U)), inputs['phi_en_en'],
+                          inputs['phi_en_en_w1'], inputs['phi_en_de'], inputs['theta_en_en'], inputs['theta_en_de'])
+    for _ in range(300):
+        tr.local_statistics()
+else:
+    for _ in range(300):
+        fb.sweep(roots, init=True, marginals=marg, keep_messages=False)
 torch.cuda.synchronize()
 assert ffi.lib.mlbp_last_sweep_kernel() == 3

@@ -3,7 +3,7 @@ export TMPDIR=/tmp
 T=${1:-r04ac}; shift
 for M in "$@"; do
   rm -rf gpurun_out/${T}_ab
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_ab -- python3 tools/ablate_shared.py $M > /dev/null 2> gpurun_out/${T}_ab.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_ab -- python3 tools/ablate_shared.py $M $ABARGS > /dev/null 2> gpurun_out/${T}_ab.err
   f=$(find gpurun_out/${T}_ab -name "*kernel_stats.csv" | head -1)
   python3 - <<PY
 import csv

@@ -139,7 +139,9 @@ int mlbp_program_reserve(mlbp_program* p, int32_t max_graphs);
 
 /* HOST only (no device needed): what the program rewrites make of an op list.  out8 = { updates of the fused
  * form, of them lone variable->factor updates, fused variable+pairwise updates, bundles (two updates under
- * one barrier); shared-table form applicable (0/1), its resident message tiles, its updates, LDS bytes of its
+ * one barrier); shared-table form: bit 0 applicable, bit 1 in its product-fused form (every variable update multiplies at
+ * most one constant product and one message: the message's producer stores the product), bit 2 the fused gradient reads
+ * the final variable->factor messages from that form's tiles; its resident message tiles, its updates, LDS bytes of its
  * tiles for 16 graphs }.  Same validation and error codes as mlbp_program_create. */
 int mlbp_program_plan(const int32_t* ops, int32_t n_ops, const int32_t* srcs, int32_t n_srcs,
                       const int32_t* sweeps, int32_t n_sweeps, int32_t n_msgs, int32_t P, int32_t U,

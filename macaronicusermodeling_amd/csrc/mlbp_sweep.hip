@@ -1427,7 +1427,7 @@ int mlbp_program_plan(const int32_t* ops, int32_t n_ops, const int32_t* srcs, in
   mlbp::SharedProgram sp;
   mlbp::build_shared_program(fp, n_msgs, P, U, sp);
   out8[0] = (int)fp.fops.size() / 8; out8[1] = lone; out8[2] = fused; out8[3] = bundled;
-  out8[4] = sp.ok ? 1 : 0; out8[5] = sp.n_live; out8[6] = sp.n_ops; out8[7] = sp.n_live * (64 * 16 + 64) * 8;
+  out8[4] = (sp.ok ? 1 : 0) | (sp.ok && sp.pf_ok ? 2 : 0) | (sp.ok && sp.pf_ok && sp.vf_direct ? 4 : 0); out8[5] = sp.n_live; out8[6] = sp.n_ops; out8[7] = sp.n_live * (64 * 16 + 64) * 8;
   return MLBP_OK;
 }
 

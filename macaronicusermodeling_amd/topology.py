@@ -164,7 +164,11 @@ class GraphTopology:
                                               len(sweeps), self.n_msgs, self.P, self.U, _ffi.i32ptr(out)))
         keys = ('updates', 'lone_variable_updates', 'fused_updates', 'bundles', 'shared_ok', 'shared_tiles',
                 'shared_updates', 'shared_tile_bytes')
-        return dict(zip(keys, (int(v) for v in out)))
+        plan = dict(zip(keys, (int(v) for v in out)))
+        plan['shared_product_fused'] = (plan['shared_ok'] >> 1) & 1       # the message's producer stores c (.) message: K2, K3, chains, rings
+        plan['shared_gradient_from_tiles'] = (plan['shared_ok'] >> 2) & 1
+        plan['shared_ok'] &= 1
+        return plan
 
     @classmethod
     def from_spec(cls, spec):

@@ -118,6 +118,44 @@ def test_degenerate_graphs_in_a_shared_batch_are_redone_exactly():
             np.testing.assert_allclose(got[b], want, rtol=RTOL, atol=1e-300)
 
 
+@pytest.mark.parametrize('name', ['user_k3_gaps_3_6', 'user_k3_gaps_1_2_3', 'user_k2'])
+def test_product_fused_form_with_zeros_in_the_constant_products(name):
+    """The product-fused form of the kernel (K2, K3: the producer of a message stores c (.) message, the marginal c (.) m_a (.) m_b
+    comes out as P_a (.) (P_b / c)) on unary tables with exact zeros -- states where c is 0: the marginal is 0 there, the
+    written-back MESSAGES are not (they come from the raw results the members stash) -- against the oracle, with and without the
+    message write-back; and the host says the form applies."""
+    from macaronicusermodeling_amd import _ffi
+    spec = SPECS[name]()
+
+    def mutate(inputs):
+        rs = np.random.RandomState(7)
+        for b, inp in enumerate(inputs):
+            if b % 2 == 0:
+                pot = inp['pot_en_de'].copy()
+                pot[rs.rand(*pot.shape) < 0.3] = 0.0           # zeros scattered over every unary column (no column all zero)
+                pot[0, :] = np.maximum(pot[0, :], 0.5)
+                inp['pot_en_de'] = pot
+    B = 37
+    fb, topo, inputs = _shared_batch(spec, B, mutate=mutate)
+    roots = ([v for v in topo.var_ids] * 3)[:3]
+    assert topo.plan(roots)['shared_product_fused'] == 1
+    marg = torch.full((B, topo.n_vars, 64), float('nan'), dtype=torch.float64, device=fb.device)
+    fb.msgs.fill_(float('nan'))
+    prog = fb.sweep(roots, init=True, marginals=marg)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == KERNEL_SHARED_MFMA, _ffi.lib.mlbp_last_error()
+    assert prog.status() == 0 and prog.exact_count(B) == 0
+    got, gm = fb.msgs.cpu().numpy(), marg.cpu().numpy()
+    assert (gm == 0.0).any()                                    # the zeros are there
+    for b in range(B):
+        g, msgs, want = oracle_msgs(spec, inputs[b], roots)
+        np.testing.assert_allclose(got[b], want, rtol=RTOL, atol=1e-300)
+        for k, v in enumerate(topo.var_ids):
+            np.testing.assert_allclose(gm[b, k], O.marginal(g, msgs, v).reshape(-1), rtol=RTOL, atol=1e-300)
+    m2 = torch.full_like(marg, float('nan'))
+    fb.sweep(roots, init=True, marginals=m2, keep_messages=False)       # read-out only: nothing is stashed, the same marginals
+    assert torch.equal(m2, marg)
+
+
 def test_a_wrong_shared_claim_is_caught_on_the_device():
     """pair_tab rows that differ inside a group of 16 graphs (the caller's flag was wrong) send the group to
     the exact kernel; results are those of the tables each graph really points at."""

@@ -141,6 +141,12 @@ def test_program_rewrites_plan():
     assert (k2['updates'], k2['fused_updates'], k2['lone_variable_updates'], k2['shared_tiles']) == (6, 6, 0, 4)
     k4 = GraphTopology.from_spec(C.user_spec(9, [0, 2, 3, 7], 64, 64, seed=4)).plan([0, 2, 3])
     assert k4['shared_tiles'] == 21 and k4['shared_tile_bytes'] > 160 * 1024
+    # the product-fused form of the shared-table kernel: variables with at most two pairwise factors (K2, K3); K3's final
+    # variable->factor messages are message tiles at the end of the sweeps (the gradient epilogue reads them there), K2's are
+    # the constant products themselves; K4's variable updates multiply two messages: the general form
+    assert (k3['shared_product_fused'], k3['shared_gradient_from_tiles']) == (1, 1)
+    assert (k2['shared_product_fused'], k2['shared_gradient_from_tiles']) == (1, 0)
+    assert (k4['shared_product_fused'], k4['shared_gradient_from_tiles']) == (0, 0)
     ring = GraphTopology.from_spec(C.ring_spec(8, 64)).plan([0, 0, 0])
     assert ring['fused_updates'] == ring['updates'] == 48 and ring['bundles'] == 24
     k1 = GraphTopology.from_spec(C.user_spec(5, [2], 64, 64, seed=5)).plan([2])      # no pairwise factor at all

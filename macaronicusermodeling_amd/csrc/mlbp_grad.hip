@@ -514,6 +514,26 @@ __global__ __launch_bounds__(WG) void step_statistics_kernel(SumCat cat, int64_t
 #pragma unroll
     for (int j = 0; j < C1; ++j) v[C0 + j] = cat.in[1][b * C1 + j];
     double total = 0.0;
+    if (cat.n_vars <= 8) {
+      // the row's labels together, then the marginal entries they select together: two rounds of memory latency, not two per
+      // variable (the sum below is in variable order, as the loop's)
+      int lab[8];
+      double mv[8];
+#pragma unroll
+      for (int vi = 0; vi < 8; ++vi) lab[vi] = vi < cat.n_vars ? cat.labels[b * cat.n_vars + vi] : 0;
+#pragma unroll
+      for (int vi = 0; vi < 8; ++vi) {
+        const bool ok = vi < cat.n_vars && (unsigned)lab[vi] < (unsigned)cat.X;
+        mv[vi] = ok ? cat.marg[(b * cat.n_vars + vi) * cat.X + lab[vi]] : 1.0;
+      }
+#pragma unroll
+      for (int vi = 0; vi < 8; ++vi) {
+        if (vi >= cat.n_vars) continue;
+        if ((unsigned)lab[vi] >= (unsigned)cat.X) { atomicExch(cat.status, 1); continue; }
+        const double lp = log(mv[vi]);
+        total += (lp == -__builtin_huge_val()) ? -99.99 : lp;  // LBP.py:254-256
+      }
+    } else
     for (int vi = 0; vi < cat.n_vars; ++vi) {
       const int lab = cat.labels[b * cat.n_vars + vi];
       if ((unsigned)lab >= (unsigned)cat.X) { atomicExch(cat.status, 1); continue; }

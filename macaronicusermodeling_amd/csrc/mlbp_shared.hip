@@ -1645,7 +1645,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
         double* out = d.marginals + ((size_t)gc * d.n_vars + v) * 64 + cq;
         const double itm = 1.0 / tm;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) out[4 * s] = m[s] * itm;
+        for (int s = 0; s < 16; ++s) __builtin_nontemporal_store(m[s] * itm, &out[4 * s]);     // (written once, read by another launch: past L2)
       }
     }
   }

@@ -354,15 +354,19 @@ def test_vocabulary_sized_shared_tables_run_as_batched_gemms(X):
         np.testing.assert_allclose(got[b].cpu().numpy(), want, rtol=RTOL, atol=1e-300)
 
 
-@pytest.mark.parametrize('which', ['ring8', 'chain8'])
+@pytest.mark.parametrize('which', ['ring8', 'chain8', 'chain2', 'chain3', 'ring3'])
 def test_shared_kernel_with_most_tiles_spilled(which):
     """Rings / chains of 8 variables need 22-24 message tiles; 8-9 stay in LDS, the rest live in the global spill area
-    (two distinct tables alternate along the factors).  Against the oracle per graph."""
+    (two distinct tables alternate along the factors).  Against the oracle per graph.  The short ones (chain of 2 or 3, ring of
+    3) fit LDS whole and take the product-fused form: a chain's end variables have one pairwise factor, so the message into them
+    is read by no update -- the kernel keeps the message itself for the read-out -- and their own message is the constant
+    product alone."""
     from macaronicusermodeling_amd import _ffi
     from macaronicusermodeling_amd.batch import FactorGraphBatch
     from macaronicusermodeling_amd.topology import GraphTopology
     X, B = 64, 21
-    spec = C.ring_spec(8, X) if which == 'ring8' else C.chain_spec(8, X)
+    n = int(which[-1])
+    spec = C.ring_spec(n, X) if which.startswith('ring') else C.chain_spec(n, X)
     topo = GraphTopology.from_spec(spec)
     inputs = [C.make_inputs(spec, 51 + 1000 * b) for b in range(B)]
     g = O.Graph(spec)
@@ -377,7 +381,8 @@ def test_shared_kernel_with_most_tiles_spilled(which):
     fb = FactorGraphBatch(topo, X, B)
     fb.set_pair_tables(np.stack(two), np.tile(np.array(pick), (B, 1)))
     fb.set_unary_tables(unary)
-    roots = [0, 5, 2]
+    roots = [0, 5 % n, 2 % n]
+    assert topo.plan(roots)['shared_product_fused'] == 1       # (every variable here has at most two pairwise factors)
     marg = torch.empty(B, topo.n_vars, X, dtype=torch.float64, device=fb.device)
     fb.msgs.fill_(float('nan'))
     prog = fb.sweep(roots, init=True, marginals=marg)

@@ -208,6 +208,41 @@ def test_shared_table_sweep_runs_the_gradient_as_its_epilogue(B, planes):
     tr.unary_tables[row] = saved
 
 
+def test_fused_gradient_with_and_without_the_message_write_back():
+    """K3 in the product-fused form: the gradient epilogue reads the final variable->factor messages from the kernel's tiles, so
+    it is the same bits whether the call also writes the messages back (the members then stash their raw results and store
+    the slots' last values) or not; and the messages written beside the gradient are those of a plain sweep."""
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.train import UserGraphTrainer
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = C.user_spec(10, [1, 2, 7], 64, 48, seed=1)
+    topo = GraphTopology.from_spec(spec)
+    inputs = C.reference_planes(C.make_inputs(spec, 78))
+    roots = list(spec['var_ids'])
+    assert topo.plan(roots)['shared_gradient_from_tiles'] == 1
+    B = 41
+    labels, obs = _instances(spec, topo, B, 6)
+    tr = UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],
+                          inputs['theta_en_en'], inputs['theta_en_de'], roots=roots)
+    fb = tr.batch
+    tr.build_potentials()
+    a_ee, a_ed = torch.full_like(tr._g_ee, float('nan')), torch.full_like(tr._g_ed, float('nan'))
+    m_a = torch.full_like(tr._marg, float('nan'))
+    fb.sweep(roots, init=True, marginals=m_a, gradient=(a_ee, a_ed), keep_messages=False)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 3 and _ffi.lib.mlbp_last_sweep_fused_gradient() == 1
+    b_ee, b_ed = torch.full_like(a_ee, float('nan')), torch.full_like(a_ed, float('nan'))
+    m_b = torch.full_like(m_a, float('nan'))
+    fb.msgs.fill_(float('nan'))
+    fb.sweep(roots, init=True, marginals=m_b, gradient=(b_ee, b_ed), keep_messages=True)
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 3 and _ffi.lib.mlbp_last_sweep_fused_gradient() == 1
+    assert torch.equal(a_ee, b_ee) and torch.equal(a_ed, b_ed) and torch.equal(m_a, m_b)
+    with_gradient = fb.msgs.clone()
+    assert bool(torch.isfinite(with_gradient).all())
+    fb.msgs.fill_(float('nan'))
+    fb.sweep(roots, init=True)
+    torch.testing.assert_close(with_gradient, fb.msgs, rtol=1e-12, atol=1e-300)
+
+
 def test_train_step_matches_sum_of_reference_steps():
     """UserGraphTrainer.step == theta + sum_i return_gradient_i (train_mp.py:398, 419-424) with the
     potentials built on the device from phi and theta (train_mp.py:220-255)."""

@@ -6,10 +6,11 @@
 // -- the factor->variable update of G graphs is a dense contraction  OUT[64 x G] = T[64 x 64] . M[64 x G]
 // (or T^T . M), i.e. exactly the case SURVEY.md section 8(d) prices against the MFMA peak instead of HBM.
 //
-// One 256-thread workgroup owns G = 16 graphs for all sweeps of the call:
-//   * wave w holds rows 16w..16w+15 of every distinct table in BOTH orientations as
-//     v_mfma_f64_16x16x4_f64 A-fragments in registers (16 doubles per table and orientation) for the
-//     whole launch -- the tables are read once per workgroup, from L2;
+// One 512-thread workgroup owns G = 16 graphs for all sweeps of the call (two halves of four waves; a bundle's two
+// independent updates run side by side, one per half, under one barrier):
+//   * wave (half, row block w) holds rows 16w..16w+15 of two of the four (table, orientation) pairs as
+//     v_mfma_f64_16x16x4_f64 A-fragments in registers (16 doubles per pair) for the whole launch -- the tables
+//     are read once per workgroup, from L2;
 //   * messages live in LDS as [state][graph] tiles (8 KiB): a tile read 64 lanes wide IS the B operand
 //     of k-step s (lane l = state 4s + (l >> 4), graph l & 15), and the D fragment of wave w (lane l,
 //     register r = state 16w + (l >> 4) + 4r, graph l & 15) is stored straight back into that layout;
@@ -20,6 +21,9 @@
 //     (LBP.py:494-498), written back once in the prologue and folded into one product per variable.
 // Degenerate graphs (zero / non-finite totals, where Message.renormalize and nan_to_num take their
 // special branches) are flagged per graph and redone by the exact kernel, like the scale-free path.
+// Where every variable has at most two pairwise factors (K2, K3, chains, rings) the kernel runs its PRODUCT-FUSED
+// form (template parameter PF; build_shared_program, "product-fused form"): the producer of a message stores
+// c (.) message, a contraction reads one tile straight into the matrix cores, read-out and gradient from LDS.
 //
 // Flops per pairwise update per graph: 2 * 64 * 64 = 8192 (shared-table mode).
 #include <hip/hip_runtime.h>
@@ -1456,7 +1460,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
       const double colsum = column_sum((p0 + p1) + (p2 + p3));
       if (cq == 0) tot[dst * 64 + gl * 4 + rb] = colsum;
     }
-    if ((flags & 32) && stash_g) {                               // the slot's last update: the raw result for the read-out (any scale: the epilogue normalises)
+    if ((flags & 32) && stash_g) {                               // the slot's last update: the raw result for the message write-back (any scale: the epilogue normalises)
       double2* out = stash_g + (size_t)(w2 >> 8) * (TILE / 2) + 128 * rb + lane;
       out[0] = make_double2(acc.x, acc.y); out[64] = make_double2(acc.z, acc.w);
     }

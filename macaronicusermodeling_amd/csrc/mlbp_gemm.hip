@@ -238,6 +238,13 @@ __device__ __forceinline__ void tiles_to_image(const double4_t (&acc)[RTW][NCT],
 
 // The contraction runs at XA = 64 * RT states; N_T = 16 * NCT graphs per workgroup.  PADDED: the messages have d.X <= XA
 // states (rows of d.X doubles in memory, any parity: 8-byte accesses), the operands are zero beyond.
+// Cache policy of the message traffic of the one-image kernel (MLBP_GEMM_NT: bit 0 source messages by non-temporal loads, bit 1
+// results by non-temporal stores).  Every message of the batch passes through once per update (134 MB at X = 512, B = 8192) and
+// the launch is one round of workgroups, all of them in the memory phase at the same time: X = 512 float32 tables 60.9 -> 58.5 us
+// per update, float64 87.1 -> 85.9 (round 4; with the reciprocal-multiply normalisation: from 62.0 / 90.1).
+#ifndef MLBP_GEMM_NT
+#define MLBP_GEMM_NT 3
+#endif
 template <typename TT, int RT, int NCT, int DEPTH, int NW, bool PADDED>
 __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 1) void contract_kernel(ContractDev d) {
   constexpr int XA = 64 * RT, NT_G = 16 * NCT, XP = XA + 2;
@@ -261,8 +268,16 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 1) void contract_kernel(Con
   static_assert(RT % 2 == 0, "X must be a multiple of 128 here");
   static_assert(KB % 4 == 0, "");
   // states 2 (lane + 64 j), + 1 of a row of X doubles; beyond X: zero
+  typedef double nt_d2 __attribute__((ext_vector_type(2)));
   auto load2 = [&](const double* row, int j) {
-    if (!PADDED) return reinterpret_cast<const double2*>(row)[lane + 64 * j];
+    if (!PADDED) {
+#if MLBP_GEMM_NT & 1
+      const nt_d2 v_ = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(row) + lane + 64 * j);
+      return make_double2(v_.x, v_.y);
+#else
+      return reinterpret_cast<const double2*>(row)[lane + 64 * j];
+#endif
+    }
     const int x0 = 2 * (lane + 64 * j);
     return make_double2(x0 < X ? row[x0] : 0.0, x0 + 1 < X ? row[x0 + 1] : 0.0);
   };
@@ -271,7 +286,15 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 1) void contract_kernel(Con
     return (!PADDED) ? make_double2(uniform, uniform) : make_double2(x0 < X ? uniform : 0.0, x0 + 1 < X ? uniform : 0.0);
   };
   auto store2 = [&](double* row, int j, double2 val) {
-    if (!PADDED) { reinterpret_cast<double2*>(row)[lane + 64 * j] = val; return; }
+    if (!PADDED) {
+#if MLBP_GEMM_NT & 2
+      nt_d2 x_; x_.x = val.x; x_.y = val.y;
+      __builtin_nontemporal_store(x_, reinterpret_cast<nt_d2*>(row) + lane + 64 * j);
+#else
+      reinterpret_cast<double2*>(row)[lane + 64 * j] = val;
+#endif
+      return;
+    }
     const int x0 = 2 * (lane + 64 * j);
     if (x0 < X) row[x0] = val.x;
     if (x0 + 1 < X) row[x0 + 1] = val.y;
@@ -337,11 +360,15 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 1) void contract_kernel(Con
           for (int j = 0; j < H; ++j) part += v[u][j].x + v[u][j].y;
           tot[u] = wave_sum64(part);
         }
+        // (one division per graph and a multiplication per state: the eight-to-sixteen divisions per lane this was are ~100
+        // float64 instructions each side of a launch whose every wave is in this phase at the same time)
 #pragma unroll
-        for (int u = 0; u < GU; ++u)
+        for (int u = 0; u < GU; ++u) {
+          const double inv = 1.0 / tot[u];
 #pragma unroll
           for (int j = 0; j < H; ++j)
-            v[u][j] = tot[u] > 0.0 ? make_double2(v[u][j].x / tot[u], v[u][j].y / tot[u]) : uniform2(j);
+            v[u][j] = tot[u] > 0.0 ? make_double2(v[u][j].x * inv, v[u][j].y * inv) : uniform2(j);
+        }
       }
       if (d.vf_slot >= 0) {
 #pragma unroll
@@ -428,10 +455,11 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 1) void contract_kernel(Con
       const int b = graph_of(g4, u);
       if (b < d.B) {
         double* o = d.out + (size_t)b * d.out_ld + (size_t)d.dst_slot * X;
+        const double inv = 1.0 / tot[u];
 #pragma unroll
         for (int j = 0; j < H; ++j) {
           double2 val = v[u][j];
-          if (d.normalize) val = tot[u] > 0.0 ? make_double2(val.x / tot[u], val.y / tot[u]) : make_double2(uniform, uniform);
+          if (d.normalize) val = tot[u] > 0.0 ? make_double2(val.x * inv, val.y * inv) : make_double2(uniform, uniform);
           store2(o, j, val);
         }
       }
@@ -502,12 +530,12 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 1) void contract_chunked_ke
       for (int j = 0; j < H; ++j) { part += v[j].x + v[j].y; store2(xo, c * CH, j, v[j]); }
     }
     if (d.normalize) {
-      const double tot = wave_sum64(part);
+      const double tot = wave_sum64(part), inv = 1.0 / tot;
       for (int c = 0; c < RP; ++c)
 #pragma unroll
         for (int j = 0; j < H; ++j) {
           const double2 v = load2(xo, c * CH, j);
-          store2(xo, c * CH, j, tot > 0.0 ? make_double2(v.x / tot, v.y / tot) : uniform2(c * CH, j));
+          store2(xo, c * CH, j, tot > 0.0 ? make_double2(v.x * inv, v.y * inv) : uniform2(c * CH, j));
         }
     }
   }
@@ -575,11 +603,12 @@ __global__ __launch_bounds__(64 * NW, NW == 16 ? 4 : 1) void contract_chunked_ke
     }
     if (!d.normalize) continue;
     double* o = d.out + (size_t)b * d.out_ld + (size_t)d.dst_slot * X;
+    const double inv = 1.0 / total;
     for (int c = 0; c < RP; ++c)
 #pragma unroll
       for (int j = 0; j < H; ++j) {
         const double2 v = load2(o, c * CH, j);
-        store2(o, c * CH, j, total > 0.0 ? make_double2(v.x / total, v.y / total) : make_double2(uniform, uniform));
+        store2(o, c * CH, j, total > 0.0 ? make_double2(v.x * inv, v.y * inv) : make_double2(uniform, uniform));
       }
   }
 }

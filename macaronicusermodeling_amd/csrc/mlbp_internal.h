@@ -55,6 +55,9 @@ struct SharedProgram {
   bool pf_ok = false;
   int off_pfb = 0, off_stash = 0, off_pinit = 0, n_stash = 0, n_pinit = 0, off_vftile = 0;
   bool vf_direct = false;             // the gradient epilogue may read the final variable->factor messages from the message tiles
+  // ... its three-source variant (K4 cliques: messages stored as sqrt(c) (.) m, constant products in memory; build_shared_program)
+  bool p3_ok = false;
+  int n_lds = 0, sqrt_mask = 0, off_map3 = 0, off_kind3 = 0, off_back3 = 0;
   std::vector<int32_t> sweeps;         // {first op, count} of the transformed op list (one sequence: sweep boundaries mean nothing here)
   std::vector<int32_t> image;          // bundles [n_bundles + 1][2][16] | cprod entries [n_cpw] | write-back pairs [n_back][2] | fill slots [n_fill] | uniform tiles [n_init]
   std::vector<int32_t> live_of_slot;   // [n_msgs + 1 + n_cprod] LDS tile of a slot (ext slots included) or -1
@@ -155,6 +158,7 @@ struct mlbp_program {
   int32_t* d_simage;      // SharedProgram::image
   int32_t* d_sreadout;    // per variable: base tile, count, live tiles (4-word aligned lists) or NULL
   int32_t n_sreadout;
+  bool sreadout_all_tiled = false;   // ... and at least one message tile
   bool sreadout_all_based = false;   // every variable of the read-out has a constant product (the product-fused read-out needs it)
   double* d_tfrag;        // [32][2][4096] table fragments in MFMA operand order (lazily allocated)
   double* d_spill = nullptr;   // message tiles of the shared-table kernel that do not fit LDS (lazily allocated)

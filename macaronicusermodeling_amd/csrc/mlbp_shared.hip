@@ -163,6 +163,7 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
   constexpr int MW = 16;
   std::vector<int32_t> mem((size_t)n_ops * MW, 0);
   std::vector<int> last_var_write(n_msgs, -1);
+  std::vector<char> pair_kind(n_ops, 0);                        // a factor update that reads a STORED variable->factor message
   out.why = "more than 254 live tiles or 65535 message slots";
   if (out.n_live > 254 || n_msgs > 65535) return;
   out.why = "a variable update multiplies more than 8 tiles";
@@ -174,6 +175,7 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
     m[2] = m[3] = -1;
     if (kind == FOP_PAIR_TM || kind == FOP_PAIR_MT) {
       m[0] = 1 | (kind == FOP_PAIR_MT ? 2 : 0) | (1 << 8);
+      pair_kind[i] = 1;
       m[1] = w[1]; m[2] = out.live_of_slot[w[3]];
       m[8] = w[2] < 0 ? -1 : out.live_of_slot[w[2]];
     } else {
@@ -412,6 +414,146 @@ void build_shared_program(const FusedProgram& fp, int n_msgs, int P, int U, Shar
       }
     }
   }
+  // ---- product-fused form, variables with THREE pairwise factors (K4 cliques: every variable update multiplies the constant
+  // product c and two factor->variable messages).  The producer of a message into such a variable stores  sqrt(c) (.) m  (the
+  // prepare kernel writes sqrt(c) for these products): the input of a contraction is then the PRODUCT OF TWO TILES,
+  // sqrt(c) m_a (.) sqrt(c) m_b = c (.) m_a (.) m_b -- two tile reads and one multiplication per element instead of three reads
+  // and two, and 12 message tiles + the stored variable->factor messages instead of 21 tiles: everything stays in LDS (one
+  // workgroup per CU; the constant products themselves stay in memory: a producer asks for its sixteen rows of them in front of
+  // its matrix instructions).  A variable with two pairwise factors in the same program keeps the c (.) m form above (the
+  // exponent is per constant product: sqrt_mask).  Stored variable->factor messages (members with flag 4, read by a later
+  // plain factor update) are raw tiles.  Record, 4 words:
+  //   [0] flags | pair slot << 16: as above, and 4 the input product is kept as tile [3] >> 8, 0x100 a second input tile [3] & 0xFF
+  //   [1] destination | input tile << 8 | message slot of the input product << 16      (tiles: LDS indices, the constant products left out)
+  //   [2] constant PRODUCT INDEX the result is multiplied by (0xFF none) | stash index << 8      [3] second input | kept tile << 8
+  // Sections: map3 [n_live] LDS index of a tile (0x100 | product index for a constant product), kind3 [n_lds] 0 raw / 1 c (.) m /
+  // 2 sqrt(c) (.) m, | 0x100 some update writes it; stash [n_lds]; back3 [n_back][2] the write-back list in LDS indices.
+  if (!out.pf_ok && out.max_sources == 3 && !getenv("MLBP_SHARED_NO_P3")) {
+    const int NL = out.n_live;
+    std::vector<char> is_c(NL, 0);
+    std::vector<int> prod_of_tile(NL, -1);
+    for (int k = 0; k < fp.n_cprod; ++k) { is_c[out.live_of_slot[n_msgs + 1 + k]] = 1; prod_of_tile[out.live_of_slot[n_msgs + 1 + k]] = k; }
+    bool ok3 = true;
+    std::vector<int> kind(NL, -2), cp(NL, -1), last_writer(NL, -1), ckind(NL, 0);
+    std::vector<int> s1(n_ops, 0xFF), s2(n_ops, 0xFF);
+    for (int i = 0; i < n_ops && ok3; ++i) {
+      const int32_t* m = &mem[(size_t)i * MW];
+      const int n = (m[0] >> 8) & 15;
+      if (pair_kind[i]) {
+        const int tl = m[8];
+        if (tl >= 0) {
+          if (is_c[tl] || (kind[tl] != -2 && kind[tl] != 0)) ok3 = false;
+          else { kind[tl] = 0; s1[i] = tl; }
+        }
+      } else {
+        int c = -1, nc = 0, nm = 0, mt[2] = {-1, -1};
+        for (int q = 0; q < n; ++q) {
+          const int tl = m[8 + q];
+          if (tl < 0) { ok3 = false; break; }
+          if (is_c[tl]) { c = tl; ++nc; }
+          else if (nm < 2) mt[nm++] = tl;
+          else ok3 = false;
+        }
+        if (nc != 1 || nm < 1) ok3 = false;
+        for (int q = 0; q < nm && ok3; ++q) {
+          if (kind[mt[q]] == -2) { kind[mt[q]] = nm; cp[mt[q]] = c; }
+          else if (kind[mt[q]] != nm || cp[mt[q]] != c) ok3 = false;
+        }
+        if (ok3) {
+          if (ckind[c] == 0) ckind[c] = nm; else if (ckind[c] != nm) ok3 = false;
+          s1[i] = mt[0]; s2[i] = nm == 2 ? mt[1] : 0xFF;
+        }
+        if (ok3 && (m[0] & 4)) {
+          const int K = m[3];
+          if (K < 0 || is_c[K] || (kind[K] != -2 && kind[K] != 0)) ok3 = false; else kind[K] = 0;
+        }
+      }
+      if (ok3 && (m[0] & 1) && m[2] >= 0) { if (is_c[m[2]]) ok3 = false; last_writer[m[2]] = i; }
+    }
+    std::vector<int32_t> uinit;
+    if (ok3) {
+      std::vector<int> bundle_of(n_ops, 0), first_touch(NL, n_ops + 1);
+      for (size_t b = 0; b < pairing.size(); b += 2) { bundle_of[pairing[b]] = (int)b / 2; if (pairing[b + 1] >= 0) bundle_of[pairing[b + 1]] = (int)b / 2; }
+      for (int i = n_ops - 1; i >= 0; --i) {
+        const int32_t* m = &mem[(size_t)i * MW];
+        if ((m[0] & 1) && m[2] >= 0) first_touch[m[2]] = bundle_of[i];
+        if (m[0] & 4) first_touch[m[3]] = bundle_of[i];
+        if (s1[i] != 0xFF) first_touch[s1[i]] = bundle_of[i];
+        if (s2[i] != 0xFF) first_touch[s2[i]] = bundle_of[i];
+      }
+      for (int q : init_tiles) first_touch[q] = -1;
+      for (int i = 0; i < n_ops && ok3; ++i) {
+        if (s1[i] != 0xFF) continue;                              // (only a plain factor update whose input nothing has written yet)
+        int pick = -1;
+        for (int tl = 0; tl < NL && pick < 0; ++tl)
+          if (!is_c[tl] && first_touch[tl] > bundle_of[i]) pick = tl;
+        if (pick < 0) { ok3 = false; break; }
+        s1[i] = pick;
+        if (std::find(uinit.begin(), uinit.end(), pick) == uinit.end()) uinit.push_back(pick);
+      }
+    }
+    out.p3_ok = ok3;
+    if (ok3) {
+      std::vector<int> lds_of(NL, -1);
+      out.n_lds = 0;
+      for (int tl = 0; tl < NL; ++tl) if (!is_c[tl]) lds_of[tl] = out.n_lds++;
+      out.sqrt_mask = 0;
+      for (int tl = 0; tl < NL; ++tl) if (is_c[tl] && ckind[tl] == 2) out.sqrt_mask |= 1 << prod_of_tile[tl];
+      std::vector<int32_t> stash(out.n_lds, -1), pfb, pinit, map3(NL, 0), kind3(out.n_lds, 0), back3;
+      out.n_stash = 0;
+      for (int tl = 0; tl < NL; ++tl) {
+        map3[tl] = is_c[tl] ? (0x100 | prod_of_tile[tl]) : lds_of[tl];
+        if (is_c[tl]) continue;
+        if (last_writer[tl] >= 0) stash[lds_of[tl]] = out.n_stash++;
+        kind3[lds_of[tl]] = std::max(kind[tl], 0) | (last_writer[tl] >= 0 ? 0x100 : 0);
+      }
+      for (int tl : uinit) { pinit.push_back(lds_of[tl]); pinit.push_back(-1); }
+      for (int q = 0; q < (int)init_tiles.size(); ++q) {
+        const int tl = init_tiles[q];
+        if (is_c[tl]) continue;
+        pinit.push_back(lds_of[tl]); pinit.push_back(cp[tl] >= 0 ? prod_of_tile[cp[tl]] : -1);
+      }
+      auto pack3 = [&](int i) {
+        int32_t w[4] = {0, 0xFFFF, 0xFF, 0xFFFF};
+        if (i >= 0) {
+          const int32_t* m = &mem[(size_t)i * MW];
+          const int dst = (m[0] & 1) ? m[2] : -1;
+          w[0] = (m[0] & (1 | 2 | 4 | 8 | 16)) | (m[1] << 16);
+          if (dst >= 0 && last_writer[dst] == i) w[0] |= 32;
+          if (dst >= 0) w[0] |= 64;
+          if (s2[i] != 0xFF) w[0] |= 0x100;
+          w[1] = ((dst >= 0 ? lds_of[dst] : 0xFF) & 0xFF) | ((lds_of[s1[i]] & 0xFF) << 8) | (m[4] << 16);
+          w[2] = ((dst >= 0 && cp[dst] >= 0 ? prod_of_tile[cp[dst]] : 0xFF) & 0xFF) | ((dst >= 0 ? stash[lds_of[dst]] : 0) << 8);
+          w[3] = ((s2[i] != 0xFF ? lds_of[s2[i]] : 0xFF) & 0xFF) | ((((m[0] & 4) ? lds_of[m[3]] : 0xFF) & 0xFF) << 8);
+        }
+        pfb.insert(pfb.end(), w, w + 4);
+      };
+      for (size_t b = 0; b < pairing.size(); b += 2) { pack3(pairing[b]); pack3(pairing[b + 1]); }
+      pack3(-1); pack3(-1);
+      for (size_t q = 0; q + 1 < back.size(); q += 2) { back3.push_back(lds_of[back[q]]); back3.push_back(back[q + 1]); }
+      out.n_pinit = (int)pinit.size() / 2;
+      out.vf_direct = false;
+      out.off_pfb = (int)out.image.size();
+      out.image.insert(out.image.end(), pfb.begin(), pfb.end());
+      out.off_stash = (int)out.image.size();
+      out.image.insert(out.image.end(), stash.begin(), stash.end());
+      out.off_pinit = (int)out.image.size();
+      out.image.insert(out.image.end(), pinit.begin(), pinit.end());
+      out.off_map3 = (int)out.image.size();
+      out.image.insert(out.image.end(), map3.begin(), map3.end());
+      out.off_kind3 = (int)out.image.size();
+      out.image.insert(out.image.end(), kind3.begin(), kind3.end());
+      out.off_back3 = (int)out.image.size();
+      out.image.insert(out.image.end(), back3.begin(), back3.end());
+      for (int q = 0; q < 16; ++q) out.image.push_back(0);
+      if (getenv("MLBP_DEBUG_SHARED_PROGRAM")) {
+        for (size_t i = 0; i + 3 < pfb.size(); i += 4)
+          fprintf(stderr, "p3 member: flags 0x%03x pair %d dst %d S %d S2 %d keep %d slot %d cprod %d stash %d\n", pfb[i] & 0xFFF, pfb[i] >> 16, pfb[i + 1] & 0xFF,
+                  (pfb[i + 1] >> 8) & 0xFF, pfb[i + 3] & 0xFF, (pfb[i + 3] >> 8) & 0xFF, pfb[i + 1] >> 16, pfb[i + 2] & 0xFF, pfb[i + 2] >> 8);
+        fprintf(stderr, "p3: n_lds %d n_stash %d n_pinit %d sqrt_mask 0x%x\n", out.n_lds, out.n_stash, out.n_pinit, out.sqrt_mask);
+      }
+    }
+  }
   out.why = "";
   out.ok = true;
 }
@@ -549,6 +691,9 @@ struct SharedDev {
   const int32_t* header;        // [groups][HDR] shared_prepare_kernel's verdict on each group of 16 graphs and its fragment sets
   int32_t off_vftile, vf_direct;  // product-fused + gradient: the epilogue reads the final variable->factor messages from the message tiles
   int32_t lds_bytes, pad3_;     // the workgroup's dynamic LDS
+  // three-source product-fused form (SharedProgram::p3_ok): tile maps, the write-back list in LDS indices, which constant products
+  // the prepare kernel stored as square roots
+  int32_t off_map3, off_kind3, off_back3, sqrt_mask;
   SharedGradDev gr;
 };
 
@@ -631,7 +776,7 @@ struct PrepareDev {
   // pairwise factor p reads the second, partition of the fragment sets over the halves}: what the sweep kernel used to work out
   // from the same data at the start of its single round, one dependent round of memory latency in front of its fragment loads
   const int32_t* pair_tab; const int32_t* image; int32_t* header;
-  int32_t P, n_pair_tables, n_bundles, pad_;
+  int32_t P, n_pair_tables, n_bundles, sqrt_mask;                 // sqrt_mask bit k: constant product k is stored as its square root (three-source product-fused form)
 };
 constexpr int HDR = 8;
 // MULTI: several groups of graphs (mlbp_sweep_groups_f64: every group its own program, tables, messages) in one launch;
@@ -780,7 +925,9 @@ __global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, co
         // be 1 when it writes the tile out as a message)
         double inv_sum = __builtin_amdgcn_rcp(sum);
         inv_sum = __builtin_fma(__builtin_fma(-sum, inv_sum, 1.0), inv_sum, inv_sum);
-        if (!ABL(65536)) ptile_lds[(size_t)k_out * TILE + tile_index(lane, col)] = cur * inv_sum;
+        // (a variable with three pairwise factors: the sweep kernel stores sqrt(c) (.) message, build_shared_program)
+        const double cval = ((d.sqrt_mask >> k_out) & 1) ? sqrt(cur * inv_sum) : cur * inv_sum;
+        if (!ABL(65536)) ptile_lds[(size_t)k_out * TILE + tile_index(lane, col)] = cval;
         ++k_out;
       }
     };
@@ -1103,9 +1250,10 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
 // group k's SharedDev, gstart[k] its first workgroup; the workgroup looks its group up and runs as if launched for it alone.
 // (the body: `d` is the kernel argument, or -- MULTI -- a reference into the group table through the scalar data cache, so
 // that in both forms the description sits in SGPRs / is fetched by scalar loads where it is used)
-template <int NTAB, bool SPILL, bool WIDE, bool GRAD, bool PF, typename Dev>
+template <int NTAB, bool SPILL, bool WIDE, bool GRAD, bool PF, bool P3, typename Dev>
 __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   static_assert(!PF || (!SPILL && !WIDE), "the product-fused form keeps every tile in LDS and reads one tile per update");
+  static_assert(!P3 || PF, "the three-source form is a product-fused form");
   extern __shared__ double lds[];
   double* tiles = lds;                                           // [n_res][64 states][16 graphs]
   double* tot = tiles + (size_t)d.n_res * TILE;                  // [n_live][16 graphs][4 row blocks] partial column sums
@@ -1216,12 +1364,14 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
     if (t < G && g0 + t < d.B) d.bail[g0 + t] = 4;
     return;
   }
+  if (!P3) {                                                     // (three-source form: the constant products stay in memory)
 #pragma unroll
   for (int k = 0; k < 8; ++k)
     if (k < d.n_cprod) {
       reinterpret_cast<double2*>(TP(ptile[k]))[t] = pv[k];
       if (t < 64) tot[ptile[k] * 64 + t] = 0.25;                 // four partials of a total of 1
     }
+  }
   // tiles the program reads before writing them start as the uniform vector (FactorGraph.initialize, LBP.py:211-216)
   if (PF) {
     // (product-fused: a message tile holds c (.) message; before the first update that is c (.) uniform -- a copy of c)
@@ -1466,6 +1616,91 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
     }
     STAMP(3)
   };
+  // Three-source product-fused member (SharedProgram::p3_ok; record layout: build_shared_program).  The input is the product of
+  // one or two tiles (sqrt(c) (.) m_a times sqrt(c) (.) m_b), formed a quarter ahead of the matrix instructions that take it; the
+  // destination's rows of ITS constant product (or its square root) come from memory, requested first and needed last.  One
+  // workgroup per CU: 256 registers a wave, nothing here is squeezed.
+  auto run_p3 = [&](const int flags, const int w1, const int w2, const int w3) {
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));
+    const int gl = lane & 15, cq = lane >> 4;
+    const bool mm = (flags & 1) != 0, second_set = (flags & 0x80) != 0, two = (flags & 0x100) != 0;
+    const bool want = (flags & (4 | 8)) != 0;
+    const int S = (w1 >> 8) & 0xFF, S2 = w3 & 0xFF, K = (w3 >> 8) & 0xFF, ck = w2 & 0xFF;
+    const double2* src = reinterpret_cast<const double2*>(tiles + (size_t)S * TILE) + lane;
+    const double2* src2 = two ? reinterpret_cast<const double2*>(tiles + (size_t)S2 * TILE) + lane : dummy + 1;      // (absent: {1, 1}, stride 0)
+    const int st2 = two ? 128 : 0, of2 = two ? 64 : 0;
+    const double2* tp = reinterpret_cast<const double2*>(tot + S * 64 + gl * 4);
+    const double2* tp2 = two ? reinterpret_cast<const double2*>(tot + S2 * 64 + gl * 4) : dummy + 2;               // (absent: a total of 1)
+    double2 c0 = make_double2(1.0, 1.0), c1 = c0;
+    if (mm && ck != 0xFF) {
+      const double2* cg = psrc + (size_t)ck * (TILE / 2) + 128 * rb + lane;
+      c0 = cg[0]; c1 = cg[64];
+    }
+    const double2 ta = tp[0], tb = tp[1], tc = tp2[0], td = tp2[1];
+    double2 q0 = src[0], q1 = src[64], r0 = src2[0], r1 = src2[of2];
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    double part = 0.0;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const double b0 = q0.x * r0.x, b1 = q0.y * r0.y, b2 = q1.x * r1.x, b3 = q1.y * r1.y;
+      __builtin_amdgcn_sched_barrier(0);
+      if (h < 3) {                                               // the next quarter's reads go out ahead of this quarter's MFMAs
+        q0 = src[128 * (h + 1)]; q1 = src[128 * (h + 1) + 64];
+        r0 = src2[st2 * (h + 1)]; r1 = src2[st2 * (h + 1) + of2];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (want) {
+        part += (b0 + b1) + (b2 + b3);
+        if ((flags & 4) && rb == h) {                            // read by a later factor update: kept as a tile (raw; its total below)
+          double2* o = reinterpret_cast<double2*>(tiles + (size_t)K * TILE) + 128 * rb + lane;
+          o[0] = make_double2(b0, b1); o[64] = make_double2(b2, b3);
+        }
+      }
+      if (mm && !ABL(1)) {
+        if (!second_set) {
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr0[4 * h], b0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr0[4 * h + 1], b1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr0[4 * h + 2], b2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr0[4 * h + 3], b3, acc, 0, 0, 0);
+        } else {
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr1[4 * h], b0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr1[4 * h + 1], b1, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr1[4 * h + 2], b2, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr1[4 * h + 3], b3, acc, 0, 0, 0);
+        }
+      }
+    }
+    const double t0 = (ta.x + ta.y) + (tb.x + tb.y), t1 = (tc.x + tc.y) + (td.x + td.y);
+    bad |= (int)!total_ok(t0) | (int)!total_ok(t1);
+    if (want) {
+      const double tprod = column_sum(part);
+      bad |= !total_ok(tprod);
+      if (flags & 4) {
+        if (cq == 0) tot[K * 64 + gl * 4 + rb] = 0.25 * tprod;
+      } else if (d.msgs && g0 + gl < d.B && !bad) {              // last value of this variable->factor slot: to memory, normalised
+        const double2 v0 = src[128 * rb], v1 = src[128 * rb + 64], u0 = src2[st2 * rb], u1 = src2[st2 * rb + of2];
+        double* out = d.msgs + ((size_t)(g0 + gl) * d.n_msgs + ((w1 >> 16) & 0xFFFF)) * 64 + 16 * rb + cq;
+        const double it = 1.0 / tprod;
+        out[0] = (v0.x * u0.x) * it; out[4] = (v0.y * u0.y) * it; out[8] = (v1.x * u1.x) * it; out[12] = (v1.y * u1.y) * it;
+      }
+    }
+    if (!mm) return;
+    const int dst = w1 & 0xFF;
+    if (flags & 64) {
+      // (any positive per-graph scale cancels downstream; 1 / (the inputs' totals) keeps the magnitudes where they are)
+      const double sc = __builtin_amdgcn_rcp(t0) * __builtin_amdgcn_rcp(t1);
+      const double p0 = acc.x * (c0.x * sc), p1 = acc.y * (c0.y * sc), p2 = acc.z * (c1.x * sc), p3 = acc.w * (c1.y * sc);
+      double2* out = reinterpret_cast<double2*>(tiles + (size_t)dst * TILE) + 128 * rb + lane;
+      out[0] = make_double2(p0, p1); out[64] = make_double2(p2, p3);
+      const double colsum = column_sum((p0 + p1) + (p2 + p3));
+      if (cq == 0) tot[dst * 64 + gl * 4 + rb] = colsum;
+    }
+    if ((flags & 32) && stash_g) {
+      double2* out = stash_g + (size_t)(w2 >> 8) * (TILE / 2) + 128 * rb + lane;
+      out[0] = make_double2(acc.x, acc.y); out[64] = make_double2(acc.z, acc.w);
+    }
+  };
   // the bundles sit in LDS; a bundle's 16 words are read (broadcast) one bundle ahead -- LDS reads return in order, so they
   // cost the tile reads behind them nothing (a scalar load from memory would be waited for with them: one counter)
   const int4* li = reinterpret_cast<const int4*>(limg) + half;  // this half's slot of bundle k: li[2 k]
@@ -1477,7 +1712,8 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
 #pragma unroll 1
     for (int rep = 0; rep < 2; ++rep) {                          // (one copy of the member code; the second round only behind CHAIN)
       if ((cf & 0x7F) != 0) {
-        if constexpr (PF) run_pf(cf, c1, c2);
+        if constexpr (P3) run_p3(cf, c1, c2, c3);
+        else if constexpr (PF) run_pf(cf, c1, c2);
         else run(cf, c1, c2, c3);
       }
       if (rep == 1 || !chain) break;
@@ -1510,7 +1746,122 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   const bool gvalid = gi < d.B;
   const int gc = gvalid ? gi : d.B - 1;
   // a bad total met only here (the last update's result) must reach the verdict of every wave
-  if constexpr (PF) {
+  if constexpr (P3) {
+    // three-source form: a tile holds C (.) message with C = c or sqrt(c) (kind3: 1 / 2; 0: the message itself), C in memory.  With
+    // n_p updated tiles of that kind the marginal c (.) prod m is  C^(e - n_p) (.) prod tiles  (e = 1 / 2: C = c / sqrt(c)); a negative
+    // power is taken out of the FIRST tile (no underflow of the product), where C is 0 so is the marginal.
+    if (stash_g) __syncthreads();
+    const const_i32p rd = as_const(d.readout);
+    double* meet = reinterpret_cast<double*>(reinterpret_cast<char*>(lds) + d.lds_bytes) - 64 * d.n_vars;      // [variable][quarter][graph] partial sums
+    if (d.marginals && !ABL(512)) {
+      constexpr int JW = 4;                                      // (4 n_vars <= 32 jobs: n_vars <= 8, shared_plan)
+      const int n_jobs = 4 * d.n_vars;
+      double m[JW][4];
+#pragma unroll
+      for (int q = 0; q < JW; ++q) {
+        const int j = wave + q * (SWG / 64);
+        if (j >= n_jobs) continue;
+        const int v = j >> 2, h = j & 3;
+        const int at = rd[v];
+        const int base = rd[at], n = rd[at + 1];
+        const int ck = img[d.off_map3 + base] & 0xFF;            // (every variable of the read-out has a constant product: shared_plan)
+        const double2* cg = psrc + (size_t)ck * (TILE / 2) + 128 * h + lane;
+        const double2 c0 = cg[0], c1 = cg[64];
+        const double cc[4] = {c0.x, c0.y, c1.x, c1.y};
+        int n_p = 0;
+        for (int k = 0; k < n; ++k) {
+          const int kd = img[d.off_kind3 + img[d.off_map3 + rd[at + 2 + k]]];
+          if ((kd & 0x100) && (kd & 0xFF)) ++n_p;
+        }
+        const int pw = (((d.sqrt_mask >> ck) & 1) ? 2 : 1) - n_p;
+        m[q][0] = m[q][1] = m[q][2] = m[q][3] = 1.0;
+        bool first = true;
+        for (int k = 0; k < n; ++k) {
+          const int tl = img[d.off_map3 + rd[at + 2 + k]];
+          const int kd = img[d.off_kind3 + tl];
+          if (!(kd & 0x100)) continue;                           // never updated: still uniform, cancels in the normalisation
+          const double2* tp = reinterpret_cast<const double2*>(tot + tl * 64 + gl * 4);
+          const double2 ta = tp[0], tb = tp[1];
+          const double2* src = reinterpret_cast<const double2*>(tiles + (size_t)tl * TILE) + 128 * h + lane;
+          const double2 x0 = src[0], x1 = src[64];
+          const double total = (ta.x + ta.y) + (tb.x + tb.y);
+          bad |= !total_ok(total);
+          const double inv = __builtin_amdgcn_rcp(total);        // (any positive scale: it cancels below)
+          m[q][0] *= x0.x * inv; m[q][1] *= x0.y * inv; m[q][2] *= x1.x * inv; m[q][3] *= x1.y * inv;
+          if ((kd & 0xFF) && first && pw < 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                        // m / C by the hardware reciprocal and one Newton step (3e-17 relative)
+              double rc = __builtin_amdgcn_rcp(cc[r]);
+              rc = __builtin_fma(__builtin_fma(-cc[r], rc, 1.0), rc, rc);
+              m[q][r] = cc[r] > 1e-290 ? m[q][r] * rc : 0.0;
+            }
+          }
+          if (kd & 0xFF) first = false;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (pw >= 1) m[q][r] *= cc[r];
+          if (pw >= 2) m[q][r] *= cc[r];
+        }
+        const double part = column_sum((m[q][0] + m[q][1]) + (m[q][2] + m[q][3]));
+        if (cq == 0) meet[v * 64 + h * G + gl] = part;
+      }
+      __syncthreads();
+      // the normalised values leave as whole 512-byte rows: staged in the variable's FIRST message tile (spent: every job holds its
+      // values), state s of graph gl at s ^ gl
+#pragma unroll
+      for (int q = 0; q < JW; ++q) {
+        const int j = wave + q * (SWG / 64);
+        if (j >= n_jobs) continue;
+        const int v = j >> 2, h = j & 3;
+        const double* rp = meet + v * 64 + gl;
+        const double tm = (rp[0] + rp[G]) + (rp[2 * G] + rp[3 * G]);
+        bad |= !total_ok(tm);
+        const double itm = 1.0 / tm;
+        double* o = tiles + (size_t)img[d.off_map3 + rd[rd[v] + 2]] * TILE + gl * 64;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(16 * h + cq + 4 * r) ^ gl] = m[q][r] * itm;
+      }
+      __syncthreads();
+    }
+    // write-back: stored variable->factor messages from their tiles (what the gradient reads; NOT the tiles the marginals were staged
+    // in: those are factor->variable tiles), factor->variable messages from the raw results the members stashed
+    if (d.msgs)
+      for (int i = wave; i < d.n_back; i += SWG / 64) {
+        const int tl = img[d.off_back3 + 2 * i], sl = img[d.off_back3 + 2 * i + 1];
+        const bool is_vf = (sl & 0x40000000) != 0;
+        if (is_vf) {
+          const double* tp = tot + tl * 64 + gl * 4;
+          const double total = (tp[0] + tp[1]) + (tp[2] + tp[3]);
+          bad |= !total_ok(total);
+          if (gvalid && !bad) {
+            const double2* src = reinterpret_cast<const double2*>(tiles + (size_t)tl * TILE) + lane;
+            double* out = d.msgs + ((size_t)gc * d.n_msgs + (sl & 0x3FFFFFFF)) * 64 + cq;
+            const double inv = 1.0 / total;
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp) { const double2 v = src[64 * sp]; out[8 * sp] = v.x * inv; out[8 * sp + 4] = v.y * inv; }
+          }
+          continue;
+        }
+        const int si = img[d.off_stash + tl];
+        if (si < 0 || !stash_g || d.vf_only) continue;
+        const double2* src = stash_g + (size_t)si * (TILE / 2) + lane;
+        double2 x[8];
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) x[sp] = src[64 * sp];
+        double part = 0.0;
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) part += x[sp].x + x[sp].y;
+        const double total = column_sum(part);
+        bad |= !total_ok(total);
+        if (gvalid && !bad) {
+          double* out = d.msgs + ((size_t)gc * d.n_msgs + (sl & 0x3FFFFFFF)) * 64 + cq;
+          const double inv = 1.0 / total;
+#pragma unroll
+          for (int sp = 0; sp < 8; ++sp) { out[8 * sp] = x[sp].x * inv; out[8 * sp + 4] = x[sp].y * inv; }
+        }
+      }
+  } else if constexpr (PF) {
     // product-fused: a tile holds c (.) message (or, when no update reads it, the message).  With the variable's constant
     // product c and P_a = c (.) m_a, P_b = c (.) m_b the marginal c (.) m_a (.) m_b is P_a (.) (P_b / c) -- where c is 0 so is the
     // marginal --: everything from LDS.  (c (.) m keeps nothing of m where c is 0, so the message WRITE-BACK reads the raw
@@ -1683,7 +2034,8 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
       for (int row = wave; row < d.n_vars * G; row += SWG / 64) {
         const int g = row & (G - 1), v = row >> 4;
         if (g0 + g < d.B && !((flagged >> g) & 0x0001000100010001ull))
-          __builtin_nontemporal_store(tiles[(size_t)rd[rd[v]] * TILE + g * 64 + (lane ^ g)], &d.marginals[((size_t)(g0 + g) * d.n_vars + v) * 64 + lane]);
+          __builtin_nontemporal_store(tiles[(size_t)(P3 ? img[d.off_map3 + rd[rd[v] + 2]] : rd[rd[v]]) * TILE + g * 64 + (lane ^ g)],
+                                      &d.marginals[((size_t)(g0 + g) * d.n_vars + v) * 64 + lane]);
       }
     }
   }
@@ -1705,18 +2057,18 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
 }
 
 typedef const SharedDev __attribute__((address_space(4))) SharedDevConst;
-template <int NTAB, bool SPILL, bool WIDE, bool MULTI, bool GRAD, bool PF = false>
-__global__ __launch_bounds__(SWG, 4) void sweep_x64_shared_kernel(SharedDev d, const SharedDev* gtab, const int32_t* gstart, int n_groups) {
+template <int NTAB, bool SPILL, bool WIDE, bool MULTI, bool GRAD, bool PF = false, bool P3 = false>
+__global__ __launch_bounds__(SWG, P3 ? 2 : 4) void sweep_x64_shared_kernel(SharedDev d, const SharedDev* gtab, const int32_t* gstart, int n_groups) {
   if (MULTI) {
     const int lo = find_group(gstart, n_groups, blockIdx.x);
     SharedDevConst& dg = *(SharedDevConst*)(uintptr_t)(gtab + lo);
-    sweep_x64_shared_body<NTAB, SPILL, WIDE, GRAD, PF>(dg, (int)blockIdx.x - as_const(gstart)[lo]);
+    sweep_x64_shared_body<NTAB, SPILL, WIDE, GRAD, PF, P3>(dg, (int)blockIdx.x - as_const(gstart)[lo]);
   } else {
     // the description is the first kernel argument: read where it is used, through the scalar cache, out of the kernel
     // argument segment -- preloaded as a by-value struct its 80 words crowd the scalar registers of the main loop
     (void)d;
     SharedDevConst& dk = *(SharedDevConst*)__builtin_amdgcn_kernarg_segment_ptr();
-    sweep_x64_shared_body<NTAB, SPILL, WIDE, GRAD, PF>(dk, (int)blockIdx.x);
+    sweep_x64_shared_body<NTAB, SPILL, WIDE, GRAD, PF, P3>(dk, (int)blockIdx.x);
   }
 }
 
@@ -1929,9 +2281,18 @@ sweep_fn grad_instance() {
 }
 
 // the instance for (two tables?, spilled tiles?, more than two sources?, groups?); raises its dynamic LDS limit once
-int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, bool pf, size_t lds, sweep_fn* out) {
+int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, bool pf, size_t lds, sweep_fn* out, bool p3 = false) {
   sweep_fn k = nullptr;
   if (spill || wide) pf = false;
+  if (p3) {                                                      // three-source product-fused form: one launch, one program
+    if (multi) return fail(MLBP_EUNSUPPORTED, "the three-source product-fused form has no grouped instance");
+#ifdef MLBP_STAMPS
+    return fail(MLBP_EUNSUPPORTED, "stamps build: no three-source instance");
+#else
+    k = two ? (grad ? (sweep_fn)sweep_x64_shared_kernel<2, false, false, false, true, true, true> : (sweep_fn)sweep_x64_shared_kernel<2, false, false, false, false, true, true>)
+            : (grad ? (sweep_fn)sweep_x64_shared_kernel<1, false, false, false, true, true, true> : (sweep_fn)sweep_x64_shared_kernel<1, false, false, false, false, true, true>);
+#endif
+  } else {
 #ifdef MLBP_STAMPS      // the diagnostic build instantiates the all-resident two-source kernels only
   if (spill || wide || multi) return fail(MLBP_EUNSUPPORTED, "stamps build: no spilling / wide / grouped instance");
   if (pf)
@@ -1961,6 +2322,7 @@ int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, bo
 #undef MLBP_SK
   }
 #endif
+  }
   static std::vector<std::pair<const void*, size_t>> granted;
   {
     std::lock_guard<std::mutex> lock(g_attr_mutex);
@@ -1973,7 +2335,7 @@ int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, bo
       int per_cu = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, SWG, lds) == hipSuccess)
         fail(MLBP_OK, "shared-table kernel <%d%s%s%s%s%s>: %zu bytes of LDS per workgroup, %d workgroups per CU", two ? 2 : 1,
-             spill ? ", spilling" : "", wide ? ", wide" : "", multi ? ", groups" : "", grad ? ", gradient" : "", pf ? ", product-fused" : "", lds, per_cu);
+             spill ? ", spilling" : "", wide ? ", wide" : "", multi ? ", groups" : "", grad ? ", gradient" : "", p3 ? ", product-fused (three sources)" : (pf ? ", product-fused" : ""), lds, per_cu);
     }
   }
   *out = k;
@@ -2012,8 +2374,8 @@ namespace {
 
 // What a shared-table sweep of (prog, a) needs: the two device descriptions, the LDS size, the grid sizes.  *ok false: the
 // kernel does not apply (mlbp_last_error says why).  Allocates the program's scratch on first use.
-struct SharedPlan { SharedDev d; PrepareDev q; size_t lds; int n_wg, n_prep_blocks; bool wide, spill, pf; };
-int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, SharedPlan* out) {
+struct SharedPlan { SharedDev d; PrepareDev q; size_t lds; int n_wg, n_prep_blocks; bool wide, spill, pf, p3; };
+int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, SharedPlan* out, bool allow_p3 = true) {
   *ok = false;
   memset(out, 0, sizeof(*out));
   const SharedProgram& sp = prog->shared;
@@ -2028,9 +2390,16 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   // graphs (21 tiles): 8 resident + 13 spilled with two workgroups per CU 0.216 ms, 16 resident + 5 spilled with
   // one 0.266 ms.
   size_t lds = 0;
-  const int n_res = resident_tiles(sp, &lds);
+  int n_res = resident_tiles(sp, &lds);
   const int n_cprod = (int)sp.cprods.size();
-  if (n_res < 1 || sp.n_live - n_res > 16 || lds > 160 * 1024)   // too much would spill: the per-graph kernels do better
+  // the three-source product-fused form (K4 cliques): every message tile and every stored variable->factor message in LDS, the
+  // constant products in memory, one workgroup per CU
+  const size_t lds3 = (size_t)sp.n_lds * (TILE + 64) * sizeof(double) + 64 + 8 * (size_t)(sp.n_bundles + 1) * sizeof(int32_t) + 64 +
+                      (size_t)prog->n_vars * 64 * sizeof(double);
+  const bool p3 = allow_p3 && sp.p3_ok && lds3 <= 160 * 1024 && n_cprod >= 1 && n_cprod <= 8 && prog->n_vars <= 8 &&
+                  (!a->marginals || (prog->sreadout_all_based && prog->sreadout_all_tiled));
+  if (p3) { n_res = sp.n_lds; lds = lds3; }
+  if (n_res < 1 || (!p3 && sp.n_live - n_res > 16) || lds > 160 * 1024)   // too much would spill: the per-graph kernels do better
     return fail(MLBP_OK, "shared-table kernel not used: %d live message tiles, %d fit LDS", sp.n_live, n_res);
   if (n_cprod < 1 || n_cprod > 8) return fail(MLBP_OK, "shared-table kernel not used: %d constant products (1..8)", n_cprod);
   mlbp_program* mp = const_cast<mlbp_program*>(prog);
@@ -2038,7 +2407,7 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   // the product-fused form (diagnostic switch: MLBP_SHARED_NO_PF in the environment keeps the general form)
   static const bool no_pf = getenv("MLBP_SHARED_NO_PF") != nullptr;
   const bool pf = sp.pf_ok && !no_pf && n_res == sp.n_live && sp.max_sources <= 2 && (!a->marginals || prog->sreadout_all_based) && prog->n_vars <= 8;     // (the read-out stages 8 variables' rows in the spent tiles)
-  const size_t spill_doubles = pf ? (size_t)n_groups * sp.n_stash * TILE : (size_t)n_groups * (sp.n_live - n_res) * TILE;
+  const size_t spill_doubles = (pf || p3) ? (size_t)n_groups * sp.n_stash * TILE : (size_t)n_groups * (sp.n_live - n_res) * TILE;
   // (first use at this size allocates -- a stream-capturing caller warms up or reserves first; a block that is outgrown stays
   // alive with the program: program_grow)
   if (spill_doubles > 0)
@@ -2056,21 +2425,22 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   d.image = prog->d_simage; d.readout = prog->d_sreadout;
   d.B = a->B; d.n_msgs = prog->n_msgs; d.P = prog->P; d.U = prog->U;
   d.n_pair_tables = a->n_pair_tables; d.n_unary_tables = a->n_unary_tables; d.n_vars = prog->n_vars;
-  d.n_bundles = sp.n_bundles; d.n_live = sp.n_live; d.n_cprod = n_cprod; d.n_back = sp.n_back;
+  d.n_bundles = sp.n_bundles; d.n_live = p3 ? sp.n_lds : sp.n_live; d.n_cprod = n_cprod; d.n_back = sp.n_back;
   d.n_fill = sp.n_fill; d.n_init = sp.n_init;
   d.off_back = sp.off_back; d.off_fill = sp.off_fill; d.off_init = sp.off_init; d.off_ptile = sp.off_ptile;
   d.ptiles = mp->d_ptiles;
-  d.n_res = n_res; d.spill = n_res < sp.n_live ? mp->d_spill : nullptr;
+  d.n_res = n_res; d.spill = (!p3 && n_res < sp.n_live) ? mp->d_spill : nullptr;
+  d.off_map3 = sp.off_map3; d.off_kind3 = sp.off_kind3; d.off_back3 = sp.off_back3; d.sqrt_mask = p3 ? sp.sqrt_mask : 0;
   d.off_written = sp.off_written;
   d.off_pfb = sp.off_pfb; d.off_stash = sp.off_stash; d.off_pinit = sp.off_pinit; d.n_pinit = sp.n_pinit; d.n_stash = sp.n_stash;
-  d.stash = pf ? mp->d_spill : nullptr;
+  d.stash = (pf || p3) ? mp->d_spill : nullptr;
   d.header = mp->d_header;
   d.off_vftile = sp.off_vftile;
   d.vf_direct = 0;                                 // (set below when the gradient is this launch's epilogue)
   // the product-fused form takes the whole half of the CU's LDS: the spare bytes behind the totals are the gradient epilogue's
   if (pf) lds = std::max(lds, (size_t)79 * 1024 + 512);
   d.lds_bytes = (int32_t)lds;
-  out->pf = pf;
+  out->pf = pf; out->p3 = p3;
   d.tfrag = nullptr;
   if (a->n_pair_tables <= FRAG_TABLES) {
     if (!mp->d_tfrag) {                            // first use (a stream-capturing caller warms up or reserves first)
@@ -2086,6 +2456,7 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   q.ptiles = mp->d_ptiles; q.bail = mp->d_bail; q.status = prog->d_status;
   q.B = a->B; q.U = prog->U; q.n_unary_tables = a->n_unary_tables; q.E = sp.n_cpw / 4; q.n_cprod = n_cprod; q.n_groups = n_groups;
   q.pair_tab = a->pair_tab; q.image = prog->d_simage; q.header = mp->d_header; q.P = prog->P; q.n_pair_tables = a->n_pair_tables; q.n_bundles = sp.n_bundles;
+  q.sqrt_mask = p3 ? sp.sqrt_mask : 0;
   // the gradient as the sweep kernel's epilogue (the prepare launch also writes its weighted table fragments)
   if (shared_gradient_fused(prog, a)) {
     const mlbp_gradient_args* ga = a->gradient;
@@ -2105,7 +2476,7 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
     d.vf_direct = (pf && sp.vf_direct && a->marginals) ? 1 : 0;      // ... or, product-fused, takes them from the message tiles
   }
   out->lds = lds; out->n_wg = n_groups; out->n_prep_blocks = (a->B + PGB - 1) / PGB;       // (= n_groups)
-  out->wide = sp.max_sources > 2; out->spill = d.spill != nullptr;
+  out->wide = !p3 && sp.max_sources > 2; out->spill = d.spill != nullptr;
   *ok = true;
   return MLBP_OK;
 }
@@ -2134,7 +2505,7 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   hipLaunchKernelGGL(shared_prepare_kernel<false>, dim3(pl.n_prep_blocks), dim3(PWG), (size_t)pl.q.n_cprod * TILE * sizeof(double), st, pl.q, nullptr, nullptr, 0);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
   sweep_fn k = nullptr;
-  if (int e = pick_sweep_kernel(prog->P >= 2, pl.spill, pl.wide, false, pl.d.gr.enabled != 0, pl.pf, pl.lds, &k)) return e;
+  if (int e = pick_sweep_kernel(prog->P >= 2, pl.spill, pl.wide, false, pl.d.gr.enabled != 0, pl.pf, pl.lds, &k, pl.p3)) return e;
   hipLaunchKernelGGL(k, dim3(pl.n_wg), dim3(SWG), pl.lds, st, pl.d, nullptr, nullptr, 0);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed");
   if (int e = enqueue_unary_writeback(prog, a, pl.d, st)) return e;
@@ -2158,7 +2529,7 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
     for (int j = 0; j < k; ++j)
       if (progs[j] == progs[k]) return MLBP_OK;      // two groups would share one set of redo flags and scratch
     bool ok = false;
-    if (int e = shared_plan(progs[k], &args[k], &ok, &plans[k])) return e;
+    if (int e = shared_plan(progs[k], &args[k], &ok, &plans[k], false)) return e;       // (the grouped launch has no three-source product-fused instance)
     if (!ok) return MLBP_OK;
     lds = std::max(lds, plans[k].lds);
     wide |= plans[k].wide; spill |= plans[k].spill; two |= progs[k]->P >= 2; grad |= plans[k].d.gr.enabled != 0; pf &= plans[k].pf;

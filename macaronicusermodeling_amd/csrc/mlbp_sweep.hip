@@ -1427,7 +1427,7 @@ int mlbp_program_plan(const int32_t* ops, int32_t n_ops, const int32_t* srcs, in
   mlbp::SharedProgram sp;
   mlbp::build_shared_program(fp, n_msgs, P, U, sp);
   out8[0] = (int)fp.fops.size() / 8; out8[1] = lone; out8[2] = fused; out8[3] = bundled;
-  out8[4] = (sp.ok ? 1 : 0) | (sp.ok && sp.pf_ok ? 2 : 0) | (sp.ok && sp.pf_ok && sp.vf_direct ? 4 : 0); out8[5] = sp.n_live; out8[6] = sp.n_ops; out8[7] = sp.n_live * (64 * 16 + 64) * 8;
+  out8[4] = (sp.ok ? 1 : 0) | (sp.ok && sp.pf_ok ? 2 : 0) | (sp.ok && sp.pf_ok && sp.vf_direct ? 4 : 0) | (sp.ok && sp.p3_ok ? 8 : 0); out8[5] = sp.n_live; out8[6] = sp.n_ops; out8[7] = sp.n_live * (64 * 16 + 64) * 8;
   return MLBP_OK;
 }
 
@@ -2056,11 +2056,12 @@ int mlbp_program_set_readout(mlbp_program* p, int32_t n_vars, const int32_t* in_
   p->d_sreadout = nullptr;
   p->n_sreadout = 0;
   std::vector<int32_t> simg;
-  p->sreadout_all_based = false;
+  p->sreadout_all_based = false; p->sreadout_all_tiled = false;
   if (p->shared.ok && mlbp::build_shared_readout(p->shared, p->n_msgs, n_vars, in_off, in_slots, simg)) {
-    p->sreadout_all_based = true;
+    p->sreadout_all_based = true; p->sreadout_all_tiled = true;
     for (int v = 0; v < n_vars; ++v) {
       p->sreadout_all_based &= simg[simg[v]] >= 0;
+      p->sreadout_all_tiled &= simg[simg[v] + 1] >= 1;       // (the three-source product-fused read-out stages a variable's rows in its first message tile)
       for (int u = 0; u < v; ++u) p->sreadout_all_based &= simg[simg[u]] != simg[simg[v]];      // (and its own: the read-out stages a variable's rows there)
     }
     HIP_TRY(hipMalloc(&p->d_sreadout, simg.size() * sizeof(int32_t)));

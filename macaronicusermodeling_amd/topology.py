@@ -167,6 +167,7 @@ class GraphTopology:
         plan = dict(zip(keys, (int(v) for v in out)))
         plan['shared_product_fused'] = (plan['shared_ok'] >> 1) & 1       # the message's producer stores c (.) message: K2, K3, chains, rings
         plan['shared_gradient_from_tiles'] = (plan['shared_ok'] >> 2) & 1
+        plan['shared_product_fused3'] = (plan['shared_ok'] >> 3) & 1      # ... stores sqrt(c) (.) message: variables with three pairwise factors (K4)
         plan['shared_ok'] &= 1
         return plan
 

@@ -46,6 +46,7 @@ SPECS = {
     'user_k3_gaps_1_2_3': lambda: C.user_spec(10, [1, 2, 4], 64, 64, seed=2),      # both en_en pots
     'user_k2': lambda: C.user_spec(6, [0, 1], 64, 64, seed=3),
     'user_k4': lambda: C.user_spec(9, [0, 2, 3, 7], 64, 64, seed=4),
+    'user_k4_both_pots': lambda: C.user_spec(9, [0, 1, 3, 4], 64, 64, seed=5),   # two adjacent pairs: both en_en pots, every orientation
 }
 
 
@@ -118,10 +119,11 @@ def test_degenerate_graphs_in_a_shared_batch_are_redone_exactly():
             np.testing.assert_allclose(got[b], want, rtol=RTOL, atol=1e-300)
 
 
-@pytest.mark.parametrize('name', ['user_k3_gaps_3_6', 'user_k3_gaps_1_2_3', 'user_k2'])
+@pytest.mark.parametrize('name', ['user_k3_gaps_3_6', 'user_k3_gaps_1_2_3', 'user_k2', 'user_k4', 'user_k4_both_pots'])
 def test_product_fused_form_with_zeros_in_the_constant_products(name):
     """The product-fused form of the kernel (K2, K3: the producer of a message stores c (.) message, the marginal c (.) m_a (.) m_b
-    comes out as P_a (.) (P_b / c)) on unary tables with exact zeros -- states where c is 0: the marginal is 0 there, the
+    comes out as P_a (.) (P_b / c); K4: it stores sqrt(c) (.) message, a contraction's input is the product of two tiles and the
+    marginal Q_a (.) Q_b (.) Q_c / sqrt(c)) on unary tables with exact zeros -- states where c is 0: the marginal is 0 there, the
     written-back MESSAGES are not (they come from the raw results the members stash) -- against the oracle, with and without the
     message write-back; and the host says the form applies."""
     from macaronicusermodeling_amd import _ffi
@@ -138,7 +140,7 @@ def test_product_fused_form_with_zeros_in_the_constant_products(name):
     B = 37
     fb, topo, inputs = _shared_batch(spec, B, mutate=mutate)
     roots = ([v for v in topo.var_ids] * 3)[:3]
-    assert topo.plan(roots)['shared_product_fused'] == 1
+    assert topo.plan(roots)['shared_product_fused3' if name.startswith('user_k4') else 'shared_product_fused'] == 1
     marg = torch.full((B, topo.n_vars, 64), float('nan'), dtype=torch.float64, device=fb.device)
     fb.msgs.fill_(float('nan'))
     prog = fb.sweep(roots, init=True, marginals=marg)

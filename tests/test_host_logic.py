@@ -147,6 +147,8 @@ def test_program_rewrites_plan():
     assert (k3['shared_product_fused'], k3['shared_gradient_from_tiles']) == (1, 1)
     assert (k2['shared_product_fused'], k2['shared_gradient_from_tiles']) == (1, 0)
     assert (k4['shared_product_fused'], k4['shared_gradient_from_tiles']) == (0, 0)
+    # K4: the three-source variant (messages stored as sqrt(c) (.) message, 12 + 5 tiles in LDS, the constant products in memory)
+    assert (k4['shared_product_fused3'], k3['shared_product_fused3'], k2['shared_product_fused3']) == (1, 0, 0)
     ring = GraphTopology.from_spec(C.ring_spec(8, 64)).plan([0, 0, 0])
     assert ring['fused_updates'] == ring['updates'] == 48 and ring['bundles'] == 24
     k1 = GraphTopology.from_spec(C.user_spec(5, [2], 64, 64, seed=5)).plan([2])      # no pairwise factor at all

@@ -2284,13 +2284,13 @@ sweep_fn grad_instance() {
 int pick_sweep_kernel(bool two, bool spill, bool wide, bool multi, bool grad, bool pf, size_t lds, sweep_fn* out, bool p3 = false) {
   sweep_fn k = nullptr;
   if (spill || wide) pf = false;
-  if (p3) {                                                      // three-source product-fused form: one launch, one program
-    if (multi) return fail(MLBP_EUNSUPPORTED, "the three-source product-fused form has no grouped instance");
+  if (p3) {                                                      // three-source product-fused form
 #ifdef MLBP_STAMPS
     return fail(MLBP_EUNSUPPORTED, "stamps build: no three-source instance");
 #else
-    k = two ? (grad ? (sweep_fn)sweep_x64_shared_kernel<2, false, false, false, true, true, true> : (sweep_fn)sweep_x64_shared_kernel<2, false, false, false, false, true, true>)
-            : (grad ? (sweep_fn)sweep_x64_shared_kernel<1, false, false, false, true, true, true> : (sweep_fn)sweep_x64_shared_kernel<1, false, false, false, false, true, true>);
+#define MLBP_P3(T, M) (grad ? (sweep_fn)sweep_x64_shared_kernel<T, false, false, M, true, true, true> : (sweep_fn)sweep_x64_shared_kernel<T, false, false, M, false, true, true>)
+    k = two ? (multi ? MLBP_P3(2, true) : MLBP_P3(2, false)) : (multi ? MLBP_P3(1, true) : MLBP_P3(1, false));
+#undef MLBP_P3
 #endif
   } else {
 #ifdef MLBP_STAMPS      // the diagnostic build instantiates the all-resident two-source kernels only
@@ -2521,48 +2521,75 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   *launched = false;
   if (n_groups < 1) return MLBP_OK;
   std::vector<SharedPlan> plans(n_groups);
-  size_t lds = 0;
-  bool wide = false, spill = false, two = false, grad = false, pf = true;
   int max_cprod = 1;
   for (int k = 0; k < n_groups; ++k) {
     if (!progs[k]) return MLBP_OK;
     for (int j = 0; j < k; ++j)
       if (progs[j] == progs[k]) return MLBP_OK;      // two groups would share one set of redo flags and scratch
     bool ok = false;
-    if (int e = shared_plan(progs[k], &args[k], &ok, &plans[k], false)) return e;       // (the grouped launch has no three-source product-fused instance)
+    if (int e = shared_plan(progs[k], &args[k], &ok, &plans[k])) return e;
     if (!ok) return MLBP_OK;
-    lds = std::max(lds, plans[k].lds);
-    wide |= plans[k].wide; spill |= plans[k].spill; two |= progs[k]->P >= 2; grad |= plans[k].d.gr.enabled != 0; pf &= plans[k].pf;
     max_cprod = std::max(max_cprod, (int)plans[k].q.n_cprod);
   }
-  // (a launch with the gradient epilogue runs the all-resident / two-source instance, or -- as soon as one group spills tiles or
-  // has wider updates: K4 and larger cliques -- the general one: pick_sweep_kernel)
-  // table image: [SharedDev x n][PrepareDev x n][sweep starts n + 1][prepare starts n + 1], as 32-bit words
+  // The groups run in up to three sweep launches, one per FORM of the kernel: product-fused (K2, K3, chains, rings), its
+  // three-source variant (K4), general (larger cliques, spilled tiles) -- a K3 group of a minibatch that also holds a K4 sentence
+  // keeps its own, faster instance (and its gradient epilogue that reads the message tiles).  One prepare launch in front of all.
+  // table image: [SharedDev x n][PrepareDev x n][prepare starts n + 1][sweep starts of class 0 | 1 | 2, each (its groups) + 1], as 32-bit
+  // words; the groups in class order
+  auto cls = [&](int k) { return plans[k].pf ? 0 : (plans[k].p3 ? 1 : 2); };
+  std::vector<int> order;
+  int first[4] = {0, 0, 0, 0};
+  for (int c = 0; c < 3; ++c) {
+    first[c] = (int)order.size();
+    for (int k = 0; k < n_groups; ++k) if (cls(k) == c) order.push_back(k);
+  }
+  first[3] = n_groups;
   const size_t w_sd = sizeof(SharedDev) / 4, w_pd = sizeof(PrepareDev) / 4;
   static_assert(sizeof(SharedDev) % 8 == 0 && sizeof(PrepareDev) % 8 == 0, "group tables are copied as words");
-  std::vector<int32_t> table((w_sd + w_pd) * n_groups + 2 * (n_groups + 1));
-  int wg = 0, pb = 0;
-  int32_t* starts = table.data() + (w_sd + w_pd) * n_groups;
-  for (int k = 0; k < n_groups; ++k) {
-    memcpy(table.data() + w_sd * k, &plans[k].d, sizeof(SharedDev));
-    memcpy(table.data() + w_sd * n_groups + w_pd * k, &plans[k].q, sizeof(PrepareDev));
-    starts[k] = wg; starts[n_groups + 1 + k] = pb;
-    wg += plans[k].n_wg; pb += plans[k].n_prep_blocks;
+  std::vector<int32_t> table((w_sd + w_pd) * n_groups + (n_groups + 1) + (n_groups + 3));
+  int32_t* pstarts = table.data() + (w_sd + w_pd) * n_groups;
+  int32_t* sstarts = pstarts + n_groups + 1;                     // class c: sstarts[first[c] + c .. first[c + 1] + c]
+  int pb = 0, grid[3] = {0, 0, 0};
+  for (int j = 0; j < n_groups; ++j) {
+    const int k = order[j];
+    memcpy(table.data() + w_sd * j, &plans[k].d, sizeof(SharedDev));
+    memcpy(table.data() + w_sd * n_groups + w_pd * j, &plans[k].q, sizeof(PrepareDev));
+    pstarts[j] = pb; pb += plans[k].n_prep_blocks;
   }
-  starts[n_groups] = wg; starts[2 * n_groups + 1] = pb;
+  pstarts[n_groups] = pb;
+  for (int c = 0; c < 3; ++c) {
+    int wg = 0;
+    for (int j = first[c]; j < first[c + 1]; ++j) { sstarts[j + c] = wg; wg += plans[order[j]].n_wg; }
+    sstarts[first[c + 1] + c] = wg;
+    grid[c] = wg;
+  }
   mlbp_program* owner = const_cast<mlbp_program*>(progs[0]);
   hipStream_t st = (hipStream_t)stream;
   int32_t* d_stable = nullptr;               // one device copy per distinct table: a captured graph keeps replaying against its own
   if (int e = group_table_device(owner->stables, table, stream, &d_stable)) return e;
   const SharedDev* d_sd = reinterpret_cast<const SharedDev*>(d_stable);
   const PrepareDev* d_pd = reinterpret_cast<const PrepareDev*>(d_stable + w_sd * n_groups);
-  const int32_t* d_starts = d_stable + (w_sd + w_pd) * n_groups;
-  hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), (size_t)max_cprod * TILE * sizeof(double), st, plans[0].q, d_pd, d_starts + n_groups + 1, n_groups);
+  const int32_t* d_pstarts = d_stable + (w_sd + w_pd) * n_groups;
+  const int32_t* d_sstarts = d_pstarts + n_groups + 1;
+  hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), (size_t)max_cprod * TILE * sizeof(double), st, plans[order[0]].q, d_pd, d_pstarts, n_groups);
   if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
-  sweep_fn k = nullptr;
-  if (int e = pick_sweep_kernel(two, spill, wide, true, grad, pf, lds, &k)) return e;
-  hipLaunchKernelGGL(k, dim3(wg), dim3(SWG), lds, st, plans[0].d, d_sd, d_starts, n_groups);
-  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed");
+  for (int c = 0; c < 3; ++c) {
+    const int n = first[c + 1] - first[c];
+    if (n == 0) continue;
+    size_t lds = 0;
+    bool wide = false, spill = false, two = false, grad = false;
+    for (int j = first[c]; j < first[c + 1]; ++j) {
+      const SharedPlan& pl = plans[order[j]];
+      lds = std::max(lds, pl.lds);
+      wide |= pl.wide; spill |= pl.spill; two |= progs[order[j]]->P >= 2; grad |= pl.d.gr.enabled != 0;
+    }
+    // (a general launch with the gradient epilogue runs the all-resident / two-source instance, or -- as soon as one group spills
+    // tiles or has wider updates -- the spilling, wide one: pick_sweep_kernel)
+    sweep_fn k = nullptr;
+    if (int e = pick_sweep_kernel(two, spill, wide, true, grad, c == 0, lds, &k, c == 1)) return e;
+    hipLaunchKernelGGL(k, dim3(grid[c]), dim3(SWG), lds, st, plans[order[first[c]]].d, d_sd + first[c], d_sstarts + first[c] + c, n);
+    if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed");
+  }
   for (int g = 0; g < n_groups; ++g)
     if (int e = enqueue_unary_writeback(progs[g], &args[g], plans[g].d, st)) return e;
   *launched = true;

@@ -449,10 +449,10 @@ def test_large_state_shared_float32_tables_on_the_f32_matrix_cores(X):
 
 
 def test_groups_of_mixed_shapes_in_one_shared_launch_sequence():
-    """mlbp_sweep_groups_f64 over four topologies (K2, two K3, K4 -- the last one spills tiles and has three-source
-    updates), each with its own roots, batch size (partial last groups of 16) and tables: ONE prepare + ONE sweep launch of
-    the shared-table kernels behind a group table.  Same bits as the four single launch sequences, the oracle's values, a
-    degenerate graph of one group redone by the exact kernel."""
+    """mlbp_sweep_groups_f64 over four topologies (K2, two K3, K4 -- the last one has three-source updates), each with its
+    own roots, batch size (partial last groups of 16) and tables: ONE prepare launch and one sweep launch PER FORM of the
+    shared-table kernel (product-fused: K2, K3; its three-source variant: K4) behind a group table.  Same bits as the four
+    single launch sequences, the oracle's values, a degenerate graph of one group redone by the exact kernel."""
     from macaronicusermodeling_amd import _ffi
     from macaronicusermodeling_amd.batch import sweep_groups
     names, sizes = ['user_k2', 'user_k3_gaps_1_2_3', 'user_k4', 'user_k3_gaps_3_6'], [5, 37, 18, 16]
@@ -473,16 +473,14 @@ def test_groups_of_mixed_shapes_in_one_shared_launch_sequence():
     assert _ffi.lib.mlbp_last_sweep_kernel() == KERNEL_SHARED_MFMA, _ffi.lib.mlbp_last_error()
     assert [p.exact_count(B) for p, B in zip(progs, sizes)] == [0, 1, 0, 0]
     for k, (fb, topo, inputs) in enumerate(built):
-        # (K2 / K3 alone run the product-fused form of the kernel, a launch that holds a K4 group the general form: the same
-        # updates, another rounding)
-        torch.testing.assert_close(fb.msgs, single_msgs[k], rtol=1e-12, atol=1e-300)
-        torch.testing.assert_close(margs[k], single_marg[k], rtol=1e-12, atol=1e-300)
+        # (every group runs the form of the kernel its single launch took: the same bits)
+        assert torch.equal(fb.msgs, single_msgs[k]) and torch.equal(margs[k], single_marg[k])
         got = fb.msgs.cpu().numpy()
         with np.errstate(all='ignore'):
             for b in range(0, fb.B, 3):
                 _, _, want = oracle_msgs(SPECS[names[k]](), inputs[b], roots[k])
                 np.testing.assert_allclose(got[b], want, rtol=RTOL, atol=1e-300)
-    # without the K4 group the launch takes the product-fused form the single launches took: the same bits
+    # without the K4 group: one sweep launch, the same bits
     few = [0, 1, 3]
     for k in few:
         built[k][0].msgs.fill_(float('nan')); margs[k].fill_(float('nan'))

@@ -1025,7 +1025,7 @@ __device__ __forceinline__ Words16 sload16(const int32_t* p) {
 // left in LDS -- c (.) message, unnormalised: any positive per-graph scale cancels in S / Z -- so nothing is written to the message
 // buffer during the sweeps and nothing read back here; partial sums and per-graph terms live in the totals' rows (spent) and the
 // spare LDS behind them.
-template <bool DIRECT, typename Dev>
+template <bool DIRECT, int NPMAX, typename Dev>
 __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
   extern __shared__ double lds[];
   double* tiles = lds;
@@ -1044,7 +1044,7 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
   __syncthreads();
   // factors per pass -- memory form: two tiles each, one tile of partial sums; direct form: what the totals' rows and the spare LDS
   // behind them hold (per factor 256 partial sums + 48 per-graph terms)
-  const int NP = DIRECT ? min(4, (int)((d.lds_bytes - 16 - (size_t)d.n_res * TILE * sizeof(double)) / ((256 + 48) * sizeof(double)))) : min(4, (d.n_res - 1) >> 1);
+  const int NP = DIRECT ? min(NPMAX, (int)((d.lds_bytes - 16 - (size_t)d.n_res * TILE * sizeof(double)) / ((256 + 48) * sizeof(double)))) : min(NPMAX, (d.n_res - 1) >> 1);
   double* red = DIRECT ? tot : tiles + (size_t)2 * NP * TILE;    // [factor][k][row block][graph]
   double* pc = DIRECT ? tot + (size_t)NP * 256 : tot;            // [factor][graph][3] per-graph terms of a pass (the totals are spent)
   // (direct form: the uniform vector's 16 bytes at the very end of the workgroup's LDS -- the sweeps' constants lie inside `red`)
@@ -1062,19 +1062,19 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
     // load here would be one more round of memory latency in front of the rows --, then all the rows are requested
     // before the first is used.  The half's first A fragment goes out ahead of them.
     const const_i32p cs = as_const(d.gr.c_slot), rs = as_const(d.gr.r_slot), pf = as_const(d.gr.plane_flags);
-    int slots[8];                                                 // tile q = 2 * factor + side: its message slot, or -1
+    int slots[2 * NPMAX];                                                 // tile q = 2 * factor + side: its message slot, or -1
 #pragma unroll
-    for (int q = 0; q < 8; ++q) slots[q] = q < 2 * np ? ((q & 1) ? cs[p0 + (q >> 1)] : rs[p0 + (q >> 1)]) : -1;
+    for (int q = 0; q < 2 * NPMAX; ++q) slots[q] = q < 2 * np ? ((q & 1) ? cs[p0 + (q >> 1)] : rs[p0 + (q >> 1)]) : -1;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 2 * NPMAX; ++q) {
       const bool in = (unsigned)slots[q] < (unsigned)d.n_msgs;
       const int w = img[d.off_written + (in ? slots[q] >> 5 : 0)];
       if (!in || !((w >> (slots[q] & 31)) & 1)) slots[q] = -1;
     }
     // direct form: tile q's LDS tile (or -1: the uniform vector, read from the constants with stride 0)
-    int vt[8];
+    int vt[2 * NPMAX];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) vt[q] = (DIRECT && slots[q] >= 0) ? img[d.off_vftile + slots[q]] : -1;
+    for (int q = 0; q < 2 * NPMAX; ++q) vt[q] = (DIRECT && slots[q] >= 0) ? img[d.off_vftile + slots[q]] : -1;
     const int n_items = 2 * np;
     auto key = [&](int j) { const int pp = j % np; return row0[p0 + pp] * 2 + (as_const(d.gr.pair_phi)[p0 + pp] ? 1 : 0); };
     auto fetchw = [&](double (&fr)[16], int j) {
@@ -1096,10 +1096,10 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
     };
     const int j_first = next_run(0);
     if (j_first < n_items) fetchw(fr0, j_first);
-    double sv[16];
+    double sv[4 * NPMAX];
     if constexpr (!DIRECT) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {                                // row i = wave + 8 j: tile i >> 4 = j >> 1, graph wave + 8 (j & 1)
+    for (int j = 0; j < 4 * NPMAX; ++j) {                                // row i = wave + 8 j: tile i >> 4 = j >> 1, graph wave + 8 (j & 1)
       sv[j] = uniform;                                            // never updated: still uniform (LBP.py:211-216)
       if (j < 4 * np && slots[j >> 1] >= 0 && !ABL(32)) {
         const int ggc = min(g0 + wave + 8 * (j & 1), d.B - 1);
@@ -1117,7 +1117,7 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
     }
     if constexpr (!DIRECT) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < 4 * NPMAX; ++j)
       if (j < 4 * np) {
         tiles[(size_t)(j >> 1) * TILE + tile_index(lane, wave + 8 * (j & 1))] = sv[j];
       }
@@ -1129,7 +1129,7 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
       if constexpr (DIRECT) {
         int tl = -1;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) if (i == q) tl = vt[i];
+        for (int i = 0; i < 2 * NPMAX; ++i) if (i == q) tl = vt[i];
         return tl >= 0 ? reinterpret_cast<const double2*>(tiles + (size_t)tl * TILE) + lane : uni2;
       } else {
         return reinterpret_cast<const double2*>(tiles + (size_t)q * TILE) + lane;
@@ -1139,7 +1139,7 @@ __device__ __forceinline__ void shared_gradient_epilogue(Dev& d, const int wg) {
       if constexpr (DIRECT) {
         int tl = -1;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) if (i == q) tl = vt[i];
+        for (int i = 0; i < 2 * NPMAX; ++i) if (i == q) tl = vt[i];
         return tl >= 0;
       } else {
         return true;
@@ -2026,7 +2026,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
     // the gradient epilogue in front of the marginals' way out: it reads the message tiles (intact: the marginals are staged in
     // the constant products' tiles) and nothing it waits for is behind 12.6 MB of stores
     if constexpr (GRAD) {
-      if (d.gr.enabled && d.vf_direct) shared_gradient_epilogue<true>(d, wg);
+      if (d.gr.enabled && d.vf_direct) shared_gradient_epilogue<true, 4>(d, wg);
     }
     if (d.marginals && !ABL(512)) {
       const const_i32p rd = as_const(d.readout);
@@ -2051,7 +2051,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   //      pass's labels and first fragment before its messages, its label features behind them.  (The unary factors'
   //      terms do not depend on the sweeps: shared_prepare_kernel has written them, this adds to them.) ----
   STAMP_FLUSH
-  if (!(PF && d.vf_direct)) shared_gradient_epilogue<false>(d, wg);
+  if (!(PF && d.vf_direct)) shared_gradient_epilogue<false, P3 ? 6 : 4>(d, wg);      // (three-source form: 256 registers a wave, six factors -- K4 -- in one pass)
   };
   tail();
 }
@@ -2481,6 +2481,14 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   return MLBP_OK;
 }
 
+// The verdict on the launch just issued (and only on it: launch_begin() drops what an earlier runtime call of this thread -- the
+// caller's, another library's -- may have left in the thread's last-error slot), with the runtime's own words.
+inline void launch_begin() { (void)hipGetLastError(); }
+inline int launch_verdict(const char* what) {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MLBP_OK : fail(MLBP_EHIP, "%s launch failed: %s", what, hipGetErrorString(e));
+}
+
 // unary factor -> variable messages of the call, written back behind the sweeps when the caller wants the message buffer
 int enqueue_unary_writeback(const mlbp_program* prog, const mlbp_sweep_args* a, const SharedDev& d, hipStream_t st) {
   const SharedProgram& sp = prog->shared;
@@ -2489,7 +2497,7 @@ int enqueue_unary_writeback(const mlbp_program* prog, const mlbp_sweep_args* a, 
   const long long rows = (long long)a->B * E;
   hipLaunchKernelGGL(unary_writeback_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(WG), 0, st, a->unary_tables, a->unary_tab,
                      prog->d_simage + sp.off_ent, E, a->B, prog->U, a->n_unary_tables, prog->n_msgs, a->msgs);
-  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "unary write-back launch failed");
+  if (int e = launch_verdict("unary write-back")) return e;
   return MLBP_OK;
 }
 
@@ -2502,12 +2510,14 @@ int launch_shared_sweep(const mlbp_program* prog, const mlbp_sweep_args* a, void
   if (int e = shared_plan(prog, a, &ok, &pl)) return e;
   if (!ok) return MLBP_OK;
   hipStream_t st = (hipStream_t)stream;
+  launch_begin();
   hipLaunchKernelGGL(shared_prepare_kernel<false>, dim3(pl.n_prep_blocks), dim3(PWG), (size_t)pl.q.n_cprod * TILE * sizeof(double), st, pl.q, nullptr, nullptr, 0);
-  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
+  if (int e = launch_verdict("shared-table prepare")) return e;
   sweep_fn k = nullptr;
   if (int e = pick_sweep_kernel(prog->P >= 2, pl.spill, pl.wide, false, pl.d.gr.enabled != 0, pl.pf, pl.lds, &k, pl.p3)) return e;
+  launch_begin();
   hipLaunchKernelGGL(k, dim3(pl.n_wg), dim3(SWG), pl.lds, st, pl.d, nullptr, nullptr, 0);
-  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed");
+  if (int e = launch_verdict("shared-table sweep")) return e;
   if (int e = enqueue_unary_writeback(prog, a, pl.d, st)) return e;
   *launched = true;
   return MLBP_OK;
@@ -2571,8 +2581,9 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   const PrepareDev* d_pd = reinterpret_cast<const PrepareDev*>(d_stable + w_sd * n_groups);
   const int32_t* d_pstarts = d_stable + (w_sd + w_pd) * n_groups;
   const int32_t* d_sstarts = d_pstarts + n_groups + 1;
+  launch_begin();
   hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), (size_t)max_cprod * TILE * sizeof(double), st, plans[order[0]].q, d_pd, d_pstarts, n_groups);
-  if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table prepare launch failed");
+  if (int e = launch_verdict("shared-table prepare")) return e;
   for (int c = 0; c < 3; ++c) {
     const int n = first[c + 1] - first[c];
     if (n == 0) continue;
@@ -2587,8 +2598,9 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
     // tiles or has wider updates -- the spilling, wide one: pick_sweep_kernel)
     sweep_fn k = nullptr;
     if (int e = pick_sweep_kernel(two, spill, wide, true, grad, c == 0, lds, &k, c == 1)) return e;
+    launch_begin();
     hipLaunchKernelGGL(k, dim3(grid[c]), dim3(SWG), lds, st, plans[order[first[c]]].d, d_sd + first[c], d_sstarts + first[c] + c, n);
-    if (hipGetLastError() != hipSuccess) return fail(MLBP_EHIP, "shared-table sweep launch failed");
+    if (int e = launch_verdict("shared-table sweep")) return e;
   }
   for (int g = 0; g < n_groups; ++g)
     if (int e = enqueue_unary_writeback(progs[g], &args[g], plans[g].d, st)) return e;

@@ -1991,6 +1991,13 @@ int fallback_scratch(int purpose, size_t bytes, void** out) {
 int group_table_device(GroupTables& gt, const std::vector<int32_t>& table, void* stream, int32_t** out) {
   for (auto& e : gt.entries)
     if (e.words == table) { *out = e.dev; return MLBP_OK; }
+  if (getenv("MLBP_DEBUG_GROUP_TABLE")) {
+    fprintf(stderr, "group table miss: %zu words, %zu cached\n", table.size(), gt.entries.size());
+    for (auto& e : gt.entries)
+      if (e.words.size() == table.size())
+        for (size_t i = 0; i < table.size(); ++i)
+          if (e.words[i] != table[i]) { fprintf(stderr, "  first difference to a cached table at word %zu: %d vs %d\n", i, e.words[i], table[i]); break; }
+  }
   GroupTables::Entry* slot = nullptr;
   if (gt.entries.size() < (size_t)GroupTables::MAX) { gt.entries.emplace_back(); slot = &gt.entries.back(); }
   else { slot = &gt.entries[gt.next_evict]; gt.next_evict = (gt.next_evict + 1) % GroupTables::MAX; }

@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 
 KERNEL_NAMES = {2: 'sweep_x64_fused_kernel (exact)',
-                3: 'shared_prepare_kernel + sweep_x64_shared_kernel (v_mfma_f64_16x16x4_f64; product-fused form where every variable has at most two pairwise factors) + the fix-up pass: the timed region is the whole launch sequence',
+                3: 'shared_prepare_kernel + sweep_x64_shared_kernel (v_mfma_f64_16x16x4_f64; product-fused form where every variable has at most two pairwise factors, its three-source variant for K4 cliques) + the fix-up pass: the timed region is the whole launch sequence',
                 4: 'sweep_wide_kernel', 5: 'sweep_generic_kernel',
                 7: 'sweep_x64_lean_kernel (scale-free, micro-op form) + the ~5 us fix-up pass of sweep_x64_fused_kernel, timed together',
                 6: 'contract_kernel (mlbp_gemm.hip): one hand-written MFMA launch per factor->variable update over the whole batch, variable product and renormalisation fused (f64: v_mfma_f64_16x16x4_f64; f32 tables: v_mfma_f32_16x16x4_f32)'}

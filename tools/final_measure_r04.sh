@@ -2,7 +2,7 @@
 # separate PMC passes for the workloads quoted in DESIGN.md / profiles/README.md.   usage: bash tools/final_measure_r04.sh <tag> <part>
 set -e
 export TMPDIR=/tmp
-T=${1:-r04o}; PART=${2:-1}
+T=${1:-r04q}; PART=${2:-1}
 stats() {  # stats <name> <bench args...>: kernel-trace stats csv of `bench.py <args>`
   local name=$1; shift
   MLBP_BENCH_SPINUP_STEPS=${SPIN:-300} rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${T}_prof_$name -- python3 bench.py "$@" --no-cpu-baseline --no-skip-unchanged --no-train-epoch > /dev/null 2>&1

@@ -925,9 +925,7 @@ __global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, co
         // be 1 when it writes the tile out as a message)
         double inv_sum = __builtin_amdgcn_rcp(sum);
         inv_sum = __builtin_fma(__builtin_fma(-sum, inv_sum, 1.0), inv_sum, inv_sum);
-        // (a variable with three pairwise factors: the sweep kernel stores sqrt(c) (.) message, build_shared_program)
-        const double cval = ((d.sqrt_mask >> k_out) & 1) ? sqrt(cur * inv_sum) : cur * inv_sum;
-        if (!ABL(65536)) ptile_lds[(size_t)k_out * TILE + tile_index(lane, col)] = cval;
+        if (!ABL(65536)) ptile_lds[(size_t)k_out * TILE + tile_index(lane, col)] = cur * inv_sum;
         ++k_out;
       }
     };
@@ -971,7 +969,17 @@ __global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, co
   if (!ABL(16)) {
     const double2* src = reinterpret_cast<const double2*>(ptile_lds);
     double2* dst = reinterpret_cast<double2*>(d.ptiles + (size_t)block * d.n_cprod * TILE);
-    for (int i = t; i < d.n_cprod * (TILE / 2); i += PWG) dst[i] = src[i];          // (columns of graphs beyond B: whatever LDS held; never read as results)
+    if (d.sqrt_mask == 0) {
+      for (int i = t; i < d.n_cprod * (TILE / 2); i += PWG) dst[i] = src[i];        // (columns of graphs beyond B: whatever LDS held; never read as results)
+    } else {
+      // a variable with three pairwise factors: the sweep kernel stores sqrt(c) (.) message (build_shared_program, three-source
+      // product-fused form) and wants sqrt(c) here -- taken on the way out, not in the products' loop
+      for (int i = t; i < d.n_cprod * (TILE / 2); i += PWG) {
+        double2 v = src[i];
+        if ((d.sqrt_mask >> (i / (TILE / 2))) & 1) { v.x = sqrt(v.x); v.y = sqrt(v.y); }
+        dst[i] = v;
+      }
+    }
   }
   if (d.header && wave == PWG / 64 - 1 && !ABL(32768)) {
     // ... and wave 0 finishes it: the distinct tables, which factor reads which, and the partition that splits most bundles

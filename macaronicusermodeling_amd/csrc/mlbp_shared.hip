@@ -1307,12 +1307,19 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
       const int32_t* b = gb + 2 * MW * (size_t)k;
       int4 A = make_int4(b[0], b[1], b[2], b[3]), B = make_int4(b[4], b[5], b[6], b[7]);
       const int sa = 2 * ((rankmask >> ((A.x >> 16) & 15)) & 1) + ((A.x >> 1) & 1), sb = 2 * ((rankmask >> ((B.x >> 16) & 15)) & 1) + ((B.x >> 1) & 1);
-      int hA = ((A.x & 1) && !single_) ? half_of(mode, sa) : -1, hB = ((B.x & 1) && !single_) ? half_of(mode, sb) : -1;
+      int hA = ((A.x & 1) && !single_ && !P3) ? half_of(mode, sa) : -1, hB = ((B.x & 1) && !single_ && !P3) ? half_of(mode, sb) : -1;
       if (hA < 0) hA = hB >= 0 ? 1 - hB : 0;                     // a member that can run anywhere goes to the idle half
       if (hB < 0) hB = 1 - hA;
       const bool runA = (A.x & 0x7F) != 0, runB = (B.x & 0x7F) != 0;
+      if (P3) {
+        // (three-source form: every wave keeps all four fragment sets -- 256 registers a wave --, any member runs on either half and
+        // a bundle always splits; bit 7 = the member's table is the second one)
+        if (A.x & 1) A.x |= (sa >> 1) << 7;
+        if (B.x & 1) B.x |= (sb >> 1) << 7;
+      } else {
       if (A.x & 1) A.x |= index_in_half(mode, sa) << 7;
       if (B.x & 1) B.x |= index_in_half(mode, sb) << 7;
+      }
       const int4 nop4 = make_int4(0, 0, 0, 0);
       int4 s0 = nop4, s1 = nop4;
       if (!(runA && runB && hA == hB)) {
@@ -1341,11 +1348,27 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
   // orientations (partition 1 with T1 = T0), so any member runs on either half and a bundle always splits
   const bool ok = verdict == 0 && !(NTAB == 1 && d1 != d0);
   double fr0[16], fr1[16];
+  double fr2[P3 ? 16 : 1], fr3[P3 ? 16 : 1];                     // (three-source form: the second table's two orientations; fr0 / fr1: the first's)
+  if constexpr (P3) {
+    if (ok && d.tfrag && d1 != d0 && NTAB > 1) {
+      const double* F = d.tfrag + (size_t)d1 * 2 * 4096 + rb * 1024 + lane;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) { fr2[s] = F[64 * s]; fr3[s] = F[4096 + 64 * s]; }
+    } else if (ok && d1 != d0 && NTAB > 1) {
+      const double* T = d.pair_tables + (size_t)d1 * 4096;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) { fr2[s] = T[(16 * rb + gl) * 64 + 4 * s + cq]; fr3[s] = T[(4 * s + cq) * 64 + 16 * rb + gl]; }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) { fr2[s] = 0.0; fr3[s] = 0.0; }
+    }
+  }
 #pragma unroll
   for (int idx = 0; idx < 2; ++idx) {
     int sel = 0;
     for (int q = 0; q < 4; ++q)
       if (half_of(mode, q) == half && index_in_half(mode, q) == idx) sel = q;
+    if (P3) sel = idx;                                           // (first table, orientation idx)
     const int ti = (sel >> 1) ? d1 : d0, mt = sel & 1;
     double (&fr)[16] = idx ? fr1 : fr0;
     if (ok && d.tfrag) {
@@ -1632,7 +1655,7 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
     int lane = lane_;
     asm volatile("" : "+v"(lane));
     const int gl = lane & 15, cq = lane >> 4;
-    const bool mm = (flags & 1) != 0, second_set = (flags & 0x80) != 0, two = (flags & 0x100) != 0;
+    const bool mm = (flags & 1) != 0, second_table = (flags & 0x80) != 0, two = (flags & 0x100) != 0;     // (bit 7: resolved by the prologue)
     const bool want = (flags & (4 | 8)) != 0;
     const int S = (w1 >> 8) & 0xFF, S2 = w3 & 0xFF, K = (w3 >> 8) & 0xFF, ck = w2 & 0xFF;
     const double2* src = reinterpret_cast<const double2*>(tiles + (size_t)S * TILE) + lane;
@@ -1666,17 +1689,16 @@ __device__ __forceinline__ void sweep_x64_shared_body(Dev& d, const int wg) {
         }
       }
       if (mm && !ABL(1)) {
-        if (!second_set) {
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr0[4 * h], b0, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr0[4 * h + 1], b1, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr0[4 * h + 2], b2, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr0[4 * h + 3], b3, acc, 0, 0, 0);
-        } else {
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr1[4 * h], b0, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr1[4 * h + 1], b1, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr1[4 * h + 2], b2, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fr1[4 * h + 3], b3, acc, 0, 0, 0);
+#define MLBP_P3_QUARTER(FR)                                                                    \
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(FR[4 * h], b0, acc, 0, 0, 0);             \
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(FR[4 * h + 1], b1, acc, 0, 0, 0);         \
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(FR[4 * h + 2], b2, acc, 0, 0, 0);         \
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(FR[4 * h + 3], b3, acc, 0, 0, 0);
+        if constexpr (P3) {
+          if (!second_table) { if (!(flags & 2)) { MLBP_P3_QUARTER(fr0) } else { MLBP_P3_QUARTER(fr1) } }
+          else               { if (!(flags & 2)) { MLBP_P3_QUARTER(fr2) } else { MLBP_P3_QUARTER(fr3) } }
         }
+#undef MLBP_P3_QUARTER
       }
     }
     const double t0 = (ta.x + ta.y) + (tb.x + tb.y), t1 = (tc.x + tc.y) + (td.x + td.y);

@@ -22,7 +22,12 @@ def timed(fn, n=10):
 
 B, X = 8192, 64
 # --k4: four predicted words (six pairwise factors, the shared-table kernel's general instance: spilled tiles, three-source updates)
-spec = C.user_spec(10, [1, 3, 5, 8], X, 64, seed=2) if '--k4' in sys.argv else C.user_spec(10, [1, 4, 7], X, 64, seed=1)
+# --k4-adjacent / --k3-adjacent: neighbouring predicted words, so that both en_en pots (gap 1 / gap > 1) are in use and a bundle's two
+# updates may need fragment sets that one half of the workgroup holds
+if '--k4-adjacent' in sys.argv: spec = C.user_spec(10, [1, 2, 5, 6], X, 64, seed=2)
+elif '--k3-adjacent' in sys.argv: spec = C.user_spec(10, [1, 2, 7], X, 64, seed=1)
+elif '--k4' in sys.argv: spec = C.user_spec(10, [1, 3, 5, 8], X, 64, seed=2)
+else: spec = C.user_spec(10, [1, 4, 7], X, 64, seed=1)
 topo = GraphTopology.from_spec(spec)
 inputs = C.make_inputs(spec, 5)
 if '--random-planes' not in sys.argv:        # the reference's tensors: [pmi, 0, 1] and [pmi, pmi_w1, 1] (train_mp.py:600-606)
@@ -35,6 +40,7 @@ for skip in (False, True):
     tr.batch.skip_unchanged = skip
     print('shared pots:  full local_statistics %.3f ms (skip_unchanged=%s)' % (timed(tr.local_statistics), skip))
 eager = tr.local_statistics().clone()
+if '--short' in sys.argv: tr.capture(); print('shared pots:  full local_statistics as one HIP graph replay %.3f ms' % timed(tr.local_statistics)); sys.exit(0)
 tr.capture()
 print('shared pots:  full local_statistics as one HIP graph replay %.3f ms' % timed(tr.local_statistics))
 assert torch.equal(eager, tr.local_statistics()), 'graph replay differs from eager'

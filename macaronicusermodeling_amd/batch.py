@@ -77,6 +77,7 @@ def _topology_signature(topo):
             tuple(tuple(f) for f in topo.facsets))
 
 
+
 class FactorGraphBatch:
     def __init__(self, topo, X, B, device='cuda:0', normalize_messages=True, use_approx_inference=False, use_approx_beliefs=False,
                  share_programs=False):
@@ -302,17 +303,26 @@ class FactorGraphBatch:
                                                   out.data_ptr(), _stream_ptr(self.device)))
         return out
 
-    def set_features(self, phi_en_en, phi_en_en_w1, phi_en_de, pair_phi, unary_kind):
+    def set_features(self, phi_en_en, phi_en_en_w1, phi_en_de, pair_phi, unary_kind, share_with=None):
         """Feature tensors (X,X,F_ee) x2 and (X,Vde,F_ed) shared by the batch, and the per-slot
         selector FactorNode.get_phi implies (LBP.py:469-480): pair_phi[p] in {0: gap > 1, 1: gap == 1},
         unary_kind[u] in {0, 1 (en_en by gap), 2 (en_de)}."""
         dev = self.device
-        self.phi_en_en = torch.as_tensor(phi_en_en, dtype=torch.float64).to(dev).contiguous()
-        self.phi_en_en_w1 = torch.as_tensor(phi_en_en_w1, dtype=torch.float64).to(dev).contiguous()
-        self.phi_en_de = torch.as_tensor(phi_en_de, dtype=torch.float64).to(dev).contiguous()
-        # transposed copies [column][x][F] (a layout change only): contiguous feature slabs for unary factors
-        self._phi_t = tuple(p.permute(1, 0, 2).contiguous() for p in (self.phi_en_en, self.phi_en_en_w1, self.phi_en_de))
-        self._phi_p = tuple(p.permute(2, 0, 1).contiguous() for p in (self.phi_en_en, self.phi_en_en_w1))   # [F][X][X]
+        if share_with is not None:
+            # the other batch's device copies (and their two re-layouts), read-only: the buckets of a TiDirTrainer -- one batch per
+            # sentence shape, hundreds of them -- read ONE set of feature tensors, and a grouped launch writes the gradient's
+            # weighted table fragments once per distinct set (mlbp_sweep_groups_f64), not once per bucket
+            if share_with.device != dev:
+                raise ValueError('feature tensors can only be shared by batches of one device')
+            self.phi_en_en, self.phi_en_en_w1, self.phi_en_de = share_with.phi_en_en, share_with.phi_en_en_w1, share_with.phi_en_de
+            self._phi_t, self._phi_p = share_with._phi_t, share_with._phi_p
+        else:
+            self.phi_en_en = torch.as_tensor(phi_en_en, dtype=torch.float64).to(dev).contiguous()
+            self.phi_en_en_w1 = torch.as_tensor(phi_en_en_w1, dtype=torch.float64).to(dev).contiguous()
+            self.phi_en_de = torch.as_tensor(phi_en_de, dtype=torch.float64).to(dev).contiguous()
+            # transposed copies [column][x][F] (a layout change only): contiguous feature slabs for unary factors
+            self._phi_t = tuple(p.permute(1, 0, 2).contiguous() for p in (self.phi_en_en, self.phi_en_en_w1, self.phi_en_de))
+            self._phi_p = tuple(p.permute(2, 0, 1).contiguous() for p in (self.phi_en_en, self.phi_en_en_w1))   # [F][X][X]
         X = self.X
         if tuple(self.phi_en_en.shape[:2]) != (X, X) or self.phi_en_en_w1.shape != self.phi_en_en.shape or \
                 self.phi_en_de.shape[0] != X:

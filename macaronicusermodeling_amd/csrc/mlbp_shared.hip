@@ -791,49 +791,56 @@ __global__ __launch_bounds__(PWG, 8) void shared_prepare_kernel(PrepareDev d, co
   ABL_DECL
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int block = blockIdx.x, n_blocks = gridDim.x;
+  const PrepareDev launch_job = d;
   if (MULTI) {
     const int lo = find_group(gstart, n_groups, block);
     load_uniform(d, gtab + lo);
     block -= as_const(gstart)[lo];
     n_blocks = as_const(gstart)[lo + 1] - as_const(gstart)[lo];
   }
-  for (int q = block; q < (ABL(16384) ? 0 : 2 * d.n_frag_tables); q += n_blocks) {
-    const int ti = q >> 1, mt = q & 1;
-    const double* T = d.pair_tables + (size_t)ti * 4096;
-    double* o = d.tfrag + ((size_t)ti * 2 + mt) * 4096;
-    for (int e = t; e < 4096; e += PWG) {
-      const int l = e & 63, sk = (e >> 6) & 15, w = e >> 10;
-      const int i = 16 * w + (l & 15), k = 4 * sk + (l >> 4);
-      o[e] = mt ? T[k * 64 + i] : T[i * 64 + k];
+  // (MULTI: the launch's shared job first -- the by-value description, spread over ALL blocks of the launch: the groups of a
+  // minibatch read the same pots, and a table's copies are written once per launch, not once per group -- then the group's own)
+  auto fragment_jobs = [&](const PrepareDev& d, const int block, const int n_blocks) {
+    for (int q = block; q < (ABL(16384) ? 0 : 2 * d.n_frag_tables); q += n_blocks) {
+      const int ti = q >> 1, mt = q & 1;
+      const double* T = d.pair_tables + (size_t)ti * 4096;
+      double* o = d.tfrag + ((size_t)ti * 2 + mt) * 4096;
+      for (int e = t; e < 4096; e += PWG) {
+        const int l = e & 63, sk = (e >> 6) & 15, w = e >> 10;
+        const int i = 16 * w + (l & 15), k = 4 * sk + (l >> 4);
+        o[e] = mt ? T[k * 64 + i] : T[i * 64 + k];
+      }
     }
-  }
-  // the gradient epilogue's A operands (what pair_weight_fragments_kernel writes): quarter jobs (one row block each) on the
-  // blocks behind those, which start as early and so finish inside the launch's main body
-  for (int q = block - 2 * d.n_frag_tables; q < 32 * d.n_wfrag_tables; q += n_blocks) {
-    if (q < 0) continue;
-    const int ti = q >> 5, which = (q >> 4) & 1, k = (q >> 2) & 3, w = q & 3;
-    const double* T = d.pair_tables + (size_t)ti * 4096;
-    const double* ph = (which ? d.phi_p1 : d.phi_p0) + (size_t)(k < 3 ? k : 0) * 4096;
-    double* o = d.wfrag + (((size_t)ti * 2 + which) * 4 + k) * 4096 + w * 1024;
-    for (int e = t; e < 1024; e += PWG) {
-      const int l = e & 63, sk = e >> 6;
-      const int idx = (16 * w + (l & 15)) * 64 + 4 * sk + (l >> 4);
-      o[e] = k < 3 ? T[idx] * ph[idx] : T[idx];
+    // the gradient epilogue's A operands (what pair_weight_fragments_kernel writes): quarter jobs (one row block each) on the
+    // blocks behind those, which start as early and so finish inside the launch's main body
+    for (int q = block - 2 * d.n_frag_tables; q < 32 * d.n_wfrag_tables; q += n_blocks) {
+      if (q < 0) continue;
+      const int ti = q >> 5, which = (q >> 4) & 1, k = (q >> 2) & 3, w = q & 3;
+      const double* T = d.pair_tables + (size_t)ti * 4096;
+      const double* ph = (which ? d.phi_p1 : d.phi_p0) + (size_t)(k < 3 ? k : 0) * 4096;
+      double* o = d.wfrag + (((size_t)ti * 2 + which) * 4 + k) * 4096 + w * 1024;
+      for (int e = t; e < 1024; e += PWG) {
+        const int l = e & 63, sk = e >> 6;
+        const int idx = (16 * w + (l & 15)) * 64 + 4 * sk + (l >> 4);
+        o[e] = k < 3 ? T[idx] * ph[idx] : T[idx];
+      }
     }
-  }
-  // ... and which feature planes are constant: the reference's tensors are [pmi, 0, 1] and [pmi, pmi_w1, 1]
-  // (train_mp.py:600-606: a zero plane and the bias), and for those the epilogue needs no contraction -- the expected
-  // feature is 0 resp. the belief's total.  One job per plane, on the blocks behind the fragment jobs.
-  for (int q = block - 2 * d.n_frag_tables - 32 * d.n_wfrag_tables; q < (d.n_wfrag_tables > 0 ? 6 : 0); q += n_blocks) {
-    if (q < 0) continue;
-    const int which = q / 3, k = q - 3 * which;
-    const double* ph = (which ? d.phi_p1 : d.phi_p0) + (size_t)k * 4096;
-    const double c = ph[0];
-    bool same = c == 0.0 || c == 1.0;
-    for (int e = t; e < 4096 && same; e += PWG) same = ph[e] == c;
-    const int all = __syncthreads_and(same ? 1 : 0);
-    if (t == 0) d.plane_flags[which * 4 + k] = all ? (c == 0.0 ? 1 : 2) : 0;
-  }
+    // ... and which feature planes are constant: the reference's tensors are [pmi, 0, 1] and [pmi, pmi_w1, 1]
+    // (train_mp.py:600-606: a zero plane and the bias), and for those the epilogue needs no contraction -- the expected
+    // feature is 0 resp. the belief's total.  One job per plane, on the blocks behind the fragment jobs.
+    for (int q = block - 2 * d.n_frag_tables - 32 * d.n_wfrag_tables; q < (d.n_wfrag_tables > 0 ? 6 : 0); q += n_blocks) {
+      if (q < 0) continue;
+      const int which = q / 3, k = q - 3 * which;
+      const double* ph = (which ? d.phi_p1 : d.phi_p0) + (size_t)k * 4096;
+      const double c = ph[0];
+      bool same = c == 0.0 || c == 1.0;
+      for (int e = t; e < 4096 && same; e += PWG) same = ph[e] == c;
+      const int all = __syncthreads_and(same ? 1 : 0);
+      if (t == 0) d.plane_flags[which * 4 + k] = all ? (c == 0.0 ? 1 : 2) : 0;
+    }
+  };
+  if (MULTI) fragment_jobs(launch_job, (int)blockIdx.x, (int)gridDim.x);
+  fragment_jobs(d, block, n_blocks);
   // one workgroup = one group of 16 graphs, one wave per graph: a wave writes its column of the group's tiles into LDS, and the
   // workgroup stores each tile as whole cache lines (a wave's column alone is 16 bytes in each of 32 lines per tile: the
   // partial-line stores of 16 different waves into the same lines were what this launch spent most of its time on)
@@ -2571,6 +2578,33 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
     if (!ok) return MLBP_OK;
     max_cprod = std::max(max_cprod, (int)plans[k].q.n_cprod);
   }
+  // Fragment copies of the pairwise tables (and the gradient's weighted ones): written ONCE per distinct set of inputs -- the
+  // groups of a minibatch read the same pots; with one small group per sentence shape (hundreds of them) every group writing its
+  // own 640 KB was the launch: 272 us of a 0.69 ms epoch.  The first set is the launch's shared job (the kernel's by-value
+  // description, spread over all blocks); the other groups read the owner's copies.
+  PrepareDev launch_job;
+  memset(&launch_job, 0, sizeof(launch_job));
+  {
+    std::vector<int> owners;
+    for (int k = 0; k < n_groups; ++k) {
+      PrepareDev& q = plans[k].q;
+      if (q.n_frag_tables == 0 && q.n_wfrag_tables == 0) continue;
+      int own = -1;
+      for (int j : owners) {
+        const PrepareDev& o = plans[j].q;
+        if (o.pair_tables == q.pair_tables && o.n_frag_tables == q.n_frag_tables && o.n_wfrag_tables == q.n_wfrag_tables &&
+            (q.n_wfrag_tables == 0 || (o.phi_p0 == q.phi_p0 && o.phi_p1 == q.phi_p1))) { own = j; break; }
+      }
+      if (own < 0) { owners.push_back(k); continue; }
+      if (q.n_frag_tables > 0) plans[k].d.tfrag = plans[own].d.tfrag;
+      if (q.n_wfrag_tables > 0) { plans[k].d.gr.wfrag = plans[own].d.gr.wfrag; plans[k].d.gr.plane_flags = plans[own].d.gr.plane_flags; }
+      q.n_frag_tables = 0; q.n_wfrag_tables = 0;
+    }
+    if (!owners.empty()) {
+      launch_job = plans[owners[0]].q;
+      plans[owners[0]].q.n_frag_tables = 0; plans[owners[0]].q.n_wfrag_tables = 0;
+    }
+  }
   // The groups run in up to three sweep launches, one per FORM of the kernel: product-fused (K2, K3, chains, rings), its
   // three-source variant (K4), general (larger cliques, spilled tiles) -- a K3 group of a minibatch that also holds a K4 sentence
   // keeps its own, faster instance (and its gradient epilogue that reads the message tiles).  One prepare launch in front of all.
@@ -2612,7 +2646,7 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   const int32_t* d_pstarts = d_stable + (w_sd + w_pd) * n_groups;
   const int32_t* d_sstarts = d_pstarts + n_groups + 1;
   launch_begin();
-  hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), (size_t)max_cprod * TILE * sizeof(double), st, plans[order[0]].q, d_pd, d_pstarts, n_groups);
+  hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), (size_t)max_cprod * TILE * sizeof(double), st, launch_job, d_pd, d_pstarts, n_groups);
   if (int e = launch_verdict("shared-table prepare")) return e;
   for (int c = 0; c < 3; ++c) {
     const int n = first[c + 1] - first[c];

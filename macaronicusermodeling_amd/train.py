@@ -31,7 +31,7 @@ from .topology import GraphTopology
 class UserGraphTrainer:
     def __init__(self, spec, var_labels, unary_obs, phi_en_en, phi_en_en_w1, phi_en_de, theta_en_en, theta_en_de,
                  device='cuda:0', sweeps=3, roots=None, planes=None, domains=None, theta_dom_en_en=None,
-                 theta_dom_en_de=None, skip_unchanged=False, shared=None):
+                 theta_dom_en_de=None, skip_unchanged=False, shared=None, features_of=None):
         """spec: a 'trainmp'-style spec (tests/golden/cases.py: factors carry factor_type / gap);
         var_labels [B][n_vars], unary_obs [B][U]: this rank's shard of instances.
         planes: optional per-instance sparse feature planes, a list (one entry per instance) of
@@ -71,7 +71,8 @@ class UserGraphTrainer:
                 unary_kind.append(0 if f['gap'] > 1 else 1)
             else:
                 raise BaseException('only two kinds of potentials are supported...')    # LBP.py:467
-        fb.set_features(phi_en_en, phi_en_en_w1, phi_en_de, pair_phi, unary_kind)
+        # features_of: another trainer given the SAME feature tensors -- its device copies are used (the buckets of one TiDirTrainer)
+        fb.set_features(phi_en_en, phi_en_en_w1, phi_en_de, pair_phi, unary_kind, share_with=features_of.batch if features_of is not None else None)
         fb.set_observations(var_labels, unary_obs)
         self.Vde = int(fb.phi_en_de.shape[1])
         self.F_ee, self.F_ed = int(fb.phi_en_en.shape[2]), int(fb.phi_en_de.shape[2])
@@ -566,7 +567,8 @@ class _BucketSet:
                     planes.append(cells)
             self.trainers[key] = UserGraphTrainer(b['spec'], b['var_labels'], b['unary_obs'], o.phi_ee, o.phi_w1, o.phi_ed_t,
                                                   o.theta_en_en, o.theta_en_de, device=o.device, sweeps=o.sweeps, roots=roots,
-                                                  planes=planes, skip_unchanged=o.skip_unchanged, shared=True, **extra)
+                                                  planes=planes, skip_unchanged=o.skip_unchanged, shared=True,
+                                                  features_of=next(iter(self.trainers.values()), None), **extra)
         self.shared = _SharedTables(list(self.trainers.values())) if self.trainers else None
 
     def statistics_into(self, stats, grouped_sweeps, select=None):

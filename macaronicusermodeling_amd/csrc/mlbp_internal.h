@@ -166,6 +166,9 @@ struct mlbp_program {
   size_t wfrag_cap = 0;          // in BYTES (program_grow); spill_cap / ptiles_cap / stable_cap / gtable_cap likewise
   int32_t* d_header = nullptr; // the prepare launch's per-group headers for the sweep kernel [groups][8] (lazily allocated)
   size_t header_cap = 0;       // in bytes
+  // grouped launches (mlbp_sweep_groups_f64) with more than one form of the shared-table kernel: the product-fused groups' sweep
+  // launch runs on a side stream beside the others' (fork / join by events behind the prepare launch); created on first use
+  void* side_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;
   double* d_ptiles = nullptr;  // constant-product tiles of the shared-table kernel [groups][n_cprod][1024] (lazily allocated)
   size_t ptiles_cap = 0;       // in doubles
   size_t spill_cap = 0;        // in doubles

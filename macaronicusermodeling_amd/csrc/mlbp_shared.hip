@@ -2648,7 +2648,27 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   launch_begin();
   hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), (size_t)max_cprod * TILE * sizeof(double), st, launch_job, d_pd, d_pstarts, n_groups);
   if (int e = launch_verdict("shared-table prepare")) return e;
-  for (int c = 0; c < 3; ++c) {
+  // Two or more forms present: the product-fused groups' launch goes to a side stream of the owner program, forked behind the
+  // prepare launch and joined in front of whatever follows -- the launches are independent, and the three-source form (one
+  // workgroup per CU, its last round partly empty) leaves CUs the product-fused workgroups fill.  (In a captured graph: two
+  // parallel kernel nodes.)  MLBP_SHARED_GROUPS_SERIAL=1 in the environment keeps one stream.
+  static const bool serial = getenv("MLBP_SHARED_GROUPS_SERIAL") != nullptr;
+  const bool fork = !serial && first[1] > first[0] && first[3] > first[1];
+  hipStream_t side = st;
+  if (fork) {
+    if (!owner->side_stream) {
+      hipStream_t s2 = nullptr; hipEvent_t e1 = nullptr, e2 = nullptr;
+      if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess)
+        return fail(MLBP_EHIP, "side stream for grouped launches: creation failed");
+      owner->side_stream = s2; owner->ev_fork = e1; owner->ev_join = e2;
+    }
+    side = (hipStream_t)owner->side_stream;
+    if (hipEventRecord((hipEvent_t)owner->ev_fork, st) != hipSuccess || hipStreamWaitEvent(side, (hipEvent_t)owner->ev_fork, 0) != hipSuccess)
+      return fail(MLBP_EHIP, "side stream for grouped launches: fork failed");
+  }
+  for (int cc = 0; cc < 3; ++cc) {
+    const int c = fork ? (cc + 1) % 3 : cc;                      // (forked: the long launches first, the product-fused one beside them)
     const int n = first[c + 1] - first[c];
     if (n == 0) continue;
     size_t lds = 0;
@@ -2663,8 +2683,12 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
     sweep_fn k = nullptr;
     if (int e = pick_sweep_kernel(two, spill, wide, true, grad, c == 0, lds, &k, c == 1)) return e;
     launch_begin();
-    hipLaunchKernelGGL(k, dim3(grid[c]), dim3(SWG), lds, st, plans[order[first[c]]].d, d_sd + first[c], d_sstarts + first[c] + c, n);
+    hipLaunchKernelGGL(k, dim3(grid[c]), dim3(SWG), lds, (fork && c == 0) ? side : st, plans[order[first[c]]].d, d_sd + first[c], d_sstarts + first[c] + c, n);
     if (int e = launch_verdict("shared-table sweep")) return e;
+  }
+  if (fork) {
+    if (hipEventRecord((hipEvent_t)owner->ev_join, side) != hipSuccess || hipStreamWaitEvent(st, (hipEvent_t)owner->ev_join, 0) != hipSuccess)
+      return fail(MLBP_EHIP, "side stream for grouped launches: join failed");
   }
   for (int g = 0; g < n_groups; ++g)
     if (int e = enqueue_unary_writeback(progs[g], &args[g], plans[g].d, st)) return e;

@@ -1583,6 +1583,9 @@ int mlbp_program_destroy(mlbp_program* p) {
   (void)hipFree(p->d_pairseq); (void)hipFree(p->d_status);
   (void)hipFree(p->d_fops); (void)hipFree(p->d_fsweeps); (void)hipFree(p->d_fpairseq); (void)hipFree(p->d_bail); (void)hipFree(p->d_readout);
   (void)hipFree(p->d_limage); (void)hipFree(p->d_lreadout); (void)hipFree(p->d_simage); (void)hipFree(p->d_sreadout); (void)hipFree(p->d_tfrag); (void)hipFree(p->d_spill); (void)hipFree(p->d_ptiles); (void)hipFree(p->d_wfrag); (void)hipFree(p->d_header);
+  if (p->side_stream) (void)hipStreamDestroy((hipStream_t)p->side_stream);
+  if (p->ev_fork) (void)hipEventDestroy((hipEvent_t)p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy((hipEvent_t)p->ev_join);
   (void)hipFree(p->d_gfrag); (void)hipFree(p->d_gxbuf); (void)hipFree(p->d_gwork);
   for (void* q : p->retired) (void)hipFree(q);
   mlbp::group_tables_free(p->gtables); mlbp::group_tables_free(p->stables);

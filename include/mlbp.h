@@ -141,7 +141,8 @@ int mlbp_program_reserve(mlbp_program* p, int32_t max_graphs);
  * form, of them lone variable->factor updates, fused variable+pairwise updates, bundles (two updates under
  * one barrier); shared-table form: bit 0 applicable, bit 1 in its product-fused form (every variable update multiplies at
  * most one constant product and one message: the message's producer stores the product), bit 2 the fused gradient reads
- * the final variable->factor messages from that form's tiles; its resident message tiles, its updates, LDS bytes of its
+ * the final variable->factor messages from that form's tiles, bit 3 the three-source variant of that form (variables with three
+ * pairwise factors, K4 cliques: sqrt(c) (.) message stored); its resident message tiles, its updates, LDS bytes of its
  * tiles for 16 graphs }.  Same validation and error codes as mlbp_program_create. */
 int mlbp_program_plan(const int32_t* ops, int32_t n_ops, const int32_t* srcs, int32_t n_srcs,
                       const int32_t* sweeps, int32_t n_sweeps, int32_t n_msgs, int32_t P, int32_t U,
@@ -275,8 +276,12 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
  * instance, train_mp.py:257-299), tables and message buffer.  Equivalent to calling mlbp_sweep_f64 on the groups one
  * after the other, in fewer launches:
  *   - every group states MLBP_SWEEP_SHARED_PAIR_TABLES and qualifies for the shared-table kernel (X = 64, normalised and
- *     initialised messages, distinct programs): ONE prepare launch and ONE sweep launch (MLBP_KERNEL_SHARED_MFMA behind a
- *     group table: a workgroup looks its group up by block index) cover ALL groups; what follows per group is its fix-up
+ *     initialised messages, distinct programs): ONE prepare launch and one sweep launch per FORM of the kernel present
+ *     among the groups (product-fused / its three-source variant / general; MLBP_KERNEL_SHARED_MFMA behind a group table: a
+ *     workgroup looks its group up by block index) cover ALL groups -- with more than one form the product-fused launch runs on
+ *     a side stream of progs[0], forked behind the prepare launch and joined before the call returns to `stream` (a stream
+ *     capture records two parallel kernel nodes); groups that name the same tables and feature tensors share one set of
+ *     fragment copies (written once per launch, owned by the first such group's program); what follows per group is its fix-up
  *     pass over flagged graphs, its unary write-back when messages are kept, and its gradient when args[k].gradient is
  *     set -- a minibatch of mixed sentence shapes over the two shared pots (train_mp.py:220-299);
  *   - otherwise, when every group qualifies for the lean X = 64 kernel (float64 tables, normalised messages, at most 8

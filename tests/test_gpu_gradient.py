@@ -539,10 +539,10 @@ def test_tidir_trainer_sweeps_all_sentence_shapes_in_one_launch(tmp_path):
 
 
 def test_tidir_trainer_groups_with_larger_cliques_share_the_launch(tmp_path):
-    """Sentences with up to four predicted words: the K4 buckets (six pairwise factors, three-source updates, spilled tiles) share
-    ONE prepare + ONE sweep launch with the K2 / K3 buckets, gradient epilogue included -- the kernel's general instance takes
-    every group (round 3 ran such a mix group by group: no instance carried the epilogue with spilled tiles).  Same statistics
-    and the same training as per-bucket launches."""
+    """Sentences with up to four predicted words: the K4 buckets (six pairwise factors, three-source updates) share ONE prepare
+    launch with the K2 / K3 buckets and run their own sweep launch beside theirs (one launch per form of the kernel, the
+    product-fused one on a side stream; gradient epilogue included, the whole step replayed from one HIP graph).  Same
+    statistics and the same training as per-bucket launches."""
     from macaronicusermodeling_amd import tidir
     from macaronicusermodeling_amd.train import TiDirTrainer
     paths = tidir.synthesize(str(tmp_path), n_instances=36, X=64, Vde=64, sent_len=(5, 8), n_predicted=(2, 4), seed=33)

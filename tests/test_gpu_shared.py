@@ -61,7 +61,7 @@ def test_shared_table_kernel_matches_oracle(name, B):
     marg = torch.full((B, topo.n_vars, 64), float('nan'), dtype=torch.float64, device=fb.device)
     fb.msgs.fill_(float('nan'))
     prog = fb.sweep(roots, init=True, marginals=marg)
-    # user_k4 needs 21 message tiles: 16 stay in LDS, the 5 stored variable->factor messages spill to global memory
+    # user_k4: the three-source product-fused form (12 message tiles + 5 stored variable->factor messages in LDS, one workgroup per CU)
     assert _ffi.lib.mlbp_last_sweep_kernel() == KERNEL_SHARED_MFMA, _ffi.lib.mlbp_last_error()
     assert prog.status() == 0 and prog.exact_count(B) == 0
     got, gm = fb.msgs.cpu().numpy(), marg.cpu().numpy()

@@ -296,7 +296,10 @@ __global__ __launch_bounds__(WG) void gradient_x64_kernel(GradDev d) {
 }
 
 // Several groups of graphs in one launch, flagged graphs only (the fix-up behind mlbp_sweep_groups_f64's fused gradients):
-// groups[k] = the group's description, first[k] = its first block (ascending; one block per graph).
+// groups[k] = the group's description, first[k] = its first block (ascending; one block per GRADIENT_GROUPS_GB graphs: the block
+// reads their flags together and runs the per-graph body for the flagged ones -- with one block per graph a launch over a few
+// thousand graphs of a few hundred groups, nothing flagged, spent 17 us on its blocks' group searches).
+constexpr int GRADIENT_GROUPS_GB = 16;
 struct GradGroup { GradDev d; int32_t first, pad_; };
 __global__ __launch_bounds__(WG) void gradient_x64_groups_kernel(const GradGroup* groups, int n_groups) {
   int lo = 0, hi = n_groups - 1;
@@ -304,11 +307,21 @@ __global__ __launch_bounds__(WG) void gradient_x64_groups_kernel(const GradGroup
     const int mid = (lo + hi + 1) >> 1;
     if (groups[mid].first <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
-  const int g = (int)blockIdx.x - groups[lo].first;
+  const int g0 = ((int)blockIdx.x - groups[lo].first) * GRADIENT_GROUPS_GB;
   const uint8_t* only = groups[lo].d.only;
-  if (g >= groups[lo].d.a.B || !only || !only[g]) return;
+  const int B = groups[lo].d.a.B;
+  if (g0 >= B || !only) return;
+  const int lane = threadIdx.x & 63;
+  const bool mine = lane < GRADIENT_GROUPS_GB && g0 + lane < B && only[g0 + lane] != 0;
+  unsigned long long todo = __ballot(mine);                     // (the same in every wave of the block)
+  if (!todo) return;
   const GradDev d = groups[lo].d;
-  gradient_x64_body<3, 6>(d, g);
+  while (todo) {
+    const int j = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    gradient_x64_body<3, 6>(d, g0 + j);
+    __syncthreads();                                             // (the body's shared scratch, before the next graph uses it)
+  }
 }
 
 template <int FEE, int FED>
@@ -716,7 +729,7 @@ int gradient_flagged_groups(const mlbp_gradient_args* args, const uint8_t* const
     memset(&table[k], 0, sizeof(GradGroup));
     table[k].d.a = args[k]; table[k].d.status = status; table[k].d.skip_pairs = 0; table[k].d.only = flags[k];
     table[k].first = blocks;
-    blocks += args[k].B;
+    blocks += (args[k].B + GRADIENT_GROUPS_GB - 1) / GRADIENT_GROUPS_GB;
   }
   static_assert(sizeof(GradGroup) % 4 == 0, "");
   std::vector<int32_t> words(sizeof(GradGroup) / 4 * (size_t)n_groups + 1);

@@ -261,6 +261,41 @@ def gpu_train_epoch(paths, dev):
     return out
 
 
+MIXED_EPOCH_TIDIR = dict(n_instances=8192, X=64, Vde=64, sent_len=(6, 9), n_predicted=(2, 4), seed=21)
+
+
+def gpu_mixed_epoch(directory, dev):
+    """The whole-file epoch on a TI_DIR whose sentences have 2-4 predicted words (train_mp.py:257-299 builds a K2 / K3 / K4 per
+    instance): hundreds of sentence shapes of a dozen instances each, one sweep launch per form of the shared-table kernel (the
+    product-fused one beside the three-source one on a side stream).  Secondary figure, never `value`."""
+    import os as _os
+    import torch
+    from macaronicusermodeling_amd import tidir
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    sub = _os.path.join(directory, 'mixed')
+    _os.makedirs(sub, exist_ok=True)
+    paths = tidir.synthesize(sub, **MIXED_EPOCH_TIDIR)
+    t0 = time.perf_counter()
+    tt = TiDirTrainer(paths['ti'], paths['end'], paths['ded'], paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'], paths['phi_ped'],
+                      device=dev, sweeps=3)
+    build_s = time.perf_counter() - t0
+    lr, reg = 1e-6, 0.2 / tt.n_total
+    by_p = {}
+    for tr in tt.trainers.values():
+        by_p[tr.topo.P] = by_p.get(tr.topo.P, 0) + tr.batch.B
+    tt.capture()
+    tt.epoch(lr, reg)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        tt.epoch(lr, reg)
+    torch.cuda.synchronize(dev)
+    el = (time.perf_counter() - t0) / 10
+    return {'instances': tt.n_total, 'sentence_shapes': len(tt.trainers), 'instances_by_pairwise_factors': {str(k): v for k, v in sorted(by_p.items())},
+            'trainer_build_s': build_s, 'ms_per_epoch': el * 1e3, 'instances_per_s': tt.n_total / el, 'updates_per_epoch': 1,
+            'contents': 'TiDirTrainer.epoch over the whole file, one HIP-graph replay per epoch; sentences with 2-4 predicted words'}
+
+
 # ---------------------------------------------------------------------------------------------------
 # CPU baseline (oracle = port of the reference's cost model).  Runs BEFORE any GPU initialisation.
 # ---------------------------------------------------------------------------------------------------
@@ -738,6 +773,10 @@ def main():
         if epoch_paths is not None:
             te = gpu_train_epoch(epoch_paths, dev)
             te['cpu_per_instance_cost_model'] = epoch_cpu
+            try:
+                te['mixed_shapes'] = gpu_mixed_epoch(epoch_dir, dev)
+            except Exception as e:      # noqa: BLE001  (a secondary figure never takes the line down)
+                te['mixed_shapes'] = {'error': repr(e)}
             out['train_epoch'] = te
             import shutil
             shutil.rmtree(epoch_dir, ignore_errors=True)

@@ -2436,7 +2436,11 @@ int shared_plan(const mlbp_program* prog, const mlbp_sweep_args* a, bool* ok, Sh
   const bool p3 = allow_p3 && sp.p3_ok && lds3 <= 160 * 1024 && n_cprod >= 1 && n_cprod <= 8 && prog->n_vars <= 8 &&
                   (!a->marginals || (prog->sreadout_all_based && prog->sreadout_all_tiled));
   if (p3) { n_res = sp.n_lds; lds = lds3; }
-  if (n_res < 1 || (!p3 && sp.n_live - n_res > 16) || lds > 160 * 1024)   // too much would spill: the per-graph kernels do better
+  // (K5 / K6 cliques -- 27 and 41 spilled tiles -- still run 4-5 x faster here than on the per-graph kernels, which re-read the
+  // shared tables per graph: 0.41 against 1.82 ms and 0.79 against 3.74 ms per trainer step of 8192 instances; the limit used to
+  // be 16 spilled tiles, a figure from the time the comparison was with per-graph TABLES)
+  constexpr int MAX_SPILLED_TILES = 96;
+  if (n_res < 1 || (!p3 && sp.n_live - n_res > MAX_SPILLED_TILES) || lds > 160 * 1024)
     return fail(MLBP_OK, "shared-table kernel not used: %d live message tiles, %d fit LDS", sp.n_live, n_res);
   if (n_cprod < 1 || n_cprod > 8) return fail(MLBP_OK, "shared-table kernel not used: %d constant products (1..8)", n_cprod);
   mlbp_program* mp = const_cast<mlbp_program*>(prog);

@@ -136,7 +136,7 @@ def _oracle_step(spec, inputs, labels, obs, roots, lr, reg):
     return tot_ee, tot_ed, lp
 
 
-@pytest.mark.parametrize('planes', ['random', 'reference', 'k4'])
+@pytest.mark.parametrize('planes', ['random', 'reference', 'k4', 'k5'])
 @pytest.mark.parametrize('B', [6, 53])
 def test_shared_table_sweep_runs_the_gradient_as_its_epilogue(B, planes):
     """Shared pots, K3 user graphs: the gradient of sweep(gradient=...) comes out of the shared-table sweep kernel itself (the
@@ -146,12 +146,13 @@ def test_shared_table_sweep_runs_the_gradient_as_its_epilogue(B, planes):
     zero plane and the bias plane of the reference's tensors, which the epilogue recognises and does not contract.
     'k4': four predicted words (train_mp.py:272-282 builds the complete graph over them: 6 pairwise factors, three-source
     variable updates, 13 of 21 message tiles spilled) -- the same epilogue in the kernel's general instance; a flagged graph
-    gets its gradient from the per-graph kernel run on the flagged graphs only."""
+    gets its gradient from the per-graph kernel run on the flagged graphs only.  'k5': ten pairwise factors, four-source updates,
+    most of the message tiles in memory -- the general instance again (the per-graph kernels are 4 x slower on shared tables)."""
     import copy
     from macaronicusermodeling_amd import _ffi
     from macaronicusermodeling_amd.train import UserGraphTrainer
     from macaronicusermodeling_amd.topology import GraphTopology
-    pred = {'random': [1, 4, 7], 'reference': [1, 2, 7], 'k4': [1, 2, 5, 8]}[planes]
+    pred = {'random': [1, 4, 7], 'reference': [1, 2, 7], 'k4': [1, 2, 5, 8], 'k5': [0, 1, 4, 6, 9]}[planes]
     spec = C.user_spec(10, pred, 64, 48, seed=1)     # ('reference', 'k4': both pots in use)
     topo = GraphTopology.from_spec(spec)
     inputs = C.make_inputs(spec, 77)

@@ -47,6 +47,8 @@ SPECS = {
     'user_k2': lambda: C.user_spec(6, [0, 1], 64, 64, seed=3),
     'user_k4': lambda: C.user_spec(9, [0, 2, 3, 7], 64, 64, seed=4),
     'user_k4_both_pots': lambda: C.user_spec(9, [0, 1, 3, 4], 64, 64, seed=5),   # two adjacent pairs: both en_en pots, every orientation
+    'user_k5': lambda: C.user_spec(9, [0, 2, 3, 5, 8], 64, 64, seed=6),          # ten pairwise factors: the general form, most tiles in memory
+    'user_k6': lambda: C.user_spec(8, [0, 1, 3, 4, 6, 7], 64, 64, seed=7),       # fifteen
 }
 
 
@@ -449,13 +451,13 @@ def test_large_state_shared_float32_tables_on_the_f32_matrix_cores(X):
 
 
 def test_groups_of_mixed_shapes_in_one_shared_launch_sequence():
-    """mlbp_sweep_groups_f64 over four topologies (K2, two K3, K4 -- the last one has three-source updates), each with its
+    """mlbp_sweep_groups_f64 over five topologies (K2, two K3, K4 -- three-source updates --, K5 -- the general form), each with its
     own roots, batch size (partial last groups of 16) and tables: ONE prepare launch and one sweep launch PER FORM of the
-    shared-table kernel (product-fused: K2, K3; its three-source variant: K4) behind a group table.  Same bits as the four
+    shared-table kernel (product-fused: K2, K3; its three-source variant: K4; general: K5) behind a group table.  Same bits as the five
     single launch sequences, the oracle's values, a degenerate graph of one group redone by the exact kernel."""
     from macaronicusermodeling_amd import _ffi
     from macaronicusermodeling_amd.batch import sweep_groups
-    names, sizes = ['user_k2', 'user_k3_gaps_1_2_3', 'user_k4', 'user_k3_gaps_3_6'], [5, 37, 18, 16]
+    names, sizes = ['user_k2', 'user_k3_gaps_1_2_3', 'user_k4', 'user_k3_gaps_3_6', 'user_k5'], [5, 37, 18, 16, 21]      # (K5: the general form, a third launch)
 
     def mutate(inputs):
         inputs[3]['pot_en_de'] = inputs[3]['pot_en_de'].copy(); inputs[3]['pot_en_de'][:, :] = 0.0
@@ -471,7 +473,7 @@ def test_groups_of_mixed_shapes_in_one_shared_launch_sequence():
     margs = [torch.full_like(m, float('nan')) for m in single_marg]
     progs = sweep_groups([fb for fb, _, _ in built], roots, init=True, marginals=margs)
     assert _ffi.lib.mlbp_last_sweep_kernel() == KERNEL_SHARED_MFMA, _ffi.lib.mlbp_last_error()
-    assert [p.exact_count(B) for p, B in zip(progs, sizes)] == [0, 1, 0, 0]
+    assert [p.exact_count(B) for p, B in zip(progs, sizes)] == [0, 1, 0, 0, 0]
     for k, (fb, topo, inputs) in enumerate(built):
         # (every group runs the form of the kernel its single launch took: the same bits)
         assert torch.equal(fb.msgs, single_msgs[k]) and torch.equal(margs[k], single_marg[k])

@@ -24,7 +24,9 @@ B, X = 8192, 64
 # --k4: four predicted words (six pairwise factors, the shared-table kernel's general instance: spilled tiles, three-source updates)
 # --k4-adjacent / --k3-adjacent: neighbouring predicted words, so that both en_en pots (gap 1 / gap > 1) are in use and a bundle's two
 # updates may need fragment sets that one half of the workgroup holds
-if '--k5' in sys.argv: spec = C.user_spec(10, [1, 3, 5, 7, 9], X, 64, seed=2)
+if '--k1' in sys.argv: spec = C.user_spec(10, [4], X, 64, seed=2)
+elif '--k2' in sys.argv: spec = C.user_spec(10, [2, 6], X, 64, seed=2)
+elif '--k5' in sys.argv: spec = C.user_spec(10, [1, 3, 5, 7, 9], X, 64, seed=2)
 elif '--k6' in sys.argv: spec = C.user_spec(10, [0, 2, 4, 5, 7, 9], X, 64, seed=2)
 elif '--k4-adjacent' in sys.argv: spec = C.user_spec(10, [1, 2, 5, 6], X, 64, seed=2)
 elif '--k3-adjacent' in sys.argv: spec = C.user_spec(10, [1, 2, 7], X, 64, seed=1)

@@ -281,7 +281,8 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
  *     workgroup looks its group up by block index) cover ALL groups -- with more than one form the product-fused launch runs on
  *     a side stream of progs[0], forked behind the prepare launch and joined before the call returns to `stream` (a stream
  *     capture records two parallel kernel nodes); groups that name the same tables and feature tensors share one set of
- *     fragment copies (written once per launch, owned by the first such group's program); what follows per group is its fix-up
+ *     fragment copies (written once per launch, owned by the first such group's program); a group WITHOUT pairwise factors (one
+ *     predicted word) may be among them: all its graphs are flagged and redone by the fix-up launch; what follows per group is its fix-up
  *     pass over flagged graphs, its unary write-back when messages are kept, and its gradient when args[k].gradient is
  *     set -- a minibatch of mixed sentence shapes over the two shared pots (train_mp.py:220-299);
  *   - otherwise, when every group qualifies for the lean X = 64 kernel (float64 tables, normalised messages, at most 8

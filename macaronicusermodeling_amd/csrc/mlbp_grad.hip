@@ -300,19 +300,20 @@ __global__ __launch_bounds__(WG) void gradient_x64_kernel(GradDev d) {
 // reads their flags together and runs the per-graph body for the flagged ones -- with one block per graph a launch over a few
 // thousand graphs of a few hundred groups, nothing flagged, spent 17 us on its blocks' group searches).
 constexpr int GRADIENT_GROUPS_GB = 16;
-struct GradGroup { GradDev d; int32_t first, pad_; };
+struct GradGroup { GradDev d; int32_t first, per_block; };      // per_block: graphs a block looks at (GRADIENT_GROUPS_GB; 1 for a group that is flagged as a whole)
 __global__ __launch_bounds__(WG) void gradient_x64_groups_kernel(const GradGroup* groups, int n_groups) {
   int lo = 0, hi = n_groups - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
     if (groups[mid].first <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
-  const int g0 = ((int)blockIdx.x - groups[lo].first) * GRADIENT_GROUPS_GB;
+  const int per = groups[lo].per_block;
+  const int g0 = ((int)blockIdx.x - groups[lo].first) * per;
   const uint8_t* only = groups[lo].d.only;
   const int B = groups[lo].d.a.B;
   if (g0 >= B || !only) return;
   const int lane = threadIdx.x & 63;
-  const bool mine = lane < GRADIENT_GROUPS_GB && g0 + lane < B && only[g0 + lane] != 0;
+  const bool mine = lane < per && g0 + lane < B && only[g0 + lane] != 0;
   unsigned long long todo = __ballot(mine);                     // (the same in every wave of the block)
   if (!todo) return;
   const GradDev d = groups[lo].d;
@@ -729,7 +730,8 @@ int gradient_flagged_groups(const mlbp_gradient_args* args, const uint8_t* const
     memset(&table[k], 0, sizeof(GradGroup));
     table[k].d.a = args[k]; table[k].d.status = status; table[k].d.skip_pairs = 0; table[k].d.only = flags[k];
     table[k].first = blocks;
-    blocks += (args[k].B + GRADIENT_GROUPS_GB - 1) / GRADIENT_GROUPS_GB;
+    table[k].per_block = args[k].P == 0 ? 1 : GRADIENT_GROUPS_GB;      // (no pairwise factor: the group is flagged as a whole, mlbp_sweep_groups_f64)
+    blocks += (args[k].B + table[k].per_block - 1) / table[k].per_block;
   }
   static_assert(sizeof(GradGroup) % 4 == 0, "");
   std::vector<int32_t> words(sizeof(GradGroup) / 4 * (size_t)n_groups + 1);

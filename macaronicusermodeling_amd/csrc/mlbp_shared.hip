@@ -2572,16 +2572,34 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   *launched = false;
   if (n_groups < 1) return MLBP_OK;
   std::vector<SharedPlan> plans(n_groups);
-  int max_cprod = 1;
+  int max_cprod = 1, n_planned = 0;
   for (int k = 0; k < n_groups; ++k) {
     if (!progs[k]) return MLBP_OK;
     for (int j = 0; j < k; ++j)
       if (progs[j] == progs[k]) return MLBP_OK;      // two groups would share one set of redo flags and scratch
+    if (progs[k]->P == 0) {
+      // a sentence shape with ONE predicted word: no pairwise factor, nothing for the matrix cores.  Every graph of such a group is
+      // handed to the fix-up pass of the call (the exact kernel over all groups' flagged graphs, and the flagged graphs' gradient:
+      // finish_shared_groups) -- its launches are shared with every other group instead of two launches per such shape
+      const mlbp_sweep_args* a = &args[k];
+      if (a->X != 64 || !a->normalize_messages || !a->init_messages) return MLBP_OK;
+      memset(&plans[k], 0, sizeof(plans[k]));
+      continue;
+    }
     bool ok = false;
     if (int e = shared_plan(progs[k], &args[k], &ok, &plans[k])) return e;
     if (!ok) return MLBP_OK;
+    ++n_planned;
     max_cprod = std::max(max_cprod, (int)plans[k].q.n_cprod);
   }
+  if (n_planned == 0) return MLBP_OK;                            // (nothing for these kernels: the per-group path)
+  for (int k = 0; k < n_groups; ++k)
+    if (progs[k]->P == 0) {
+      mlbp_program* mp = const_cast<mlbp_program*>(progs[k]);
+      if (mp->bail_cap < args[k].B)
+        if (int e = mlbp_program_reserve(mp, args[k].B)) return e;
+      if (hipMemsetAsync(mp->d_bail, 1, (size_t)args[k].B, (hipStream_t)stream) != hipSuccess) return fail(MLBP_EHIP, "flagging a pairwise-free group failed");
+    }
   // Fragment copies of the pairwise tables (and the gradient's weighted ones): written ONCE per distinct set of inputs -- the
   // groups of a minibatch read the same pots; with one small group per sentence shape (hundreds of them) every group writing its
   // own 640 KB was the launch: 272 us of a 0.69 ms epoch.  The first set is the launch's shared job (the kernel's by-value
@@ -2614,27 +2632,28 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   // keeps its own, faster instance (and its gradient epilogue that reads the message tiles).  One prepare launch in front of all.
   // table image: [SharedDev x n][PrepareDev x n][prepare starts n + 1][sweep starts of class 0 | 1 | 2, each (its groups) + 1], as 32-bit
   // words; the groups in class order
-  auto cls = [&](int k) { return plans[k].pf ? 0 : (plans[k].p3 ? 1 : 2); };
+  auto cls = [&](int k) { return progs[k]->P == 0 ? 3 : (plans[k].pf ? 0 : (plans[k].p3 ? 1 : 2)); };      // (3: not in these launches)
   std::vector<int> order;
   int first[4] = {0, 0, 0, 0};
   for (int c = 0; c < 3; ++c) {
     first[c] = (int)order.size();
     for (int k = 0; k < n_groups; ++k) if (cls(k) == c) order.push_back(k);
   }
-  first[3] = n_groups;
+  first[3] = (int)order.size();
+  const int n_tab = (int)order.size();                           // groups in the table (the pairwise-free ones are not)
   const size_t w_sd = sizeof(SharedDev) / 4, w_pd = sizeof(PrepareDev) / 4;
   static_assert(sizeof(SharedDev) % 8 == 0 && sizeof(PrepareDev) % 8 == 0, "group tables are copied as words");
-  std::vector<int32_t> table((w_sd + w_pd) * n_groups + (n_groups + 1) + (n_groups + 3));
-  int32_t* pstarts = table.data() + (w_sd + w_pd) * n_groups;
-  int32_t* sstarts = pstarts + n_groups + 1;                     // class c: sstarts[first[c] + c .. first[c + 1] + c]
+  std::vector<int32_t> table((w_sd + w_pd) * n_tab + (n_tab + 1) + (n_tab + 3));
+  int32_t* pstarts = table.data() + (w_sd + w_pd) * n_tab;
+  int32_t* sstarts = pstarts + n_tab + 1;                     // class c: sstarts[first[c] + c .. first[c + 1] + c]
   int pb = 0, grid[3] = {0, 0, 0};
-  for (int j = 0; j < n_groups; ++j) {
+  for (int j = 0; j < n_tab; ++j) {
     const int k = order[j];
     memcpy(table.data() + w_sd * j, &plans[k].d, sizeof(SharedDev));
-    memcpy(table.data() + w_sd * n_groups + w_pd * j, &plans[k].q, sizeof(PrepareDev));
+    memcpy(table.data() + w_sd * n_tab + w_pd * j, &plans[k].q, sizeof(PrepareDev));
     pstarts[j] = pb; pb += plans[k].n_prep_blocks;
   }
-  pstarts[n_groups] = pb;
+  pstarts[n_tab] = pb;
   for (int c = 0; c < 3; ++c) {
     int wg = 0;
     for (int j = first[c]; j < first[c + 1]; ++j) { sstarts[j + c] = wg; wg += plans[order[j]].n_wg; }
@@ -2646,11 +2665,11 @@ int launch_shared_groups(const mlbp_program* const* progs, const mlbp_sweep_args
   int32_t* d_stable = nullptr;               // one device copy per distinct table: a captured graph keeps replaying against its own
   if (int e = group_table_device(owner->stables, table, stream, &d_stable)) return e;
   const SharedDev* d_sd = reinterpret_cast<const SharedDev*>(d_stable);
-  const PrepareDev* d_pd = reinterpret_cast<const PrepareDev*>(d_stable + w_sd * n_groups);
-  const int32_t* d_pstarts = d_stable + (w_sd + w_pd) * n_groups;
-  const int32_t* d_sstarts = d_pstarts + n_groups + 1;
+  const PrepareDev* d_pd = reinterpret_cast<const PrepareDev*>(d_stable + w_sd * n_tab);
+  const int32_t* d_pstarts = d_stable + (w_sd + w_pd) * n_tab;
+  const int32_t* d_sstarts = d_pstarts + n_tab + 1;
   launch_begin();
-  hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), (size_t)max_cprod * TILE * sizeof(double), st, launch_job, d_pd, d_pstarts, n_groups);
+  hipLaunchKernelGGL(shared_prepare_kernel<true>, dim3(pb), dim3(PWG), (size_t)max_cprod * TILE * sizeof(double), st, launch_job, d_pd, d_pstarts, n_tab);
   if (int e = launch_verdict("shared-table prepare")) return e;
   // Two or more forms present: the product-fused groups' launch goes to a side stream of the owner program, forked behind the
   // prepare launch and joined in front of whatever follows -- the launches are independent, and the three-source form (one

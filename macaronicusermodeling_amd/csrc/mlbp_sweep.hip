@@ -595,7 +595,7 @@ __device__ __forceinline__ void sweep_x64_fused_body(const SweepDev& d, const Fu
     for (int i = t; i < d.n_msgs * 32; i += WG) dst[i] = src[i];
   }
   if (NORM) marginals_from_lds_x64(d, msg, g, wave, lane);
-  if (GRAD && NT > 0) gradient_epilogue_x64<(NT > 0 ? NT : 1)>(d, gf, tab, msg, umsg, upos, red, g);
+  if (GRAD) gradient_epilogue_x64<(NT > 0 ? NT : 1)>(d, gf, tab, msg, umsg, upos, red, g);       // (NT = 0 with GRAD: no pairwise factor at all -- a single predicted word --, the unary terms only: every pairwise step of the epilogue is behind p < d.P)
 }
 
 // Log-posteriors of the block's 64 graphs from the marginals in memory (the fast kernel's, or the ones this workgroup has just
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(WG, (NT >= 4 ? 2 : (NT == 3 ? 3 : 4))) void sweep_x
 // minibatch of mixed sentence shapes used to pay one near-empty launch per shape).  groups[k]: the group's descriptions as a
 // single-group fix-up launch would get them, and its first workgroup; tables are streamed (NT = 0: any number of pairwise
 // factors), the gradient of a redone graph comes from gradient_x64_kernel's flagged-only mode (mlbp_grad.hip).
-struct FixupGroup { SweepDev d; FusedDev f; int32_t first_block, pad_; };
+struct FixupGroup { SweepDev d; FusedDev f; int32_t first_block, per_wg; };      // per_wg: graphs a workgroup looks at (64; 1 for a group that is redone as a whole)
 __global__ __launch_bounds__(WG, 4) void sweep_x64_fixup_groups_kernel(const FixupGroup* groups, int n_groups) {
   int lo = 0, hi = n_groups - 1;
   while (lo < hi) {
@@ -703,9 +703,9 @@ __global__ __launch_bounds__(WG, 4) void sweep_x64_fixup_groups_kernel(const Fix
     if (groups[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const FixupGroup& G = groups[lo];
-  const int base = ((int)blockIdx.x - G.first_block) * FIXUP_GRAPHS_PER_WG;
+  const int base = ((int)blockIdx.x - G.first_block) * G.per_wg;
   const int mine = base + (threadIdx.x & 63);
-  unsigned long long todo = __ballot(mine < G.f.n_graphs && G.f.only[mine] != 0);
+  unsigned long long todo = __ballot((int)(threadIdx.x & 63) < G.per_wg && mine < G.f.n_graphs && G.f.only[mine] != 0);
   if (!todo) return;
   const SweepDev d = G.d;
   const FusedDev f = G.f;
@@ -1310,7 +1310,10 @@ bool exact_kernel_fuses_gradient(const mlbp_program* prog, const mlbp_sweep_args
   const mlbp_gradient_args* ga = a->gradient;
   if (!ga || a->X != 64 || !a->normalize_messages) return false;
   if (ga->B != a->B || ga->X != a->X || ga->P != prog->P || ga->U != prog->U || ga->n_msgs != prog->n_msgs || ga->msgs != a->msgs) return false;
-  return ga->F_ee == 3 && ga->F_ed == 6 && prog->P >= 1 && prog->P <= 3 && prog->n_hoist == prog->U && prog->U <= WG &&
+  // (P = 0: a single predicted word, unary terms only -- fused for small batches, where the second launch is what costs: at 8192
+  // graphs the per-graph gradient kernel behind the sweeps is the faster pair, 0.106 against 0.131 ms per trainer step)
+  if (prog->P == 0 && a->B > 1024) return false;
+  return ga->F_ee == 3 && ga->F_ed == 6 && prog->P >= 0 && prog->P <= 3 && prog->n_hoist == prog->U && prog->U <= WG &&
          ga->phi_en_en_t && ga->phi_en_en_w1_t && ga->phi_en_de_t && !(ga->flags & MLBP_GRADIENT_APPROX_BELIEFS);
 }
 }  // namespace mlbp
@@ -1733,7 +1736,7 @@ int mlbp_sweep_f64(const mlbp_program* prog, const mlbp_sweep_args* a, void* str
         case 1: MLBP_PICK(1); break;
         case 2: MLBP_PICK(2); break;
         case 3: MLBP_PICK(3); break;
-        default: k = norm ? sweep_x64_fused_kernel<true, 0, false> : sweep_x64_fused_kernel<false, 0, false>; break;
+        default: MLBP_PICK(0); break;
       }
 #undef MLBP_PICK
       if (int e = ensure_dynamic_lds((const void*)k, lds)) return e;
@@ -1871,7 +1874,9 @@ static int finish_shared_groups(const mlbp_program* const* progs, const mlbp_swe
     const size_t lds = ((size_t)(prog->n_msgs + n_ext) * 64 + 64 + 512) * sizeof(double) + (img_words + prog->P + 6 * prog->U + 8) * sizeof(int32_t);
     if (lds > LDS_MAX) return MLBP_OK;
     lds_max = std::max(lds_max, lds);
-    if (a->gradient && !mlbp::shared_gradient_fused(prog, a)) return MLBP_OK;
+    // (a group without pairwise factors -- one predicted word -- never ran the shared-table kernels: launch_shared_groups flagged
+    // all of its graphs, so this pass and the flagged graphs' gradient below ARE its sweep call)
+    if (a->gradient && prog->P > 0 && !mlbp::shared_gradient_fused(prog, a)) return MLBP_OK;
     mlbp_program* mp = const_cast<mlbp_program*>(prog);
     FixupGroup& G = table[k];
     memset(&G, 0, sizeof(G));
@@ -1887,7 +1892,8 @@ static int finish_shared_groups(const mlbp_program* const* progs, const mlbp_swe
     f.n_fops = prog->n_fops; f.n_psrcs = prog->n_psrcs; f.n_hoist = prog->n_hoist; f.n_cprod = prog->n_cprod; f.n_cpw = prog->n_cpw;
     f.n_ext = n_ext; f.init = a->init_messages; f.n_graphs = a->B;
     G.first_block = blocks;
-    blocks += (a->B + FIXUP_GRAPHS_PER_WG - 1) / FIXUP_GRAPHS_PER_WG;
+    G.per_wg = prog->P == 0 ? 1 : FIXUP_GRAPHS_PER_WG;          // (a pairwise-free group is all flagged: one workgroup per graph, not 64 graphs in a row)
+    blocks += (a->B + G.per_wg - 1) / G.per_wg;
     if (a->gradient) { any_grad = true; grads.push_back(*a->gradient); grad_flags.push_back(mp->d_bail); }
   }
   if (any_grad && (int)grads.size() != n_groups) return MLBP_OK;        // (all groups or none carry a gradient)

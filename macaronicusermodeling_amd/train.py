@@ -585,6 +585,11 @@ class _BucketSet:
         together = [tr for tr in trs if tr.topo.P >= 1 and tr.batch.X == 64] if grouped_sweeps else []
         if len(together) < 2 and grouped_sweeps is not True:
             together = []
+        if together:
+            # shapes with ONE predicted word (no pairwise factor) join the call: the library hands all their graphs to the launches
+            # it runs behind the matrix-core kernels anyway (the exact kernel over flagged graphs, their gradient) -- two launches
+            # per such shape otherwise
+            together = [tr for tr in trs if any(tr is t for t in together) or (tr.topo.P == 0 and tr.batch.X == 64)]
         for tr in trs:
             if not any(tr is t for t in together):
                 tr._sweep_with_gradient()

@@ -1162,3 +1162,74 @@ def test_tune_set_is_evaluated_after_every_epoch(tmp_path):
     t2 = _trainer(paths, gold)
     t2.train(epochs=1, reg_param=0.2, tune=paths['ti'], capture=False)
     np.testing.assert_allclose(t2.tune_history[0][0], tt.tune_history[0][0], rtol=1e-9)
+
+
+def test_single_predicted_word_takes_its_gradient_in_the_sweep_launch():
+    """A sentence with ONE predicted word has no pairwise factor (train_mp.py:257-299: the complete graph over one variable): the
+    exact X = 64 kernel computes its marginal and -- fused -- its gradient, unary terms only, in one launch (it used to be two: the
+    sweep launch and the per-graph gradient kernel).  Against the standalone gradient kernel and the oracle."""
+    import copy
+    from macaronicusermodeling_amd import _ffi
+    from macaronicusermodeling_amd.train import UserGraphTrainer
+    from macaronicusermodeling_amd.topology import GraphTopology
+    spec = C.user_spec(9, [4], 64, 48, seed=3)
+    topo = GraphTopology.from_spec(spec)
+    assert topo.P == 0
+    inputs = C.reference_planes(C.make_inputs(spec, 41))
+    B = 45
+    labels, obs = _instances(spec, topo, B, 9)
+    tr = UserGraphTrainer(spec, labels, obs, inputs['phi_en_en'], inputs['phi_en_en_w1'], inputs['phi_en_de'],
+                          inputs['theta_en_en'], inputs['theta_en_de'])
+    fb = tr.batch
+    tr.build_potentials()
+    roots = tr.roots[:tr.n_sweeps_run]
+    g_ee, g_ed = torch.full_like(tr._g_ee, float('nan')), torch.full_like(tr._g_ed, float('nan'))
+    fb.sweep(roots, init=True, marginals=tr._marg, gradient=(g_ee, g_ed), keep_messages=False)
+    assert _ffi.lib.mlbp_last_sweep_fused_gradient() == 1
+    marg = tr._marg.clone()
+    fb.sweep(roots, init=True, marginals=tr._marg)
+    assert _ffi.lib.mlbp_last_sweep_fused_gradient() == 0
+    assert torch.equal(marg, tr._marg)
+    h_ee, h_ed = fb.gradient()
+    np.testing.assert_allclose(g_ee.cpu().numpy(), h_ee.cpu().numpy(), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(g_ed.cpu().numpy(), h_ed.cpu().numpy(), rtol=1e-12, atol=1e-13)
+    for b in range(0, B, 11):
+        s = copy.deepcopy(spec)
+        g0 = O.Graph(s)
+        s['labels'] = [int(labels[b, g0.var_order.index(v)]) for v in s['var_ids']]
+        unary_ids = [f['id'] for f in g0.factors if len(f['vars']) == 1]
+        for f in s['factors']:
+            f['observed_dim'] = int(obs[b, unary_ids.index(f['id'])])
+        g = O.Graph(s)
+        msgs = O.init_messages(g)
+        O.treelike_inference(g, inputs, msgs, len(roots), list(roots), O.has_loops(g, roots[0]))
+        ee, ed = O.unregularized_gradient(g, inputs, msgs)
+        np.testing.assert_allclose(g_ee[b].cpu().numpy(), ee.reshape(-1), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(g_ed[b].cpu().numpy(), ed.reshape(-1), rtol=1e-9, atol=1e-12)
+
+
+def test_tidir_trainer_groups_take_single_word_sentences_along(tmp_path):
+    """Sentences with ONE predicted word (no pairwise factor) ride on the grouped call of the other shapes: the library flags all
+    their graphs, and the exact kernel's pass over every group's flagged graphs and the flagged graphs' gradient -- launches the
+    call makes anyway -- do their work.  Same statistics and the same training as per-bucket launches (replayed from HIP graphs)."""
+    from macaronicusermodeling_amd import _ffi, tidir
+    from macaronicusermodeling_amd.train import TiDirTrainer
+    paths = tidir.synthesize(str(tmp_path), n_instances=48, X=64, Vde=64, sent_len=(4, 7), n_predicted=(1, 3), seed=52)
+    mk = lambda grouped: TiDirTrainer(paths['ti'], paths['end'], paths['ded'], paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'],
+                                      paths['phi_ped'], sweeps=3, grouped_sweeps=grouped)
+    a, b = mk(True), mk(False)
+    ps = {tr.topo.P for tr in a._full.trainers.values()}
+    assert 0 in ps and ps & {1, 3}
+    for t in (a, b):
+        t.theta_en_en += torch.tensor([0.3, -0.2, 0.1], dtype=torch.float64, device=t.theta_en_en.device)
+        t.theta_en_de += torch.tensor([0.2, 0.1, -0.3, 0.05, 0.0, 0.1], dtype=torch.float64, device=t.theta_en_de.device)
+    sa = a.local_statistics().cpu().numpy()
+    assert _ffi.lib.mlbp_last_sweep_kernel() == 3 and _ffi.lib.mlbp_last_sweep_fused_gradient() == 1
+    np.testing.assert_allclose(sa, b.local_statistics().cpu().numpy(), rtol=1e-9, atol=1e-12)
+    ha, hb = a.train(epochs=3, reg_param=0.2), b.train(epochs=3, reg_param=0.2)
+    np.testing.assert_allclose(ha, hb, rtol=1e-9)
+    np.testing.assert_allclose(a.theta_en_en.cpu().numpy(), b.theta_en_en.cpu().numpy(), rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(a.theta_en_de.cpu().numpy(), b.theta_en_de.cpu().numpy(), rtol=1e-8, atol=1e-12)
+    # predictions (marginals of every shape) agree as well
+    pa, pb = a.predict(), b.predict()
+    np.testing.assert_allclose(pa[0], pb[0], rtol=1e-9)

@@ -9,7 +9,8 @@ from macaronicusermodeling_amd import tidir
 from macaronicusermodeling_amd.train import TiDirTrainer
 dev = torch.device('cuda:0')
 d = tempfile.mkdtemp()
-paths = tidir.synthesize(d, n_instances=8192, X=64, Vde=64, sent_len=(6, 9), n_predicted=(2, 4), seed=21)
+lo = 1 if '--k1' in sys.argv else 2          # --k1: sentences with a single predicted word (no pairwise factor) among them
+paths = tidir.synthesize(d, n_instances=8192, X=64, Vde=64, sent_len=(6, 9), n_predicted=(lo, 4), seed=21)
 tt = TiDirTrainer(paths['ti'], paths['end'], paths['ded'], paths['phi_pmi'], paths['phi_pmi_w1'], paths['phi_ed'], paths['phi_ped'],
                   device=dev, sweeps=3)
 lr, reg = 1e-6, 0.2 / tt.n_total
